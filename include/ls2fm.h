@@ -1,0 +1,213 @@
+/*
+ * ls2fm.h -- C ABI of libls2fm_hip.so: the MI355X (gfx950) implementation of Level-S2fM's
+ * SDF ray-marching / volumetric-rendering hot path.
+ *
+ * Every entry point replaces something the reference reaches through a native extension or
+ * through PyTorch device code on that path; the replaced interface is cited per function
+ * (file:line relative to the reference tree).  The reference-side bindings a maintainer
+ * would add are shown in INTEGRATION.md.
+ *
+ * Conventions (all functions)
+ *   - plain C types only: raw DEVICE pointers, sizes, small by-value descriptor structs that
+ *     live in HOST memory; no torch types
+ *   - all tensors are contiguous, row-major; float = IEEE fp32, indices are uint32/int32/int64
+ *   - the caller owns every buffer (inputs, outputs, gradient accumulators, workspace); the
+ *     library never allocates device memory and keeps no global state
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream); buffers must stay alive until the stream reaches the end of the call
+ *   - gradient outputs documented as "accumulate" are added to with atomics and must be
+ *     zeroed (or hold a running sum) by the caller; all others are overwritten
+ *   - return value: 0 on success, a negative ls2fm_status otherwise (nothing is enqueued on
+ *     LS2FM_ERR_INVALID_ARGUMENT / LS2FM_ERR_UNSUPPORTED); thread-safe for distinct streams
+ */
+#ifndef LS2FM_H
+#define LS2FM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS2FM_ABI_VERSION 1
+#define LS2FM_MAX_LEVELS 16
+#define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
+#define LS2FM_FEAT 16
+#define LS2FM_VIEW_ENC 27      /* Fourier view embedding, 4 octaves (models/base.py:143-151) */
+
+typedef enum ls2fm_status {
+    LS2FM_OK = 0,
+    LS2FM_ERR_INVALID_ARGUMENT = -1,
+    LS2FM_ERR_UNSUPPORTED = -2,
+    LS2FM_ERR_LAUNCH = -3,
+    LS2FM_ERR_WORKSPACE = -4
+} ls2fm_status;
+
+/* Geometry of one multiresolution hash grid (tcnn Grid/Hash/Linear, n_features_per_level = 2).
+ * Built on the host (level-s2fm_official_amd/ls2fm/hashgrid.py) exactly as tcnn's constructor
+ * does (grid_scale / grid_resolution / offset table); replaces the `encoding_config` dict the
+ * reference hands to tinycudann.Encoding (models/base.py:17, :130-139). */
+typedef struct ls2fm_grid_desc {
+    int32_t n_levels;                         /* <= LS2FM_MAX_LEVELS */
+    int32_t n_features;                       /* must be 2 */
+    float scale[LS2FM_MAX_LEVELS];            /* grid_scale(level) */
+    uint32_t resolution[LS2FM_MAX_LEVELS];    /* ceil(scale) + 1 */
+    uint32_t size[LS2FM_MAX_LEVELS];          /* entries in the level */
+    uint32_t offset[LS2FM_MAX_LEVELS + 1];    /* first entry of the level (in entries, not floats) */
+    uint32_t hashed[LS2FM_MAX_LEVELS];        /* 1: coherent prime hash, 0: dense stride walk */
+} ls2fm_grid_desc;
+
+/* Scene / field constants the path reads from `opt` (SURVEY.md section 5 "config / flags"). */
+typedef struct ls2fm_field_desc {
+    float bound_min[3];      /* opt.data.bound_min */
+    float bound_max[3];      /* opt.data.bound_max */
+    float rescale;           /* opt.SDF.VolSDF.rescale        (models/base.py:38-40) */
+    float sdf_scale;         /* +1/scale_mlp if opt.data.inside else -1/scale_mlp (models/SDF.py:66-71) */
+    int32_t bg_sdf;          /* opt.data.inside && opt.data.bg_sdf: sdf = min(sdf, bg_rad - |p|) */
+    float bg_rad;
+    float bgcolor[3];        /* models/Renderer.py:25-31 */
+    int32_t n_samples;       /* opt.SDF.VolSDF.sample_intvs */
+    int32_t dual_field;      /* opt.Ablate_config.dual_field */
+} ls2fm_field_desc;
+
+/* One weight-normed linear layer as the reference stores it (legacy torch weight_norm, dim 0):
+ * W[o][i] = g[o] * v[o][i] / ||v[o]||,  models/base.py:200, :241; state_dict keys App. E. */
+typedef struct ls2fm_linear {
+    const float* weight_v;   /* [out][in] */
+    const float* weight_g;   /* [out]     */
+    const float* bias;       /* [out]     */
+} ls2fm_linear;
+
+typedef struct ls2fm_linear_grad {      /* same shapes; overwritten */
+    float* weight_v;
+    float* weight_g;
+    float* bias;
+} ls2fm_linear_grad;
+
+/* All learnable state of the path (device pointers into the nn.Parameters). */
+typedef struct ls2fm_params {
+    const float* sdf_table;             /* SDF.embed_fn.embedder_obj.params        [n_params] */
+    ls2fm_linear sdf_mlp[2];            /* SDF.SDF_MLP.mlp.{0,1}: (3+2L)->64->17   */
+    const float* beta;                  /* SDF.beta [1] (log-space parameter, SDF.py:28-32) */
+    float beta_speed;                   /* opt.SDF.VolSDF.beta_speed */
+    const float* rad_table;             /* RadF.embed_fn.embedder_obj.params (dual field) or NULL */
+    ls2fm_linear geo_mlp[2];            /* RadF.Geo_enc.mlp.{0,1} (dual field) */
+    ls2fm_linear rad_mlp[3];            /* RadF.Rad_dec.mlp_radiance.{0,1,2}: (49|65)->64->64->3 */
+} ls2fm_params;
+
+typedef struct ls2fm_param_grads {      /* mirrors ls2fm_params */
+    float* sdf_table;                   /* accumulate (atomics) -- caller zeroes */
+    ls2fm_linear_grad sdf_mlp[2];
+    float* beta;                        /* [1] overwritten */
+    float* rad_table;                   /* accumulate */
+    ls2fm_linear_grad geo_mlp[2];
+    ls2fm_linear_grad rad_mlp[3];
+} ls2fm_param_grads;
+
+int ls2fm_abi_version(void);
+const char* ls2fm_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ray / AABB slab test.
+ * Replaces: vren.ray_aabb_intersect as bound by utils/custom_functions.py:28-31
+ *           (called from models/Renderer.py:178-179 and models/SDF.py:120-121).
+ * rays_o, rays_d [n_rays,3] (directions NOT normalised); center, half_size [n_voxels,3].
+ * Outputs: hits_cnt int32[n_rays]; hits_t float[n_rays,max_hits,2] (near clamped to >= 0; -1,-1 in
+ * unused slots); hits_voxel_idx int64[n_rays,max_hits] (-1 in unused slots); slots sorted by near t.
+ */
+int ls2fm_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* center,
+                             const float* half_size, int64_t n_rays, int32_t n_voxels, int32_t max_hits,
+                             int32_t* hits_cnt, float* hits_t, int64_t* hits_voxel_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multiresolution hash-grid encoding (fp32), forward / backward / double backward.
+ * Replaces: tinycudann.Encoding(Grid, Hash, Linear) -- constructor models/base.py:17, forward
+ *           models/base.py:37; its backward is reached through loss.backward() and its double
+ *           backward through SDF.gradient's create_graph=True (models/SDF.py:102-114).
+ * x [n,3] is the NORMALISED position the reference feeds ((p-bmin)/(bmax-bmin), base.py:35); no
+ * clamping.  y [n, L*2] is level-major ([l*2+f]).  dy_dx [n, L*2, 3] optional (NULL to skip).
+ */
+int ls2fm_grid_encode_fwd(const ls2fm_grid_desc* grid, const float* x, const float* table, int64_t n,
+                          float* y, float* dy_dx, void* stream);
+
+/* dtable (accumulate, NULL to skip) += scatter of dy;  dx [n,3] (overwritten, NULL to skip). */
+int ls2fm_grid_encode_bwd(const ls2fm_grid_desc* grid, const float* x, const float* table, const float* dy,
+                          int64_t n, float* dtable, float* dx, void* stream);
+
+/* Backward of the map (dy, table, x) -> dx of ls2fm_grid_encode_bwd, given ddx = dL/d(dx) [n,3]:
+ *   d_dy [n,L*2] (overwritten), dtable (accumulate), dx2 [n,3] (overwritten; mixed second partials).
+ * Any output may be NULL. */
+int ls2fm_grid_encode_bwd_bwd(const ls2fm_grid_desc* grid, const float* x, const float* table,
+                              const float* dy, const float* ddx, int64_t n, float* d_dy, float* dtable,
+                              float* dx2, void* stream);
+
+/* Debug / parity: the 8 level-local corner indices per (point, level): out uint32[n, L, 8]. */
+int ls2fm_grid_indices(const ls2fm_grid_desc* grid, const float* x, int64_t n, uint32_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused SDF evaluation without autograd: hash encode -> 35->64 softplus(100) -> 64->17, sign /
+ * scale_mlp, optional analytic normal d sdf / d p.
+ * Replaces: SDF.infer_sdf (models/SDF.py:55-78) in its no-grad uses (sphere-tracing inner loop
+ *           SDF.py:185-196, mesh sweeps utils/util.py:426-428) and SDF.gradient (SDF.py:102-114)
+ *           when no graph is needed.
+ * p [n,3] world positions.  sdf [n]; feat [n,17] or NULL; normal [n,3] or NULL.
+ * workspace: ls2fm_sdf_eval_workspace_bytes() bytes.
+ */
+int64_t ls2fm_sdf_eval_workspace_bytes(void);
+int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                   const float* p, int64_t n, float* sdf, float* feat, float* normal, void* workspace,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused volumetric rendering, forward.
+ * Replaces: Renderer.forward (models/Renderer.py:51-116) and everything it calls: ray/AABB near-far
+ * (Renderer.py:178), uniform mid-point sampling (Renderer.py:118-127), p = c + d t (utils/camera.py:
+ * 262-266), SDF.infer_sdf + SDF.gradient (SDF.py:55-78, 102-114), RadF.Geometry_feat / infer_embed_v /
+ * infer_app (RadF.py:66-86), SDF.sdf_to_sigma (SDF.py:84-87), Renderer.composite (Renderer.py:33-49)
+ * and the background / depth / normal epilogue (Renderer.py:89-107).
+ * center, ray [n_rays,3].  Outputs: rgb [n_rays,3], sdfs_volume [n_rays,N], normals [n_rays,N,3],
+ * depth_mlp [n_rays], normal_mlp [n_rays,3].
+ * workspace: ls2fm_render_workspace_bytes(...) bytes; its contents are consumed by ls2fm_render_bwd
+ * for the same inputs, so it must be kept untouched between the two calls.
+ */
+int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n_rays);
+int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
+                     const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
+                     const float* ray, int64_t n_rays, float* rgb, float* sdfs_volume, float* normals,
+                     float* depth_mlp, float* normal_mlp, void* workspace, void* stream);
+
+/* Fused backward of ls2fm_render_fwd, including the analytic double backward of the normal path
+ * (normals feed the radiance decoder, normal_mlp and the eikonal loss).
+ * Upstream gradients (any may be NULL = zero): d_rgb [n_rays,3], d_sdfs_volume [n_rays,N],
+ * d_normals [n_rays,N,3], d_depth_mlp [n_rays], d_normal_mlp [n_rays,3].
+ * Parameter gradients go to `grads` in the reference's own parametrisation (weight_v/weight_g/bias,
+ * beta).  d_center / d_ray [n_rays,3] (overwritten) may be NULL; when requested they carry the full
+ * pose gradient (near/far are constants, exactly as in the reference: SURVEY.md 8a row a1).
+ */
+int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
+                     const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
+                     const float* ray, int64_t n_rays, const float* d_rgb, const float* d_sdfs_volume,
+                     const float* d_normals, const float* d_depth_mlp, const float* d_normal_mlp,
+                     const ls2fm_param_grads* grads, float* d_center, float* d_ray, void* workspace,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bidirectional sphere tracing, the no-grad root-find loop.
+ * Replaces: the `while True` of SDF.sphere_tracing (models/SDF.py:149-200) including the AABB
+ * near/far (SDF.py:120-122).  Each ray is advanced independently for up to iters_max trips and
+ * records, per trip k, its pre-update start point (the reference's pts_track) and its far-end
+ * distance; `trips` receives the GLOBAL trip count K of the reference's loop (min(iters_max, the
+ * trip at which no start ray is unfinished)), which the caller uses to truncate the track.
+ * Outputs: near, far [n_rays]; track [n_rays, iters_max+1, 3]; t_end [n_rays, iters_max+1];
+ * trips int32[1].  The differentiable re-evaluation of the track (SDF.py:203-214) is done by the
+ * caller through the autograd-capable ops above.
+ */
+int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                       const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
+                       int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
+                       void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS2FM_H */

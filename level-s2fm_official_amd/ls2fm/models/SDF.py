@@ -1,0 +1,175 @@
+"""SDF field with the reference's class surface (models/SDF.py): hash-grid + tiny MLP -> (sdf, 16-d
+feature), learnable VolSDF beta, normals, surface projection and bidirectional sphere tracing.
+
+Two execution forms share the same Parameters:
+  * general / autograd-composed: HIP hash-grid op (first + second order autograd) + torch dense layers.
+    Used whenever a graph is needed (infer_sdf with grad, `gradient`, `get_surface_pts`, the
+    differentiable tail of `sphere_tracing`).
+  * fused kernels (ls2fm.fused): no-grad `infer_sdf`, the sphere-tracing root-find loop, and -- through
+    Renderer.forward -- the whole render forward/backward.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import fused
+from ..util_layers import get_layer_dims
+from ..utils.custom_functions import RayAABBIntersector
+from .base import Geometry, get_Embedder
+
+
+class SDF(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        lo = torch.tensor(np.array(opt.data.bound_min), dtype=torch.float32)[None, None, :]
+        hi = torch.tensor(np.array(opt.data.bound_max), dtype=torch.float32)[None, None, :]
+        # plain tensors in the reference (created on opt.device); buffers here so .to() moves them,
+        # non-persistent so the state_dict keeps the reference's keys
+        self.register_buffer("bound_max", hi, persistent=False)
+        self.register_buffer("bound_min", lo, persistent=False)
+        self.register_buffer("center", (hi + lo) / 2, persistent=False)
+        self.register_buffer("half_size", (hi - lo) / 2, persistent=False)
+
+        vol = opt.SDF.VolSDF
+        self.rescale = vol.rescale
+        self.beta_speed = vol.beta_speed
+        self.beta = nn.Parameter(torch.tensor([math.log(vol.beta_init) / self.beta_speed], dtype=torch.float32))
+        self.sdf_threshold = float(vol.sdf_threshold)
+        self.iters_max = int(vol.iters_max_st)
+        self.scale_mlp = opt.SDF.NN_Init.scale_mlp
+        self.define_network(opt)
+
+    def define_network(self, opt):
+        self.embed_fn = get_Embedder(opt=opt, input_dim=3)
+        self.SDF_MLP = Geometry(opt=opt, input_dim=self.embed_fn.out_dim, skip=opt.SDF.arch.skip,
+                                tf_init=opt.SDF.NN_Init.tf_init, layers=get_layer_dims(opt.SDF.arch.layers))
+
+    # ------------------------------------------------------------------ field evaluation
+    def _signed(self, feat, xyz):
+        if self.opt.data.inside == True:  # noqa: E712  (opt values may be yaml scalars)
+            sdf = feat[..., :1] / self.scale_mlp
+            if self.opt.data.bg_sdf == True:  # noqa: E712
+                sdf = torch.min(sdf, self.opt.data.bg_rad - xyz.norm(dim=-1, keepdim=True))
+            return sdf
+        return -feat[..., :1] / self.scale_mlp
+
+    def infer_sdf(self, xyz, mode="ret_sdf"):
+        if fused.can_eval_without_graph(self, xyz):
+            sdf, feat = fused.sdf_eval(self, xyz, want_feat=(mode != "ret_sdf"))
+        else:
+            enc = self.embed_fn(xyz, rescale=self.rescale, bound_min=self.bound_min, bound_max=self.bound_max)
+            feat = self.SDF_MLP(enc)
+            sdf = self._signed(feat, xyz)
+        if mode == "ret_sdf":
+            return sdf
+        if mode == "ret_feat":
+            return feat
+        if mode == "ret_all":
+            return sdf, feat
+        raise ValueError(f"unknown mode {mode!r}")
+
+    def forward_ab(self):
+        beta = torch.exp(self.beta * self.beta_speed)
+        return 1.0 / beta, beta
+
+    def sdf_to_sigma(self, sdf, alpha, beta):
+        half_lap = 0.5 * torch.exp(-sdf.abs() / beta)
+        return alpha * torch.where(sdf >= 0, half_lap, 1 - half_lap)
+
+    def density(self, xyzs):
+        alpha, beta = self.forward_ab()
+        return self.sdf_to_sigma(self.infer_sdf(xyzs, mode="ret_sdf"), alpha, beta)
+
+    def gradient(self, p):
+        """d sdf / d p, itself differentiable (callers put its norm inside losses)."""
+        with torch.enable_grad():
+            p.requires_grad_(True)
+            y = self.infer_sdf(p, mode="ret_sdf")
+            (g,) = torch.autograd.grad(outputs=y, inputs=p, grad_outputs=torch.ones_like(y), create_graph=True,
+                                       retain_graph=True, only_inputs=True, allow_unused=True)
+        return g
+
+    def get_surface_pts(self, pts):
+        sdf = self.infer_sdf(pts.detach(), mode="ret_sdf")
+        normals = self.gradient(pts)
+        length = torch.norm(normals, dim=-1, keepdim=True)
+        return pts - normals / length.detach() * sdf, length
+
+    # ------------------------------------------------------------------ sphere tracing
+    def _trace_loop_torch(self, o, d, near, far):
+        """The reference's no-grad root-find loop written with torch ops over the HIP field evaluation
+        (kept as the cross-check of the fused kernel; semantics: SURVEY.md Appendix A.5)."""
+        thr = self.sdf_threshold
+        t_s, t_e = near.clone(), far.clone()
+        p_s = o + t_s[:, None] * d
+        p_e = o + t_e[:, None] * d
+        s_s = self.infer_sdf(p_s)[:, 0].clone()
+        s_e = self.infer_sdf(p_e)[:, 0].clone()
+        live_s = live_e = None
+        track, t_end = [], [t_e]
+        trips = 0
+        while True:
+            s_s = torch.where(s_s.abs() <= thr, torch.zeros_like(s_s), s_s)
+            s_e = torch.where(s_e.abs() <= thr, torch.zeros_like(s_e), s_e)
+            live_s = (s_s.abs() > thr) if live_s is None else live_s & (s_s.abs() > thr)
+            live_e = (s_e.abs() > thr) if live_e is None else live_e & (s_e.abs() > thr)
+            if trips == self.iters_max or not bool(live_s.any()):
+                break
+            trips += 1
+            t_s = t_s + s_s
+            t_e = t_e + s_e
+            t_s = torch.where(t_s > far, far, t_s)
+            t_e = torch.where(t_e > far, far, t_e)
+            track.append(p_s)
+            p_s = o + t_s[:, None] * d
+            p_e = o + t_e[:, None] * d
+            if bool(live_s.any()):
+                s_s = s_s.clone()
+                s_s[live_s] = self.infer_sdf(p_s[live_s])[:, 0]
+            if bool(live_e.any()):
+                s_e = s_e.clone()
+                s_e[live_e] = self.infer_sdf(p_e[live_e])[:, 0]
+            ordered = t_s < t_e
+            live_s, live_e = live_s & ordered, live_e & ordered
+            t_end.append(t_e)
+        if not track:
+            track = [p_s]
+        return torch.stack(track, dim=1), t_end[-1], trips
+
+    def sphere_tracing(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129),
+                       n_secant_steps=8, depth_range=(0.0, 2.4), max_points=3500000, rad=1.0, iter=0,
+                       impl="fused"):
+        """ray0, ray_direction [B,R,3] -> (d_pred [B,R], sdf_last [B*R], sampled_pts [1, <=4096+B*R, 3],
+        finish_mask [B*R,1]).  `d_pred = near + sum_k sdf(track_k)` is differentiable w.r.t. the SDF
+        parameters; the root-find itself runs without a graph.  Unused reference arguments are accepted."""
+        shape2 = ray_direction.shape[:2]
+        o = ray0.reshape(-1, 3)
+        d = ray_direction.reshape(-1, 3)
+        with torch.no_grad():
+            if impl == "fused" and fused.available(self, o):
+                near, far, pts_tracks, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach())
+            else:
+                _, hits_t, _ = RayAABBIntersector.apply(o, d, self.center.view(1, 3), self.half_size.view(1, 3), 1)
+                near, far = hits_t[:, 0, 0], hits_t[:, 0, 1]
+                pts_tracks, t_end, trips = self._trace_loop_torch(o.detach(), d.detach(), near, far)
+        self.last_trips = trips
+        sdf_tracks = self.infer_sdf(pts_tracks.detach(), mode="ret_sdf")          # graph-enabled  [R,K,1]
+        d_pred = sdf_tracks.sum(dim=-2).view(*shape2) + near.view(*shape2)
+        far2 = far.view(*shape2)
+        d_pred = torch.where(d_pred > far2, far2, d_pred)
+        extent = self.bound_max.reshape(-1)[0] - self.bound_min.reshape(-1)[0]
+        finish_mask = sdf_tracks[:, -1, :].abs() < extent / 10 / self.opt.Res
+        # random eikonal sample points (RNG stays on the host side in torch, same call order as the reference)
+        u = torch.rand_like(d_pred)
+        t_up = 1.5 * t_end.view(*shape2)
+        t_up = torch.where(t_up > far2, far2, t_up)
+        t_rand = (1 - u) * t_up + u * near.view(*shape2)
+        sampled = ray0 + t_rand[..., None] * ray_direction
+        pick = torch.randperm(pts_tracks.shape[0])[:4096]
+        sampled = torch.cat([pts_tracks[pick.to(pts_tracks.device)].view(1, -1, 3), sampled.view(1, -1, 3)], dim=1)
+        return d_pred, sdf_tracks[:, -1, 0], sampled, finish_mask

@@ -1,0 +1,73 @@
+"""GPU parity of the general (autograd-composed) form of the path -- HIP hash-grid op with first/second order
+autograd + torch dense layers behind the reference's class surface -- against the golden vectors recorded
+from the reference's own classes, incl. pose gradients, double backward and sphere tracing."""
+import numpy as np
+import pytest
+import torch
+
+import losses
+from conftest import GOLDEN_CASES, load_golden, rel_err
+from helpers import named_grads, product_for
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 2e-5        # fp32, different summation orders (atomics, GPU GEMMs); north star bar is 1e-4
+GTOL = 1e-4
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_infer_sdf_gradient_double_backward(case, manifest):
+    g = load_golden(case)
+    opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
+    pts = torch.from_numpy(g["pts"]).to(DEV)
+    y, feat = sdf.infer_sdf(pts.clone(), mode="ret_all")
+    assert rel_err(y.cpu(), g["pts_sdf"]) < TOL and rel_err(feat.cpu(), g["pts_feat"]) < TOL
+    p_req = pts.clone()
+    nrm = sdf.gradient(p_req)
+    assert rel_err(nrm.cpu(), g["pts_normal"]) < TOL
+    eik = ((nrm.norm(dim=-1) - 1) ** 2).mean() + 0.2 * (nrm * torch.tensor([0.3, -0.5, 0.8], device=DEV)).sum(-1).mean()
+    (eik + 0.1 * y.mean() + 0.05 * (feat[..., 1:] ** 2).mean()).backward()
+    assert rel_err(p_req.grad.cpu(), g["pts_dx"]) < GTOL
+    for k, v in named_grads(sdf).items():
+        assert rel_err(v, g[f"pts_grad/sdf/{k}"]) < GTOL, k
+    surf, nlen = sdf.get_surface_pts(pts.clone())
+    assert rel_err(surf.cpu(), g["surf_pts"]) < TOL and rel_err(nlen.cpu(), g["surf_nlen"]) < TOL
+    if manifest[case]["dual_field"]:
+        assert rel_err(rad.Geometry_feat(pts).cpu(), g["pts_geofeat"]) < TOL
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_render_composed_forward_and_all_gradients(case, manifest):
+    g = load_golden(case)
+    opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
+    center = torch.from_numpy(g["center"]).to(DEV).requires_grad_(True)
+    ray = torch.from_numpy(g["ray"]).to(DEV).requires_grad_(True)
+    ret = ren.forward_composed(opt, center, ray, sdf, rad)
+    for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
+        assert tuple(ret[k].shape) == g[f"ret/{k}"].shape
+        assert rel_err(ret[k].cpu(), g[f"ret/{k}"]) < TOL, k
+    loss = losses.render_loss(ret, torch.from_numpy(g["rgb_target"]).to(DEV), torch.from_numpy(g["nm_dir"]).to(DEV))
+    assert abs(loss.item() - float(g["render_loss"])) < 1e-4 * abs(float(g["render_loss"]))
+    loss.backward()
+    assert rel_err(center.grad.cpu(), g["d_center"]) < GTOL
+    assert rel_err(ray.grad.cpu(), g["d_ray"]) < GTOL
+    for name, mod in (("sdf", sdf), ("rad", rad)):
+        for k, v in named_grads(mod).items():
+            assert rel_err(v, g[f"render_grad/{name}/{k}"]) < GTOL, (name, k)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_sphere_tracing_torch_loop(case, manifest):
+    g = load_golden(case)
+    opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
+    c = torch.from_numpy(g["st_center"]).to(DEV).view(1, -1, 3)
+    d = torch.from_numpy(g["st_ray"]).to(DEV).view(1, -1, 3)
+    d_pred, sdf_last, sampled, finish = sdf.sphere_tracing(c, d, sdf, impl="torch")
+    assert sdf.last_trips == int(g["st_trips"])
+    assert tuple(sampled.shape) == tuple(g["st_sampled_shape"])
+    assert rel_err(d_pred.cpu(), g["st_d_pred"]) < 1e-4
+    assert rel_err(sdf_last.cpu(), g["st_sdf_last"]) < 1e-4
+    assert np.array_equal(finish.cpu().numpy(), g["st_finish"])
+    losses.tracing_loss(d_pred, sdf_last).backward()
+    for k, v in named_grads(sdf).items():
+        assert rel_err(v, g[f"st_grad/sdf/{k}"]) < 2e-4, k

@@ -1,0 +1,130 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/ls2fm.h
+declares, level geometry equals the oracle's, the class surface / state_dict layout is the reference's,
+and the product refuses CPU tensors instead of silently falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ls2fm
+from ls2fm import _lib, hashgrid
+from ls2fm.options import make_options, Options
+from ls2fm.models.SDF import SDF
+from ls2fm.models.RadF import RadF
+from ls2fm.models.Renderer import Renderer
+from ls2fm.models import base as lbase
+from oracle import fields as OF
+from conftest import ROOT, load_golden
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ls2fm.h")).read()
+    declared = sorted(set(re.findall(r"\b(ls2fm_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no prototypes found in include/ls2fm.h"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ls2fm.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared          # the python binding covers the whole header
+    assert lib.ls2fm_abi_version() == 1
+    assert lib.ls2fm_status_string(-2) == b"unsupported configuration"
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_lib.GridDesc) == 4 * (2 + 16 * 4 + 17)
+    assert ctypes.sizeof(_lib.FieldDesc) == 4 * (3 + 3 + 1 + 1 + 1 + 1 + 3 + 1 + 1)
+    assert ctypes.sizeof(_lib.Linear) == 24
+    assert ctypes.sizeof(_lib.Params) == 8 + 48 + 8 + 8 + 8 + 48 + 72
+    assert ctypes.sizeof(_lib.ParamGrads) == 8 + 48 + 8 + 8 + 48 + 72
+
+
+@pytest.mark.parametrize("ds", ["DTU", "ETH3D", "BlendedMVS", "scannet"])
+@pytest.mark.parametrize("L,log2_T", [(16, 19), (8, 10), (4, 11), (5, 14)])
+def test_grid_desc_equals_oracle_table(ds, L, log2_T):
+    cfg = OF.dataset_config(ds, n_levels=L, log2_hashmap_size=log2_T)
+    t = cfg.table()
+    d = hashgrid.build_grid_desc(L, 2, log2_T, 16, t.per_level_scale)
+    assert np.array_equal(np.array(d.scale[:L], np.float32).view(np.uint32), t.scale.view(np.uint32))
+    assert list(d.resolution[:L]) == list(t.resolution) and list(d.size[:L]) == list(t.size)
+    assert list(d.offset[:L + 1]) == list(t.offset) and [bool(h) for h in d.hashed[:L]] == list(t.hashed)
+    assert hashgrid.n_table_floats(d) == t.n_params
+
+
+def test_state_dict_layout_is_the_references(manifest):
+    for dual in (False, True):
+        opt = make_options("DTU", device="cpu", dual_field=dual)
+        ref = manifest["_state_dict_full_dtu"]["dual" if dual else "single"]
+        assert {k: list(v.shape) for k, v in SDF(opt).state_dict().items()} == ref["sdf"]
+        assert {k: list(v.shape) for k, v in RadF(opt).state_dict().items()} == ref["rad"]
+    geo = manifest["_hash_geometry"]
+    for ds in ("DTU", "ETH3D", "BlendedMVS", "scannet"):
+        e = lbase.get_Embedder(make_options(ds, device="cpu"), input_dim=3, input_choice="Hash")
+        assert e.out_dim == geo[ds]["out_dim"] == 35
+        assert hashgrid.n_table_floats(e.embedder_obj.desc) == geo[ds]["n_params"]
+
+
+def test_class_surface():
+    opt = make_options("BlendedMVS", device="cpu", dual_field=True)
+    sdf, rad, ren = SDF(opt), RadF(opt), Renderer(opt)
+    for attr in ("bound_max", "bound_min", "center", "half_size", "rescale", "beta_speed", "beta", "sdf_threshold",
+                 "iters_max", "scale_mlp", "embed_fn", "SDF_MLP"):
+        assert hasattr(sdf, attr), attr
+    for m in ("infer_sdf", "forward_ab", "sdf_to_sigma", "get_surface_pts", "gradient", "sphere_tracing"):
+        assert callable(getattr(sdf, m))
+    for attr in ("embed_fn", "Geo_enc", "embed_fn_v", "Rad_dec", "Geometry_feat", "infer_embed_v", "infer_app"):
+        assert hasattr(rad, attr), attr
+    for m in ("forward", "composite", "sample_depth", "volsdf_sampling", "sdf_to_sigma", "error_bound", "sample_pdf",
+              "opacity_to_sample", "sample_depth_from_opacity"):
+        assert callable(getattr(ren, m))
+    assert tuple(sdf.bound_max.shape) == (1, 1, 3) and tuple(ren.center.shape) == (1, 1, 3)
+    assert ren.bgcolor.tolist() == [1.0, 1.0, 1.0]
+    assert sdf.iters_max == 20 and sdf.scale_mlp == 3.0
+    a, b = sdf.forward_ab()
+    assert abs(b.item() - 0.05) < 1e-7 and abs(a.item() - 20.0) < 1e-4
+    # geometric init: hash columns of the first layer are zero, last-layer bias is -radius
+    assert float(sdf.SDF_MLP.mlp[0].weight_v[:, 3:].abs().max()) == 0.0
+    assert torch.allclose(sdf.SDF_MLP.mlp[1].bias, torch.full((17,), -1.0))
+    assert rad.Rad_dec.mlp_radiance[0].weight_v.shape == (64, 65)
+    opt1 = make_options("DTU", device="cpu", dual_field=False)
+    assert RadF(opt1).Rad_dec.mlp_radiance[0].weight_v.shape == (64, 49)
+    assert not hasattr(RadF(opt1), "Geo_enc")
+
+
+def test_fourier_embedding_matches_reference_golden():
+    g = load_golden("fourier")
+    emb = lbase.get_Embedder(None, input_dim=3, input_choice="Fourier")
+    out = emb(torch.from_numpy(g["d"]))
+    assert out.shape[-1] == emb.out_dim == 27
+    assert np.abs(out.numpy() - g["out"]).max() < 1e-6
+
+
+def test_cpu_tensors_are_refused_not_silently_served():
+    opt = make_options("DTU", device="cpu", hash_encoding=dict(n_levels=4, n_features_per_level=2,
+                                                               log2_hashmap_size=10, base_resolution=16))
+    sdf = SDF(opt)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sdf.infer_sdf(torch.zeros(4, 3))
+    ren = Renderer(opt)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ren.forward(opt, torch.zeros(1, 2, 3), torch.ones(1, 2, 3), sdf, RadF(opt))
+
+
+def test_composite_helper_matches_golden():
+    """Renderer.composite is plain torch (used by the general form); check it against the reference"""
+    g = load_golden("dtu_single")
+    ren = Renderer(make_options("DTU", device="cpu"))
+    rgb, prob = ren.composite(torch.from_numpy(g["comp_ray"]), torch.from_numpy(g["comp_rgb_s"]),
+                              torch.from_numpy(g["comp_sig_s"]), torch.from_numpy(g["comp_t_s"]))
+    assert np.abs(rgb.numpy() - g["comp_rgb"]).max() < 1e-5
+    assert np.abs(prob.numpy() - g["comp_prob"]).max() < 1e-6
+
+
+def test_options_attribute_dict():
+    o = Options(a=dict(b=dict(c=3)), d=[1, 2])
+    assert o.a.b.c == 3 and o["a"]["b"]["c"] == 3 and o.d == [1, 2]
+    o.a.b.c = 4
+    assert o.a.b.c == 4
+    with pytest.raises(AttributeError):
+        _ = o.missing
