@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Benchmark of the Level-S2fM render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic rays, forward + backward:
+Renderer.forward (fused HIP kernels) -> loss head -> loss.backward() (fused HIP backward), and for N > 1 the
+RCCL all-reduce of the gradients.  Workload (BASELINE.json configs[1]): ETH3D bounds (+-5, scale_mlp 5,
+inside = false), 1024 rays x 128 samples per GPU, full L16/F2/T19 hash grids, dual field (SDF + radiance grid),
+synthetic inputs per BASELINE.md section 3.  Weak scaling: every rank renders its own 1024 rays.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "level-s2fm_official_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+F32_PEAK_TFLOPS = 157.3        # f32 vector / f32 MFMA peak (same number on gfx950)
+
+
+def synthetic_rays(n_rays, s, device, seed=0):
+    """center = (0,0,-2.5 s); ray = (0,0,1) + 0.15 N(0,1), unnormalised"""
+    g = torch.Generator().manual_seed(seed)
+    center = torch.tensor([0.0, 0.0, -2.5 * s]).repeat(1, n_rays, 1)
+    ray = torch.tensor([0.0, 0.0, 1.0]).repeat(1, n_rays, 1) + 0.15 * torch.randn(1, n_rays, 3, generator=g)
+    return center.to(device), ray.to(device)
+
+
+def randomize(modules, seed=0):
+    """tables U(-0.1, 0.1), first-layer hash columns N(0, 0.05): the hash path is live (SURVEY C-12)"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in modules:
+            for name, p in mod.named_parameters():
+                if name.endswith("embedder_obj.params"):
+                    p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * 0.1).to(p.device))
+                if name.endswith("mlp.0.weight_v") and "Rad_dec" not in name:
+                    p[:, 3:] = (torch.randn(p[:, 3:].shape, generator=g) * 0.05).to(p.device)
+                    gname = name.replace("weight_v", "weight_g")
+                    dict(mod.named_parameters())[gname].copy_(p.norm(dim=1, keepdim=True))
+
+
+def loss_head(ret):
+    """10^3 L1(rgb, 0.5) + 10^2 L1(|n|, 1) + smoothL1(depth)   (weights: options/LevelS2fM.yaml:102-107)"""
+    rgb = (ret["rgb"] - 0.5).abs().mean()
+    eik = (ret["normals"].norm(dim=-1) - 1.0).abs().mean()
+    dep = torch.nn.functional.smooth_l1_loss(ret["depth_mlp"], torch.zeros_like(ret["depth_mlp"]))
+    return 1e3 * rgb + 1e2 * eik + dep
+
+
+def cpu_baseline(dataset, dual, n_samples, budget_s=20.0):
+    """The CPU oracle (a torch restatement of the reference's op sequence, pinned against the reference's golden
+    vectors) timed on the host cores of this box on a bounded sample of the same workload."""
+    from oracle import fields as OF
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cfg = OF.dataset_config(dataset, dual_field=dual, sample_intvs=n_samples)
+    gen = torch.Generator().manual_seed(0)
+    sd, rd = OF.init_sdf_state(cfg, gen), OF.init_rad_state(cfg, gen)
+    OF.randomize_state(sd, gen)
+    OF.randomize_state(rd, gen)
+    sd = OF.to_dtype(sd, torch.float32, True)
+    rd = OF.to_dtype(rd, torch.float32, True)
+    n_rays = 128
+    s = cfg.bound_max[0]
+    center, ray = synthetic_rays(n_rays, s, "cpu")
+    table = cfg.table()
+
+    def step():
+        for st in (sd, rd):
+            for v in st.values():
+                v.grad = None
+        loss_head(OF.render(cfg, center, ray, sd, rd, table, table)).backward()
+
+    step()                                    # warm-up (allocators, thread pool)
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 50):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of {n_rays} rays x {n_samples} samples (same field config, torch CPU, "
+                      f"{threads} threads), {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rays", type=int, default=1024)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--dataset", default="ETH3D")
+    ap.add_argument("--single-field", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product has no CPU path); the CPU figure is the "
+                         "`cpu_baseline` leg of the GPU run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ls2fm import _lib, fused
+    from ls2fm.dist import GradAllReducer
+    from ls2fm.options import make_options
+    from ls2fm.models.SDF import SDF
+    from ls2fm.models.RadF import RadF
+    from ls2fm.models.Renderer import Renderer
+
+    lib = _lib.load()
+    dual = not args.single_field
+    opt = make_options(args.dataset, device=str(dev), dual_field=dual, sample_intvs=args.samples)
+    torch.manual_seed(0)
+    sdf, rad, ren = SDF(opt).to(dev), RadF(opt).to(dev), Renderer(opt)
+    randomize([sdf, rad], seed=0)                         # identical replicas on every rank
+    s = float(opt.data.bound_max[0])
+    center, ray = synthetic_rays(args.rays, s, dev, seed=rank)      # each rank: its own view's rays
+    assert fused.can_render(ren, opt, center, ray, sdf, rad), "fused HIP path not taken"
+    params = list(sdf.parameters()) + list(rad.parameters())
+    reducer = GradAllReducer(params) if world > 1 else None
+
+    def step():
+        for p in params:
+            p.grad = None
+        ret = ren.forward(opt, center, ray, sdf, rad)
+        loss_head(ret).backward()
+        if reducer is not None:
+            reducer.all_reduce()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    has_prof = hasattr(lib, "ls2fm_profile_enable")
+    if has_prof:
+        lib.ls2fm_profile_reset()
+        lib.ls2fm_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if has_prof:
+        lib.ls2fm_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = args.rays * world * args.steps / dt
+    roofline = None
+    if has_prof and rank == 0:
+        from ls2fm.profile import dominant_kernel_roofline
+        roofline = dominant_kernel_roofline(lib, n_points=args.rays * args.samples, dual=dual,
+                                            hbm_peak_gbs=HBM_PEAK_GBS, f32_peak_tflops=F32_PEAK_TFLOPS)
+    out = {
+        "metric": "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
+                               f"{'dual' if dual else 'single'} field, L16/F2/T19 hash grid, fwd+loss+bwd"
+                               + (", RCCL grad all-reduce" if world > 1 else ""),
+                   "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "dual_field": dual,
+                   "parallelism": f"dp{world} (rays sharded by view)"},
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.dataset, dual, args.samples)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,8 @@ typedef struct ls2fm_field_desc {
     float bound_min[3];      /* opt.data.bound_min */
     float bound_max[3];      /* opt.data.bound_max */
     float rescale;           /* opt.SDF.VolSDF.rescale        (models/base.py:38-40) */
-    float sdf_scale;         /* +1/scale_mlp if opt.data.inside else -1/scale_mlp (models/SDF.py:66-71) */
+    float scale_mlp;         /* opt.SDF.NN_Init.scale_mlp: sdf = +-f0 / scale_mlp (true division) */
+    int32_t inside;          /* opt.data.inside: sign of the sdf (models/SDF.py:66-71) */
     int32_t bg_sdf;          /* opt.data.inside && opt.data.bg_sdf: sdf = min(sdf, bg_rad - |p|) */
     float bg_rad;
     float bgcolor[3];        /* models/Renderer.py:25-31 */
@@ -96,10 +97,10 @@ typedef struct ls2fm_params {
 } ls2fm_params;
 
 typedef struct ls2fm_param_grads {      /* mirrors ls2fm_params */
-    float* sdf_table;                   /* accumulate (atomics) -- caller zeroes */
+    float* sdf_table;                   /* overwritten in full (LDS-slab scatter, no atomics) */
     ls2fm_linear_grad sdf_mlp[2];
     float* beta;                        /* [1] overwritten */
-    float* rad_table;                   /* accumulate */
+    float* rad_table;                   /* overwritten in full */
     ls2fm_linear_grad geo_mlp[2];
     ls2fm_linear_grad rad_mlp[3];
 } ls2fm_param_grads;

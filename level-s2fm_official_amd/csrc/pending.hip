@@ -5,14 +5,6 @@
 extern "C" int64_t ls2fm_sdf_eval_workspace_bytes(void) { return 0; }
 extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc*, const ls2fm_grid_desc*, const ls2fm_params*, const float*,
                               int64_t, float*, float*, float*, void*, void*) { return LS2FM_ERR_UNSUPPORTED; }
-extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc*, const ls2fm_grid_desc*, int64_t) { return 0; }
-extern "C" int ls2fm_render_fwd(const ls2fm_field_desc*, const ls2fm_grid_desc*, const ls2fm_grid_desc*,
-                                const ls2fm_params*, const float*, const float*, int64_t, float*, float*, float*,
-                                float*, float*, void*, void*) { return LS2FM_ERR_UNSUPPORTED; }
-extern "C" int ls2fm_render_bwd(const ls2fm_field_desc*, const ls2fm_grid_desc*, const ls2fm_grid_desc*,
-                                const ls2fm_params*, const float*, const float*, int64_t, const float*, const float*,
-                                const float*, const float*, const float*, const ls2fm_param_grads*, float*, float*,
-                                void*, void*) { return LS2FM_ERR_UNSUPPORTED; }
 extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc*, const ls2fm_grid_desc*, const ls2fm_params*, const float*,
                                   const float*, int64_t, float, int32_t, float*, float*, float*, float*, int32_t*,
                                   void*, void*) { return LS2FM_ERR_UNSUPPORTED; }

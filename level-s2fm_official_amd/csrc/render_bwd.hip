@@ -1,0 +1,630 @@
+// Fused volumetric-rendering backward for gfx950, including the analytic double backward of the normal
+// path.  Replaces what loss.backward() traverses for Renderer.forward:
+// composite / sigma / radiance / Geometry MLPs / SDF.gradient's create_graph graph / tcnn backward kernels.
+//
+//   shade_bwd     block per ray, lane per sample: composite backward (prefix + suffix scans), sigma and
+//                 radiance backward, then the SDF MLP backward with the extra double-backward terms; per-sample
+//                 operands of the weight-gradient GEMMs are written as SoA channels
+//   wgrad         dW = A[M x P] * B[N x P]^T  with P = all sample points as the contraction axis:
+//                 f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32) from LDS-staged tiles, split over P, partials to HBM
+//   wgrad_reduce  sum of the split-P partials
+//   slab scatter  (slab_scatter.hip) LDS-owned slabs of the table gradient, no table-wide global atomics; for the SDF
+//                 grid the first-order (trilinear) and double-backward (derivative-weight) terms in one add
+//   finalize      un-collapse the radiance chain, weight-norm backward, d beta
+#include <cstdlib>
+#include <initializer_list>
+
+#include "render_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------- shade_bwd
+struct Upstream {                  // dL/d(outputs of render_fwd); any pointer may be null (= zeros)
+    const float* d_rgb;            // [R,3]
+    const float* d_sdfs;           // [R,N]
+    const float* d_normals;        // [R,N,3]
+    const float* d_depth;          // [R]
+    const float* d_nm;             // [R,3]
+};
+
+template <bool DUAL, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+shade_bwd_kernel(FieldC fc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
+                 const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
+                 Upstream up, float* __restrict__ out) {
+    __shared__ float s_part[16][8];
+    __shared__ double s_db[16];
+    const int N = fc.n_samples;
+    const int64_t r = blockIdx.x;
+    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    const bool live = n < N;
+    const int nn = live ? n : N - 1;
+    const int64_t i = r * N + nn;
+    const int64_t P = w.p_pad;
+    const RayGeom g = load_ray(fc, center, ray, r);
+    const float t = sample_depth(g, nn, N);
+    const float t_next = sample_depth(g, nn + 1, N);
+    const float t_last = sample_depth(g, N - 1, N);
+    float p[3], x[3];
+    sample_position(fc, g, t, p, x);
+    const float ray_len = sqrtf(g.d[0] * g.d[0] + g.d[1] * g.d[1] + g.d[2] * g.d[2]);
+
+    // ---- upstream gradients of the ray outputs
+    float g_rgb[3], g_nm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g_rgb[c] = up.d_rgb ? up.d_rgb[r * 3 + c] : 0.f;
+        g_nm[c] = up.d_nm ? up.d_nm[r * 3 + c] : 0.f;
+    }
+    const float g_dep = up.d_depth ? up.d_depth[r] : 0.f;
+
+    // ---- forward per-sample values saved by shade_fwd
+    const float sdf = fws[w.sdfv + i];
+    float nrm[3], col[3], n_last[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        nrm[a] = fws[w.nrm + a * P + i];
+        col[a] = fws[w.rgbs + a * P + i];
+        n_last[a] = fws[w.nrm + a * P + r * N + N - 1];
+    }
+    const float alpha = pk->alpha, beta = pk->beta;
+    const float lap = 0.5f * expf(-fabsf(sdf) / beta);
+    const float sigma = alpha * (sdf >= 0.f ? lap : 1.0f - lap);
+
+    // ---- composite forward quantities (same scans as shade_fwd)
+    const bool interval = n < N - 1;
+    const float delta = (t_next - t) * ray_len;
+    const float tau = interval ? sigma * delta : 0.f;
+    const float incl = wave_scan_incl(tau, lane);
+    if (lane == 63) s_part[wave][0] = incl;
+    __syncthreads();
+    float before = incl - tau;
+    for (int q = 0; q < wave; ++q) before += s_part[q][0];
+    const float trans = expf(-before), ex = expf(-tau);
+    const float wgt = interval ? trans * (1.0f - ex) : 0.f;
+
+    // ---- composite backward:  L = sum_i w_i (V_i - B) + B ;  dL/dtau_k = U_k T_k e^{-tau_k} - sum_{i>k} U_i w_i
+    float b_term = g_dep * t_last, v_term = g_dep * t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        b_term = fmaf(g_rgb[c], fc.bg[c], b_term);
+        b_term = fmaf(g_nm[c], n_last[c], b_term);
+        v_term = fmaf(g_rgb[c], col[c], v_term);
+        v_term = fmaf(g_nm[c], nrm[c], v_term);
+    }
+    const float u_w = interval ? (v_term - b_term) * wgt : 0.f;
+    const float incl_uw = wave_scan_incl(u_w, lane);
+    const float wsum_w = wave_sum(wgt);
+    if (lane == 63) s_part[wave][1] = incl_uw;
+    if (lane == 0) s_part[wave][2] = wsum_w;
+    __syncthreads();
+    float uw_total = 0.f, opacity = 0.f, uw_before = 0.f;
+    for (int q = 0; q < n_waves; ++q) {
+        uw_total += s_part[q][1];
+        opacity += s_part[q][2];
+        if (q < wave) uw_before += s_part[q][1];
+    }
+    const float suffix = uw_total - (incl_uw + uw_before);
+    const float d_tau = interval ? (v_term - b_term) * trans * ex - suffix : 0.f;
+    const float g_sigma = d_tau * delta;
+    const float rest = 1.0f - opacity;
+
+    // ---- per-sample upstream of colour, normal, sdf
+    float gc[3], gn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        gc[a] = wgt * g_rgb[a];
+        float v = wgt * g_nm[a];
+        if (n == N - 1) v += rest * g_nm[a];
+        if (live && up.d_normals) v += up.d_normals[i * 3 + a];
+        gn[a] = live ? v : 0.f;
+    }
+    float g_sdf = (live && up.d_sdfs) ? up.d_sdfs[i] : 0.f;
+
+    // ---- sigma backward (+ d beta)
+    {
+        const float abs_s = fabsf(sdf);
+        const float dsig_ds = sdf != 0.f ? -alpha * lap / beta : 0.f;
+        g_sdf = fmaf(g_sigma, dsig_ds, g_sdf);
+        const float inv_b2 = 1.0f / (beta * beta);
+        const float dsig_db = sdf >= 0.f ? lap * (abs_s * inv_b2 / beta - inv_b2)
+                                         : -(1.0f - lap) * inv_b2 - lap * abs_s * inv_b2 / beta;
+        // d beta is one scalar summed over every sample with heavy cancellation: accumulate it in fp64
+        double db = (double)g_sigma * (double)dsig_db;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) db += __shfl_xor(db, o, 64);
+        if (lane == 0) s_db[wave] = db;
+    }
+
+    // ---- collapsed radiance decoder backward
+    float dz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dz[c] = gc[c] * col[c] * (1.0f - col[c]);
+    float gf[kOut], gf2[kOut];
+    gf[0] = fc.kappa * g_sdf;
+    gf2[0] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s1 = fmaf(pk->wc[c][33 + m], dz[c], s1);
+            if (DUAL) s2 = fmaf(pk->wc[c][49 + m], dz[c], s2);
+        }
+        gf[1 + m] = s1;
+        gf2[1 + m] = s2;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gn[a] = fmaf(pk->wc[c][3 + a], dz[c], gn[a]);
+    // per-ray sums of dz (view-embedding columns of the decoder) and the d beta total
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float s = wave_sum(dz[c]);
+        if (lane == 0) s_part[wave][4 + c] = s;
+    }
+    __syncthreads();
+    if (n < 3) {
+        float s = 0.f;
+        for (int q = 0; q < n_waves; ++q) s += s_part[q][4 + n];
+        out[w.dzr + n * w.r_pad + r] = s;
+    }
+    if (n == 3) {
+        double s = 0.0;
+        for (int q = 0; q < n_waves; ++q) s += s_db[q];
+        atomicAdd(reinterpret_cast<double*>(out + w.dbeta), s);
+    }
+    if (n < kView) out[w.renc + n * w.r_pad + r] = view_component(g.d, n);
+
+    // ---- SDF MLP backward with the double-backward terms of the normal path (A.4)
+    float u[kInMax], v[kInMax], de[kInMax], rr[kInMax];
+    float gns[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float gnk = fc.kappa * gn[a];
+        u[a] = p[a] / fc.rescale;
+        v[a] = gnk / fc.rescale;
+        gns[a] = gnk * fc.inv_ext[a];
+    }
+#pragma unroll
+    for (int c = 0; c < kInMax - 3; ++c) {
+        const bool on = c < ch1;
+        u[3 + c] = on ? fws[w.e1 + c * P + i] : 0.f;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc = fmaf(on ? fws[w.j1 + (c * 3 + a) * P + i] : 0.f, gns[a], acc);
+        v[3 + c] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < kInMax; ++k) { de[k] = 0.f; rr[k] = 0.f; }
+    {
+        const float* __restrict__ rec = pk->sdf;
+#pragma unroll 1
+        for (int j = 0; j < kHidden; ++j) {
+            const float* __restrict__ wj = rec + j * kRecStride;
+            float a0 = wj[kRecB0], a1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int k = 0; k + 1 < kInMax; k += 2) {
+                a0 = fmaf(wj[k], u[k], a0);
+                a1 = fmaf(wj[k + 1], u[k + 1], a1);
+                q0 = fmaf(wj[k], v[k], q0);
+                q1 = fmaf(wj[k + 1], v[k + 1], q1);
+            }
+            a0 = fmaf(wj[kInMax - 1], u[kInMax - 1], a0);
+            q0 = fmaf(wj[kInMax - 1], v[kInMax - 1], q0);
+            float h, s1, s2;
+            softplus100(a0 + a1, h, s1, s2);
+            const float q = q0 + q1;
+            float tj = 0.f;
+#pragma unroll
+            for (int o = 0; o < kOut; ++o) tj = fmaf(wj[kRecW1 + o], gf[o], tj);
+            const float w10 = wj[kRecW1];
+            const float da = fmaf(s1, tj, s2 * w10 * q);
+            const float gj = s1 * w10;
+#pragma unroll
+            for (int k = 0; k < kInMax; ++k) {
+                de[k] = fmaf(wj[k], da, de[k]);
+                rr[k] = fmaf(wj[k], gj, rr[k]);
+            }
+            if (live) {
+                out[w.da + j * P + i] = da;
+                out[w.g + j * P + i] = gj;
+                out[w.h + j * P + i] = h;
+                out[w.sq + j * P + i] = s1 * q;
+            }
+        }
+    }
+    if (live) {
+        // scatter payload of the SDF grid: one 32-byte record per (level, point)
+#pragma unroll
+        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
+            if (2 * l < ch1) {
+                float4* dst = reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + i) * 8);
+                dst[0] = make_float4(de[3 + 2 * l], de[4 + 2 * l], rr[3 + 2 * l], rr[4 + 2 * l]);
+                dst[1] = make_float4(gns[0], gns[1], gns[2], 0.f);
+            }
+#pragma unroll
+        for (int k = 0; k < kInMax; ++k) out[w.v + k * P + i] = v[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            out[w.pu + a * P + i] = u[a];
+            out[w.p3 + a * P + i] = p[a];
+            out[w.dz + a * P + i] = dz[a];
+        }
+#pragma unroll
+        for (int o = 0; o < kOut; ++o) out[w.gf + o * P + i] = gf[o];
+    }
+
+    // ---- second field: plain first-order backward of its Geometry MLP
+    if (DUAL) {
+#pragma unroll
+        for (int c = 0; c < kInMax - 3; ++c) u[3 + c] = c < ch2 ? fws[w.e2 + c * P + i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < kInMax; ++k) de[k] = 0.f;
+        const float* __restrict__ rec = pk->geo;
+#pragma unroll 1
+        for (int j = 0; j < kHidden; ++j) {
+            const float* __restrict__ wj = rec + j * kRecStride;
+            float a0 = wj[kRecB0], a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k + 1 < kInMax; k += 2) {
+                a0 = fmaf(wj[k], u[k], a0);
+                a1 = fmaf(wj[k + 1], u[k + 1], a1);
+            }
+            a0 = fmaf(wj[kInMax - 1], u[kInMax - 1], a0);
+            float h, s1, s2;
+            softplus100(a0 + a1, h, s1, s2);
+            float tj = 0.f;
+#pragma unroll
+            for (int o = 1; o < kOut; ++o) tj = fmaf(wj[kRecW1 + o], gf2[o], tj);
+            const float da = s1 * tj;
+#pragma unroll
+            for (int k = 0; k < kInMax; ++k) de[k] = fmaf(wj[k], da, de[k]);
+            if (live) {
+                out[w.da2 + j * P + i] = da;
+                out[w.h2 + j * P + i] = h;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
+                if (2 * l < ch2)
+                    *reinterpret_cast<float2*>(out + w.rec2 + ((int64_t)l * P + i) * 2) = make_float2(de[3 + 2 * l], de[4 + 2 * l]);
+#pragma unroll
+            for (int o = 0; o < kOut; ++o) out[w.gf2 + o * P + i] = gf2[o];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- wgrad (MFMA)
+struct Seg { const float* base; int rows; int pad; };
+struct WJob {
+    Seg a[2];
+    Seg b[5];
+    int m, n;             // live rows of A (<= 64) and of B (<= 80)
+    int64_t k, ld;        // contraction length and channel stride
+    int out_off, out_ld;  // destination inside the reduced-gradient buffer
+};
+struct WJobs { WJob job[kWgradJobs]; };
+
+constexpr int kTileK = 64;
+constexpr int kLdsLd = kTileK + 2;      // row stride == 2 (mod 32) banks: conflict-free MFMA operand reads
+
+template <int NSEG>
+__device__ __forceinline__ const float* seg_row(const Seg (&s)[NSEG], int row, int64_t ld) {
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < NSEG; ++q) {
+        if (row < base + s[q].rows) return s[q].base ? s[q].base + (int64_t)(row - base) * ld : nullptr;   // null base: zero rows
+        base += s[q].rows;
+    }
+    return nullptr;
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_kernel(WJobs jobs, int nblk, float* __restrict__ part) {
+    __shared__ float As[64 * kLdsLd];
+    __shared__ float Bs[80 * kLdsLd];
+    const WJob& J = jobs.job[blockIdx.y];
+    const int64_t k_begin = (int64_t)blockIdx.x * kWgradKB;
+    if (k_begin >= J.k) return;
+    const int64_t k_end = k_begin + kWgradKB < J.k ? k_begin + kWgradKB : J.k;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (J.n + 15) / 16;
+    f32x4 acc[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Staging is software pipelined through registers: the global loads of tile t+1 are in flight while the
+    // MFMAs consume tile t from LDS (each row of a tile is one coalesced 256-byte segment).
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4;
+    const float* src_row[9];
+#pragma unroll
+    for (int pass = 0; pass < 9; ++pass) {
+        const int row = pass * 16 + lrow;                     // 0..143: A rows 0..63, then B rows 0..79
+        const int rr = row < 64 ? row : row - 64;
+        src_row[pass] = nullptr;
+        if (row < 64) { if (rr < J.m) src_row[pass] = seg_row<2>(J.a, rr, J.ld); }
+        else          { if (rr < J.n) src_row[pass] = seg_row<5>(J.b, rr, J.ld); }
+    }
+    float4 stage[9];
+    auto load_stage = [&](int64_t kt) {
+#pragma unroll
+        for (int pass = 0; pass < 9; ++pass) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src_row[pass]) {
+                val = *reinterpret_cast<const float4*>(src_row[pass] + kt + lcol);
+                const int64_t k0 = kt + lcol;
+                if (k0 + 0 >= J.k) val.x = 0.f;
+                if (k0 + 1 >= J.k) val.y = 0.f;
+                if (k0 + 2 >= J.k) val.z = 0.f;
+                if (k0 + 3 >= J.k) val.w = 0.f;
+            }
+            stage[pass] = val;
+        }
+    };
+    load_stage(k_begin);
+    for (int64_t kt = k_begin; kt < k_end; kt += kTileK) {
+#pragma unroll
+        for (int pass = 0; pass < 9; ++pass) {
+            const int row = pass * 16 + lrow;
+            float* dst = (row < 64 ? As + row * kLdsLd : Bs + (row - 64) * kLdsLd) + lcol;
+            *reinterpret_cast<float2*>(dst) = make_float2(stage[pass].x, stage[pass].y);
+            *reinterpret_cast<float2*>(dst + 2) = make_float2(stage[pass].z, stage[pass].w);
+        }
+        __syncthreads();
+        if (kt + kTileK < k_end) load_stage(kt + kTileK);
+        if (wave * 16 < J.m) {
+            const float* a_base = As + (wave * 16 + (lane & 15)) * kLdsLd + (lane >> 4);
+            const float* b_base = Bs + (lane & 15) * kLdsLd + (lane >> 4);
+#pragma unroll 4
+            for (int ks = 0; ks < kTileK / 4; ++ks) {
+                const float a = a_base[ks * 4];
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    if (q < n_tiles)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_base[q * 16 * kLdsLd + ks * 4], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D layout (16x16): column = lane & 15, row = 4 * (lane >> 4) + reg
+    float* dst = part + ((int64_t)blockIdx.y * nblk + blockIdx.x) * kWgradTile;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (q < n_tiles) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                dst[(wave * 16 + 4 * (lane >> 4) + reg) * 80 + q * 16 + (lane & 15)] = acc[q][reg];
+        }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(WJobs jobs, int nblk, const float* __restrict__ part, float* __restrict__ wg) {
+    // 64 output elements per workgroup, 4 threads per element striding over the split-P partials
+    __shared__ float s_sum[4][64];
+    const WJob& J = jobs.job[blockIdx.y];
+    const int sub = threadIdx.x >> 6, el = threadIdx.x & 63;
+    const int e = blockIdx.x * 64 + el;
+    const int mi = e / 80, ni = e % 80;
+    const bool on = mi < J.m && ni < J.n;
+    const int live_blocks = (int)((J.k + kWgradKB - 1) / kWgradKB);
+    float s = 0.f;
+    if (on)
+        for (int b = sub; b < live_blocks; b += 4)
+            s += part[((int64_t)blockIdx.y * nblk + b) * kWgradTile + mi * 80 + ni];
+    s_sum[sub][el] = s;
+    __syncthreads();
+    if (sub == 0 && on)     // two jobs may target the same matrix (dW0): a + b == b + a, still deterministic
+        atomicAdd(wg + J.out_off + mi * J.out_ld + ni, (s_sum[0][el] + s_sum[1][el]) + (s_sum[2][el] + s_sum[3][el]));
+}
+
+// ------------------------------------------------------------------------------------------- finalize
+// weight-norm backward of a whole layer:  W = (g/||v||) v  ->  dg = <dW,v>/||v|| ; dv = (g/||v||) dW - g <dW,v>/||v||^3 v.
+// Called by all 256 threads; 16 lanes cooperate on a row (coalesced accesses, 16-wide shuffle reduction).
+__device__ void weight_norm_bwd_rows(const float* v, const float* g, const float* dw, int dw_ld, int rows, int n_in,
+                                     float* dv, float* dg, int tid) {
+    const int sub = tid & 15;
+    for (int row0 = 0; row0 < rows; row0 += 16) {
+        const int row = row0 + (tid >> 4);
+        const bool on = row < rows;
+        float ss = 0.f, dot = 0.f;
+        if (on)
+            for (int k = sub; k < n_in; k += 16) {
+                const float x = v[row * n_in + k];
+                ss = fmaf(x, x, ss);
+                dot = fmaf(dw[row * dw_ld + k], x, dot);
+            }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) { ss += __shfl_xor(ss, m, 16); dot += __shfl_xor(dot, m, 16); }
+        if (on) {
+            const float nrm = sqrtf(ss);
+            const float s = g[row] / nrm;
+            const float c = g[row] * dot / (nrm * nrm * nrm);
+            for (int k = sub; k < n_in; k += 16) dv[row * n_in + k] = s * dw[row * dw_ld + k] - c * v[row * n_in + k];
+            if (sub == 0) dg[row] = dot / nrm;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, int rad_in, int dual,
+                const Packed* __restrict__ pk, const float* __restrict__ wg, const float* __restrict__ dbeta) {
+    __shared__ float s_dwc[3][68];
+    __shared__ float s_dbc[4];
+    __shared__ float s_dt1[3][64];
+    __shared__ float s_row[64][68];       // effective-weight gradients of the layer being processed
+    const int tid = threadIdx.x;
+
+    // ---- geometry MLPs
+    for (int which = 0; which < (dual ? 2 : 1); ++which) {
+        const float* dW0 = wg + (which ? WgLayout::dG0 : WgLayout::dW0);
+        const float* dW1 = wg + (which ? WgLayout::dG1 : WgLayout::dW1);
+        const ls2fm_linear* lin = which ? P.geo_mlp : P.sdf_mlp;
+        const ls2fm_linear_grad* gl = which ? G.geo_mlp : G.sdf_mlp;
+        const int ind = which ? in_dim2 : in_dim;
+        weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, dW0, 36, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid);
+        if (tid < kHidden) gl[0].bias[tid] = dW0[tid * 36 + 35];
+        __syncthreads();
+        for (int idx = tid; idx < kOut * kHidden; idx += 256) {
+            const int o = idx / kHidden, j = idx % kHidden;
+            s_row[o][j] = dW1[o * 65 + j] + ((which == 0 && o == 0) ? wg[WgLayout::dW1r0 + j] : 0.f);
+        }
+        __syncthreads();
+        weight_norm_bwd_rows(lin[1].weight_v, lin[1].weight_g, &s_row[0][0], 68, kOut, kHidden, gl[1].weight_v,
+                             gl[1].weight_g, tid);
+        if (tid < kOut) gl[1].bias[tid] = dW1[tid * 65 + 64];
+        __syncthreads();
+    }
+
+    // ---- radiance decoder: expand dWc (3 x rad_in) and back through Wc = R2 R1 R0, bc = T1 b0 + R2 b1 + b2
+    for (int idx = tid; idx < 3 * 68; idx += 256) {
+        const int c = idx / 68, k = idx % 68;
+        const float* row = wg + WgLayout::dWc + c * 39;
+        float val = 0.f;
+        if (k < 6) val = row[k];
+        else if (k < 33) val = wg[WgLayout::dWv + c * 27 + (k - 6)];
+        else if (k < 49) val = row[6 + (k - 33)];
+        else if (k < 65) val = dual ? row[22 + (k - 49)] : 0.f;
+        s_dwc[c][k] = val;
+    }
+    if (tid < 3) s_dbc[tid] = wg[WgLayout::dWc + tid * 39 + 38];
+    __syncthreads();
+    for (int idx = tid; idx < 3 * 64; idx += 256) {       // dT1 = dWc R0^T + dbc b0^T
+        const int c = idx / 64, j = idx % 64;
+        float acc = s_dbc[c] * P.rad_mlp[0].bias[j];
+        for (int k = 0; k < rad_in; ++k) acc = fmaf(s_dwc[c][k], pk->r0[j][k], acc);
+        s_dt1[c][j] = acc;
+    }
+    for (int idx = tid; idx < 64 * 68; idx += 256) {      // dR0 = T1^T dWc
+        const int j = idx / 68, k = idx % 68;
+        float acc = 0.f;
+        for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][j], s_dwc[c][k], acc);
+        s_row[j][k] = acc;
+    }
+    __syncthreads();
+    weight_norm_bwd_rows(P.rad_mlp[0].weight_v, P.rad_mlp[0].weight_g, &s_row[0][0], 68, 64, rad_in,
+                         G.rad_mlp[0].weight_v, G.rad_mlp[0].weight_g, tid);
+    if (tid < 64) {
+        float acc = 0.f;
+        for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][tid], s_dbc[c], acc);
+        G.rad_mlp[0].bias[tid] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 64; idx += 256) {      // dR1 = R2^T dT1
+        const int m = idx / 64, j = idx % 64;
+        float acc = 0.f;
+        for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][m], s_dt1[c][j], acc);
+        s_row[m][j] = acc;
+    }
+    __syncthreads();
+    weight_norm_bwd_rows(P.rad_mlp[1].weight_v, P.rad_mlp[1].weight_g, &s_row[0][0], 68, 64, 64,
+                         G.rad_mlp[1].weight_v, G.rad_mlp[1].weight_g, tid);
+    if (tid < 64) {
+        float acc = 0.f;
+        for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][tid], s_dbc[c], acc);
+        G.rad_mlp[1].bias[tid] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 3 * 64; idx += 256) {       // dR2 = dT1 R1^T + dbc b1^T
+        const int c = idx / 64, m = idx % 64;
+        float acc = s_dbc[c] * P.rad_mlp[1].bias[m];
+        for (int j = 0; j < 64; ++j) acc = fmaf(s_dt1[c][j], pk->r1[m][j], acc);
+        s_row[c][m] = acc;
+    }
+    __syncthreads();
+    weight_norm_bwd_rows(P.rad_mlp[2].weight_v, P.rad_mlp[2].weight_g, &s_row[0][0], 68, 3, 64,
+                         G.rad_mlp[2].weight_v, G.rad_mlp[2].weight_g, tid);
+    if (tid < 3) G.rad_mlp[2].bias[tid] = s_dbc[tid];
+    // ---- beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed
+    if (tid == 0) G.beta[0] = (float)(*reinterpret_cast<const double*>(dbeta) * (double)pk->beta * (double)P.beta_speed);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- C ABI
+int ls2fm_launch_slab_scatter(const ls2fm_grid_desc* grid, const float* x4, int64_t n_points, int64_t p_pad,
+                              const float* rec, bool second_order, float* dtable, hipStream_t stream);
+
+extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
+                                const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
+                                const float* ray, int64_t n_rays, const float* d_rgb, const float* d_sdfs_volume,
+                                const float* d_normals, const float* d_depth_mlp, const float* d_normal_mlp,
+                                const ls2fm_param_grads* grads, float* d_center, float* d_ray, void* workspace,
+                                void* stream) {
+    LS2FM_CHECK_ARG(field && grid_desc_ok(sdf_grid) && params && grads && n_rays >= 0);
+    LS2FM_CHECK_ARG(!field->dual_field || grid_desc_ok(rad_grid));
+    if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;
+    if (field->dual_field && rad_grid->n_levels != sdf_grid->n_levels) return LS2FM_ERR_UNSUPPORTED;
+    if (field->n_samples < 1 || field->n_samples > 512) return LS2FM_ERR_UNSUPPORTED;
+    if (d_center || d_ray) return LS2FM_ERR_UNSUPPORTED;   // pose gradients: general (composed) form
+    if (n_rays == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(center && ray && grads->sdf_table && grads->beta && (!field->dual_field || grads->rad_table));
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int dual = field->dual_field ? 1 : 0;
+    const int L1 = sdf_grid->n_levels, L2 = dual ? rad_grid->n_levels : 0;
+    const WsLayout w = make_ws_layout(n_rays, field->n_samples, L1, dual ? L2 : L1, dual);
+    float* ws = (float*)workspace;
+    const Packed* pk = (const Packed*)(ws + w.packed);
+    const FieldC fc = make_field_c(field);
+    const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
+    const int64_t P = w.p_pad;
+
+    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (WgLayout::total), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + w.dbeta, 0, sizeof(float) * 64, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+
+    const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
+    const int threads = (field->n_samples + 63) / 64 * 64;
+#define LS2FM_SHADE_BWD(DUAL, MAXT) \
+    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, 2 * L1, 2 * L2, w, pk, center, ray, ws, up, ws)
+    if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
+    else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
+#undef LS2FM_SHADE_BWD
+
+    // weight-gradient GEMMs over all sample points
+    WJobs jobs;
+    for (int q = 0; q < kWgradJobs; ++q) jobs.job[q] = WJob{};
+    auto seg = [&](int64_t off, int rows) { return Seg{ws + off, rows, 0}; };
+    int nj = 0;
+    auto add = [&](Seg a0, Seg a1, std::initializer_list<Seg> bs, int64_t k, int64_t ld, int out_off, int out_ld) {
+        WJob& J = jobs.job[nj++];
+        J.a[0] = a0; J.a[1] = a1;
+        int q = 0;
+        J.n = 0;
+        for (const Seg& b : bs) { J.b[q++] = b; J.n += b.rows; }
+        J.m = a0.rows + a1.rows;
+        J.k = k; J.ld = ld; J.out_off = out_off; J.out_ld = out_ld;
+    };
+    const Seg none{nullptr, 0, 0};
+    const Seg ones = seg(w.ones, 1);
+    add(seg(w.da, 64), none, {seg(w.pu, 3), seg(w.e1, 2 * L1), Seg{nullptr, 32 - 2 * L1, 0}, ones}, w.p, P, WgLayout::dW0, 36);
+    add(seg(w.g, 64), none, {seg(w.v, 35)}, w.p, P, WgLayout::dW0, 36);
+    add(seg(w.gf, 17), none, {seg(w.h, 64), ones}, w.p, P, WgLayout::dW1, 65);
+    add(ones, none, {seg(w.sq, 64)}, w.p, P, WgLayout::dW1r0, 64);
+    add(seg(w.dz, 3), none, {seg(w.p3, 3), seg(w.nrm, 3), seg(w.fe, 16), dual ? seg(w.fe2, 16) : Seg{nullptr, 16, 0}, ones},
+        w.p, P, WgLayout::dWc, 39);
+    add(seg(w.dzr, 3), none, {seg(w.renc, 27)}, n_rays, w.r_pad, WgLayout::dWv, 27);
+    if (dual) {
+        add(seg(w.da2, 64), none, {seg(w.pu, 3), seg(w.e2, 2 * L2), Seg{nullptr, 32 - 2 * L2, 0}, ones}, w.p, P, WgLayout::dG0, 36);
+        add(seg(w.gf2, 17), none, {seg(w.h2, 64), ones}, w.p, P, WgLayout::dG1, 65);
+    }
+    wgrad_kernel<<<dim3((unsigned)w.nblk, (unsigned)nj), 256, 0, s>>>(jobs, w.nblk, ws + w.part);
+    wgrad_reduce_kernel<<<dim3((64 * 80 + 63) / 64, (unsigned)nj), 256, 0, s>>>(jobs, w.nblk, ws + w.part, ws + w.wg);
+
+    // hash-table gradients: LDS-slab scatter (no table-wide global atomics; the tables are overwritten in full)
+    {
+        int st = ls2fm_launch_slab_scatter(sdf_grid, ws + w.x4, w.p, P, ws + w.rec1, true, grads->sdf_table, s);
+        if (st != LS2FM_OK) return st;
+        if (dual) {
+            st = ls2fm_launch_slab_scatter(rad_grid, ws + w.x4, w.p, P, ws + w.rec2, false, grads->rad_table, s);
+            if (st != LS2FM_OK) return st;
+        }
+    }
+    finalize_kernel<<<1, 256, 0, s>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
+                                      ws + w.dbeta);
+    return ls2fm_launch_status();
+}

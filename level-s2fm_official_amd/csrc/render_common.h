@@ -1,0 +1,216 @@
+// Shared definitions of the fused render pipeline (render_fwd.hip, render_bwd.hip, sdf_eval.hip).
+//
+// Pipeline (one C-ABI call each way, several kernels inside):
+//   forward : prep_weights -> ray_encode (grid 1, +Jacobian) [-> ray_encode (grid 2)] -> shade_fwd
+//   backward: shade_bwd -> wgrad (MFMA GEMM over points) -> wgrad_reduce -> table scatter(s) -> finalize
+// Per-sample intermediates live in HBM as structure-of-arrays [channel][P_pad] so that every
+// "lane = sample" access is a fully coalesced 256-byte wave transaction.
+#pragma once
+
+#include "ls2fm_device.h"
+
+constexpr int kHidden = LS2FM_HIDDEN;     // 64
+constexpr int kOut = LS2FM_FEAT + 1;      // 17: sdf + 16 features
+constexpr int kInMax = 3 + 2 * LS2FM_MAX_LEVELS;   // 35
+constexpr int kView = LS2FM_VIEW_ENC;     // 27
+constexpr int kRadIn = 3 + 3 + kView + 2 * LS2FM_FEAT;   // 65 (49 without the second field)
+
+// One record per hidden unit j (256 B, scalar-load friendly):
+//   [0..34] W0[j][k] (zero beyond the live input width)   [35] b0[j]   [36..52] W1[o][j], o = 0..16
+constexpr int kRecStride = 64;
+constexpr int kRecB0 = 35;
+constexpr int kRecW1 = 36;
+constexpr int kMlpFloats = kHidden * kRecStride + 32;      // + b1[17] (padded)
+
+struct Packed {
+    float sdf[kMlpFloats];
+    float geo[kMlpFloats];
+    float wc[3][68];        // collapsed radiance decoder: cols [0,3) p  [3,6) n  [6,33) view  [33,49) f  [49,65) f2
+    float bc[4];
+    float t1[3][64];        // R2 * R1 (effective weights)
+    float r0[64][68];       // effective R0, rows padded
+    float r1[64][64];
+    float r2[3][64];
+    float beta, alpha, pad0, pad1;
+};
+
+// scene constants in kernel-argument form
+struct FieldC {
+    float bmin[3], bmax[3];
+    float box_c[3], box_h[3];     // (bmax+bmin)/2, (bmax-bmin)/2 in fp32, as the reference computes them
+    float inv_ext[3];             // 1 / (bmax - bmin)
+    float rescale, scale_mlp, kappa;   // kappa = +-1/scale_mlp : d sdf / d f0
+    int inside;
+    float bg[3];
+    int n_samples;
+};
+
+static inline FieldC make_field_c(const ls2fm_field_desc* f) {
+    FieldC c;
+    for (int d = 0; d < 3; ++d) {
+        c.bmin[d] = f->bound_min[d];
+        c.bmax[d] = f->bound_max[d];
+        c.box_c[d] = (f->bound_max[d] + f->bound_min[d]) / 2.0f;
+        c.box_h[d] = (f->bound_max[d] - f->bound_min[d]) / 2.0f;
+        c.inv_ext[d] = 1.0f / (f->bound_max[d] - f->bound_min[d]);
+        c.bg[d] = f->bgcolor[d];
+    }
+    c.rescale = f->rescale;
+    c.scale_mlp = f->scale_mlp;
+    c.inside = f->inside;
+    c.kappa = (f->inside ? 1.0f : -1.0f) / f->scale_mlp;
+    c.n_samples = f->n_samples;
+    return c;
+}
+
+// Sample n of ray r: AABB near/far (constants w.r.t. the pose), mid-point depth, world position and
+// grid-normalised position -- each step the same IEEE operation the reference performs
+// (Renderer.py:118-127, camera.py:262-266, base.py:35), so the hash cell of every sample is the oracle's.
+struct RayGeom {
+    float o[3], d[3];
+    float t_near, t_far;
+};
+
+__device__ __forceinline__ RayGeom load_ray(const FieldC& fc, const float* __restrict__ center,
+                                            const float* __restrict__ ray, int64_t r) {
+    RayGeom g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g.o[a] = center[r * 3 + a]; g.d[a] = ray[r * 3 + a]; }
+    bool hit;
+    ray_box(g.o, g.d, fc.box_c, fc.box_h, g.t_near, g.t_far, hit);
+    return g;
+}
+
+__device__ __forceinline__ float sample_depth(const RayGeom& g, int n, int n_samples) {
+    return ((float)n + 0.5f) / (float)n_samples * (g.t_far - g.t_near) + g.t_near;
+}
+
+__device__ __forceinline__ void sample_position(const FieldC& fc, const RayGeom& g, float t, float p[3], float x[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        p[a] = g.o[a] + g.d[a] * t;
+        x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+    }
+}
+
+// VolSDF density sigma = alpha * Psi_beta(sdf) and its derivatives (SDF.py:84-87)
+__device__ __forceinline__ float sigma_of(float s, float alpha, float beta) {
+    const float e = 0.5f * expf(-fabsf(s) / beta);
+    return alpha * (s >= 0.0f ? e : 1.0f - e);
+}
+
+// Geometry MLP forward with the weights streamed from the packed records (wave-uniform addresses ->
+// scalar loads; every FMA is a VALU op with one SGPR operand).  u[35] -> f[17] and, optionally,
+// r = W0^T (s' * w1_0)  (the vector whose contraction with d u / d p gives the analytic normal).
+template <bool WANT_R>
+__device__ __forceinline__ void geometry_forward(const float* __restrict__ rec, const float (&u)[kInMax],
+                                                 float (&f)[kOut], float (&r)[kInMax]) {
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) f[o] = rec[kHidden * kRecStride + o];
+    if (WANT_R) {
+#pragma unroll
+        for (int k = 0; k < kInMax; ++k) r[k] = 0.0f;
+    }
+#pragma unroll 1
+    for (int j = 0; j < kHidden; ++j) {
+        const float* __restrict__ w = rec + j * kRecStride;
+        float a0 = w[kRecB0], a1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k + 1 < kInMax; k += 2) {
+            a0 = fmaf(w[k], u[k], a0);
+            a1 = fmaf(w[k + 1], u[k + 1], a1);
+        }
+        a0 = fmaf(w[kInMax - 1], u[kInMax - 1], a0);
+        float h, s1, s2;
+        softplus100(a0 + a1, h, s1, s2);
+#pragma unroll
+        for (int o = 0; o < kOut; ++o) f[o] = fmaf(w[kRecW1 + o], h, f[o]);
+        if (WANT_R) {
+            const float g = s1 * w[kRecW1];
+#pragma unroll
+            for (int k = 0; k < kInMax; ++k) r[k] = fmaf(w[k], g, r[k]);
+        }
+    }
+}
+
+// Fourier view embedding component c (0..26) of direction d: [d, sin(1 d), cos(1 d), sin(2 d), ...]
+__device__ __forceinline__ float view_component(const float d[3], int c) {
+    if (c < 3) return d[c];
+    const int q = (c - 3) / 3, a = (c - 3) % 3;       // q: 0 sin f0, 1 cos f0, 2 sin f1, ...
+    const float f = (float)(1 << (q >> 1));
+    const float x = d[a] * f;
+    return (q & 1) ? cosf(x) : sinf(x);
+}
+
+// Workspace carve-up (offsets in floats).  Channels are SoA with stride p_pad.
+struct WsLayout {
+    int64_t p, p_pad, r_pad;
+    int l1, l2, dual;
+    // forward -> backward
+    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4;
+    // backward scratch
+    int64_t rec1, rec2, da, g, h, sq, v, pu, p3, gf, dz, da2, h2, gf2, dzr, renc, part, wg, dbeta;
+    int64_t total;
+    int nblk;
+};
+
+constexpr int kWgradKB = 1024;         // points per wgrad block
+constexpr int kWgradJobs = 8;
+constexpr int kWgradTile = 64 * 80;    // max M x N of one job
+
+// reduced raw weight gradients (floats)
+struct WgLayout {
+    static constexpr int dW0 = 0;                     // [64][36]: p/rescale(3) e(32) 1
+    static constexpr int dW1 = dW0 + 64 * 36;         // [17][65]: h(64) 1
+    static constexpr int dW1r0 = dW1 + 17 * 65;       // [64]    : extra row-0 term (double backward)
+    static constexpr int dG0 = dW1r0 + 64;            // [64][36]
+    static constexpr int dG1 = dG0 + 64 * 36;         // [17][65]
+    static constexpr int dWc = dG1 + 17 * 65;         // [3][39] : p(3) n(3) f(16) f2(16) 1
+    static constexpr int dWv = dWc + 3 * 39;          // [3][27] : view embedding columns
+    static constexpr int total = dWv + 3 * 27;
+};
+
+static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int l2, int dual) {
+    WsLayout w;
+    w.p = n_rays * n_samples;
+    w.p_pad = (w.p + 63) / 64 * 64;
+    w.r_pad = (n_rays + 63) / 64 * 64;
+    w.l1 = l1; w.l2 = l2; w.dual = dual;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += (n + 63) / 64 * 64; return at; };
+    const int64_t P = w.p_pad;
+    w.packed = take((sizeof(Packed) + 3) / 4);
+    w.e1 = take(2 * l1 * P);
+    w.j1 = take(6 * l1 * P);
+    w.e2 = take(dual ? 2 * l2 * P : 0);
+    w.sdfv = take(P);
+    w.nrm = take(3 * P);
+    w.rgbs = take(3 * P);
+    w.fe = take(16 * P);
+    w.fe2 = take(dual ? 16 * P : 0);
+    w.ones = take(P);
+    w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
+    w.rec1 = take(8 * (int64_t)l1 * P);          // [level][point]{de0 de1 rr0 rr1 gn0 gn1 gn2 -}: SDF-grid scatter payload
+    w.rec2 = take(dual ? 2 * (int64_t)l2 * P : 0); // [level][point]{de0 de1}: second-grid scatter payload
+    w.da = take(64 * P);
+    w.g = take(64 * P);
+    w.h = take(64 * P);
+    w.sq = take(64 * P);
+    w.v = take(35 * P);
+    w.pu = take(3 * P);
+    w.p3 = take(3 * P);
+    w.gf = take(17 * P);
+    w.dz = take(3 * P);
+    w.da2 = take(dual ? 64 * P : 0);
+    w.h2 = take(dual ? 64 * P : 0);
+    w.gf2 = take(dual ? 17 * P : 0);
+    w.dzr = take(3 * w.r_pad);
+    w.renc = take(27 * w.r_pad);
+    w.nblk = (int)((w.p + kWgradKB - 1) / kWgradKB);
+    if (w.nblk < 1) w.nblk = 1;
+    w.part = take((int64_t)kWgradJobs * w.nblk * kWgradTile);
+    w.wg = take(WgLayout::total);
+    w.dbeta = take(64);
+    w.total = o;
+    return w;
+}

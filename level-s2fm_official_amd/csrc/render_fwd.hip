@@ -1,0 +1,354 @@
+// Fused volumetric-rendering forward for gfx950 (replaces Renderer.forward, models/Renderer.py:51-116).
+//
+//   prep_weights : weight-norm -> effective weights, packed per hidden unit for scalar loads; the affine
+//                  radiance decoder chain (no activation ever fires in the reference: base.py:255-258) is
+//                  collapsed to one 3 x 65 map  Wc = R2 R1 R0
+//   ray_encode   : thread per (sample, level): AABB near/far + mid-point sample + hash-grid gather with
+//                  Jacobian, written as SoA channels
+//   shade_fwd    : block per ray, lane per sample: SDF MLP + analytic normal + (second field) + collapsed
+//                  radiance + VolSDF sigma, then the front-to-back composite as a wave/block scan
+#include "render_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- prep
+struct LayerRef { const float* v; const float* g; const float* b; int out, in; };
+
+__device__ __forceinline__ LayerRef layer_ref(const ls2fm_params& P, int li, int in_dim, int rad_in) {
+    switch (li) {
+        case 0: return {P.sdf_mlp[0].weight_v, P.sdf_mlp[0].weight_g, P.sdf_mlp[0].bias, kHidden, in_dim};
+        case 1: return {P.sdf_mlp[1].weight_v, P.sdf_mlp[1].weight_g, P.sdf_mlp[1].bias, kOut, kHidden};
+        case 2: return {P.geo_mlp[0].weight_v, P.geo_mlp[0].weight_g, P.geo_mlp[0].bias, kHidden, in_dim};
+        case 3: return {P.geo_mlp[1].weight_v, P.geo_mlp[1].weight_g, P.geo_mlp[1].bias, kOut, kHidden};
+        case 4: return {P.rad_mlp[0].weight_v, P.rad_mlp[0].weight_g, P.rad_mlp[0].bias, kHidden, rad_in};
+        case 5: return {P.rad_mlp[1].weight_v, P.rad_mlp[1].weight_g, P.rad_mlp[1].bias, kHidden, kHidden};
+        default: return {P.rad_mlp[2].weight_v, P.rad_mlp[2].weight_g, P.rad_mlp[2].bias, 3, kHidden};
+    }
+}
+
+// first weight-norm row of layer li in the 293-row list (sdf0 sdf1 geo0 geo1 rad0 rad1 rad2)
+__device__ __forceinline__ int row_base(int li) {
+    switch (li) {
+        case 0: return 0;
+        case 1: return 64;
+        case 2: return 81;
+        case 3: return 145;
+        case 4: return 162;
+        case 5: return 226;
+        case 6: return 290;
+        default: return 293;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, Packed* __restrict__ out) {
+    __shared__ float row_scale[296];
+    const int tid = threadIdx.x;
+    // 1. weight-norm row scales  s = g / ||v||   (torch._weight_norm(v, g, 0) = v * (g / norm))
+    //    (16 lanes per row: coalesced reads + a 16-wide shuffle reduction instead of a serial latency chain)
+    for (int row0 = 0; row0 < 293; row0 += 16) {
+        const int row = row0 + (tid >> 4), sub = tid & 15;
+        int li = 0;
+        while (li < 6 && row >= row_base(li + 1)) ++li;
+        const bool on = row < 293 && (dual || (li != 2 && li != 3));
+        const LayerRef L = layer_ref(P, li, li == 2 ? in_dim2 : in_dim, rad_in);
+        const int o = row - row_base(li);
+        float ss = 0.f;
+        if (on)
+            for (int k = sub; k < L.in; k += 16) { const float x = L.v[o * L.in + k]; ss = fmaf(x, x, ss); }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 16);
+        if (sub == 0 && row < 293) row_scale[row] = on ? L.g[o] / sqrtf(ss) : 0.f;
+    }
+    __syncthreads();
+    // 2. packed geometry MLPs
+    for (int which = 0; which < (dual ? 2 : 1); ++which) {
+        float* dst = which ? out->geo : out->sdf;
+        const int ind = which ? in_dim2 : in_dim;
+        const LayerRef L0 = layer_ref(P, which ? 2 : 0, ind, rad_in), L1 = layer_ref(P, which ? 3 : 1, ind, rad_in);
+        const float* s0 = row_scale + row_base(which ? 2 : 0);
+        const float* s1 = row_scale + row_base(which ? 3 : 1);
+        for (int idx = tid; idx < kHidden * kRecStride; idx += 256) {
+            const int j = idx / kRecStride, k = idx % kRecStride;
+            float val = 0.f;
+            if (k < ind) val = L0.v[j * ind + k] * s0[j];
+            else if (k == kRecB0) val = L0.b[j];
+            else if (k >= kRecW1 && k < kRecW1 + kOut) val = L1.v[(k - kRecW1) * kHidden + j] * s1[k - kRecW1];
+            dst[idx] = val;
+        }
+        for (int o = tid; o < 32; o += 256) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
+    }
+    // 3. effective radiance layers
+    {
+        const LayerRef R0 = layer_ref(P, 4, in_dim, rad_in), R1 = layer_ref(P, 5, in_dim, rad_in),
+                       R2 = layer_ref(P, 6, in_dim, rad_in);
+        for (int idx = tid; idx < 64 * 68; idx += 256) {
+            const int j = idx / 68, k = idx % 68;
+            out->r0[j][k] = k < rad_in ? R0.v[j * rad_in + k] * row_scale[row_base(4) + j] : 0.f;
+        }
+        for (int idx = tid; idx < 64 * 64; idx += 256)
+            out->r1[idx / 64][idx % 64] = R1.v[idx] * row_scale[row_base(5) + idx / 64];
+        for (int idx = tid; idx < 3 * 64; idx += 256)
+            out->r2[idx / 64][idx % 64] = R2.v[idx] * row_scale[row_base(6) + idx / 64];
+    }
+    __syncthreads();
+    // 4. T1 = R2 R1
+    for (int idx = tid; idx < 3 * 64; idx += 256) {
+        const int c = idx / 64, j = idx % 64;
+        float acc = 0.f;
+        for (int m = 0; m < 64; ++m) acc = fmaf(out->r2[c][m], out->r1[m][j], acc);
+        out->t1[c][j] = acc;
+    }
+    __syncthreads();
+    // 5. Wc = T1 R0 ; bc = T1 b0 + R2 b1 + b2
+    for (int idx = tid; idx < 3 * 68; idx += 256) {
+        const int c = idx / 68, k = idx % 68;
+        float acc = 0.f;
+        if (k < rad_in)
+            for (int j = 0; j < 64; ++j) acc = fmaf(out->t1[c][j], out->r0[j][k], acc);
+        out->wc[c][k] = acc;
+    }
+    if (tid < 3) {
+        const int c = tid;
+        float acc = P.rad_mlp[2].bias[c];
+        for (int m = 0; m < 64; ++m) acc = fmaf(out->r2[c][m], P.rad_mlp[1].bias[m], acc);
+        for (int j = 0; j < 64; ++j) acc = fmaf(out->t1[c][j], P.rad_mlp[0].bias[j], acc);
+        out->bc[c] = acc;
+    }
+    if (tid == 3) {
+        out->bc[3] = 0.f;
+        const float beta = expf(P.beta[0] * P.beta_speed);
+        out->beta = beta;
+        out->alpha = 1.0f / beta;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- ray_encode
+template <bool WITH_JAC>
+__global__ void __launch_bounds__(256)
+ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
+                  const float* __restrict__ table, int64_t n_points, int64_t p_pad, float* __restrict__ enc,
+                  float* __restrict__ jac, float* __restrict__ ones, float* __restrict__ xs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= n_points) return;
+    const int64_t r = i / fc.n_samples;
+    const int n = (int)(i - r * fc.n_samples);
+    const RayGeom g = load_ray(fc, center, ray, r);
+    float p[3], x[3];
+    sample_position(fc, g, sample_depth(g, n, fc.n_samples), p, x);
+    Cell c;
+    locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+    float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float wt = corner_weight(c.w, k);
+        y0 = fmaf(wt, v[k].x, y0);
+        y1 = fmaf(wt, v[k].y, y1);
+    }
+    enc[(2 * l + 0) * p_pad + i] = y0;
+    enc[(2 * l + 1) * p_pad + i] = y1;
+    if (WITH_JAC) {
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dw = corner_dweight(c.w, k, gd);
+                g0 = fmaf(dw, v[k].x, g0);
+                g1 = fmaf(dw, v[k].y, g1);
+            }
+            jac[((2 * l + 0) * 3 + gd) * p_pad + i] = lv.scale[l] * g0;
+            jac[((2 * l + 1) * 3 + gd) * p_pad + i] = lv.scale[l] * g1;
+        }
+    }
+    if (ones && l == 0) {
+        ones[i] = 1.0f;
+        reinterpret_cast<float4*>(xs)[i] = make_float4(x[0], x[1], x[2], 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- shade_fwd
+// Block = one ray, thread = one sample (blockDim = 64 * ceil(N / 64)).
+template <bool DUAL, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, const float* __restrict__ center,
+                 const float* __restrict__ ray, int64_t p_pad, const float* __restrict__ E1,
+                 const float* __restrict__ J1, const float* __restrict__ E2, float* __restrict__ rgb_out,
+                 float* __restrict__ sdfs_out, float* __restrict__ normals_out, float* __restrict__ depth_out,
+                 float* __restrict__ nm_out, float* __restrict__ SDFV, float* __restrict__ NRM,
+                 float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2) {
+    __shared__ float s_part[16][10];     // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
+    __shared__ float s_view[3];
+    const int N = fc.n_samples;
+    const int64_t r = blockIdx.x;
+    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    const bool live = n < N;
+    const int64_t i = r * N + (live ? n : N - 1);
+    const RayGeom g = load_ray(fc, center, ray, r);
+    const float t = sample_depth(g, live ? n : N - 1, N);
+    const float t_next = sample_depth(g, (live ? n : N - 1) + 1, N);
+    float p[3], x[3];
+    sample_position(fc, g, t, p, x);
+
+    // view-embedding part of the radiance decoder, once per ray (wave 0)
+    if (wave == 0) {
+        const float e = lane < kView ? view_component(g.d, lane) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = wave_sum(lane < kView ? pk->wc[c][6 + lane] * e : 0.f);
+            if (lane == 0) s_view[c] = s + pk->bc[c];
+        }
+    }
+
+    float u[kInMax], f[kOut], rr[kInMax];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = p[a] / fc.rescale;
+#pragma unroll
+    for (int c = 0; c < kInMax - 3; ++c) u[3 + c] = c < ch1 ? E1[c * p_pad + i] : 0.f;
+    geometry_forward<true>(pk->sdf, u, f, rr);
+    const float sdf = fc.inside ? f[0] / fc.scale_mlp : -f[0] / fc.scale_mlp;
+    // analytic normal: n = kappa * (d u / d p)^T r
+    float nrm[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < kInMax - 3; ++c) acc = fmaf(c < ch1 ? J1[(c * 3 + a) * p_pad + i] : 0.f, rr[3 + c], acc);
+        nrm[a] = fc.kappa * (rr[a] / fc.rescale + acc * fc.inv_ext[a]);
+    }
+    float f2[kOut];
+    if (DUAL) {
+#pragma unroll
+        for (int c = 0; c < kInMax - 3; ++c) u[3 + c] = c < ch2 ? E2[c * p_pad + i] : 0.f;
+        geometry_forward<false>(pk->geo, u, f2, rr);
+    }
+    __syncthreads();          // s_view ready
+    float col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float z = s_view[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) z = fmaf(pk->wc[c][a], p[a], z);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) z = fmaf(pk->wc[c][3 + a], nrm[a], z);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) z = fmaf(pk->wc[c][33 + m], f[1 + m], z);
+        if (DUAL) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) z = fmaf(pk->wc[c][49 + m], f2[1 + m], z);
+        }
+        col[c] = 1.0f / (1.0f + expf(-z));
+    }
+    const float sigma = sigma_of(sdf, pk->alpha, pk->beta);
+
+    if (live) {
+        sdfs_out[i] = sdf;
+        SDFV[i] = sdf;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            normals_out[i * 3 + a] = nrm[a];
+            NRM[a * p_pad + i] = nrm[a];
+            RGBS[a * p_pad + i] = col[a];
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) FE[m * p_pad + i] = f[1 + m];
+        if (DUAL) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) FE2[m * p_pad + i] = f2[1 + m];
+        }
+    }
+
+    // composite (Renderer.py:33-49): N-1 intervals, exclusive prefix of sigma*delta
+    const float ray_len = sqrtf(g.d[0] * g.d[0] + g.d[1] * g.d[1] + g.d[2] * g.d[2]);
+    const bool interval = n < N - 1;
+    const float tau = interval ? sigma * ((t_next - t) * ray_len) : 0.f;
+    const float incl = wave_scan_incl(tau, lane);
+    if (lane == 63) s_part[wave][0] = incl;
+    __syncthreads();
+    float before = incl - tau;
+    for (int w = 0; w < wave; ++w) before += s_part[w][0];
+    const float wgt = interval ? expf(-before) * (1.0f - expf(-tau)) : 0.f;
+    float sums[8] = {wgt * col[0], wgt * col[1], wgt * col[2], wgt * t, wgt * nrm[0], wgt * nrm[1], wgt * nrm[2], wgt};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float s = wave_sum(sums[q]);
+        if (lane == 0) s_part[wave][1 + q] = s;
+    }
+    __syncthreads();
+    if (n == N - 1) {         // the last sample's thread owns t_last / n_last and writes the ray outputs
+        float tot[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            tot[q] = 0.f;
+            for (int w = 0; w < n_waves; ++w) tot[q] += s_part[w][1 + q];
+        }
+        const float rest = 1.0f - tot[7];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb_out[r * 3 + c] = tot[c] + rest * fc.bg[c];
+        depth_out[r] = tot[3] + rest * t;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nm_out[r * 3 + a] = tot[4 + a] + rest * nrm[a];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- C ABI
+static bool render_config_ok(const ls2fm_field_desc* field, const ls2fm_grid_desc* g1, const ls2fm_grid_desc* g2) {
+    if (!field || !grid_desc_ok(g1)) return false;
+    if (field->dual_field && !grid_desc_ok(g2)) return false;
+    if (field->n_samples < 1 || field->n_samples > 1024) return false;
+    return true;
+}
+
+extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid,
+                                                int64_t n_rays) {
+    if (!field || !grid_desc_ok(grid) || n_rays < 0) return LS2FM_ERR_INVALID_ARGUMENT;
+    // the second grid (dual field) uses the same encoding config as the first (models/RadF.py:35-39)
+    const WsLayout w = make_ws_layout(n_rays, field->n_samples, grid->n_levels, grid->n_levels, field->dual_field);
+    return w.total * (int64_t)sizeof(float);
+}
+
+extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
+                                const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
+                                const float* ray, int64_t n_rays, float* rgb, float* sdfs_volume, float* normals,
+                                float* depth_mlp, float* normal_mlp, void* workspace, void* stream) {
+    LS2FM_CHECK_ARG(render_config_ok(field, sdf_grid, rad_grid) && params && n_rays >= 0);
+    if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;       // min(sdf, bg_rad-|p|): general (composed) form only
+    if (field->dual_field && rad_grid->n_levels != sdf_grid->n_levels) return LS2FM_ERR_UNSUPPORTED;
+    if (n_rays == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(center && ray && rgb && sdfs_volume && normals && depth_mlp && normal_mlp);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int dual = field->dual_field ? 1 : 0;
+    const int L1 = sdf_grid->n_levels, L2 = dual ? rad_grid->n_levels : 0;
+    const WsLayout w = make_ws_layout(n_rays, field->n_samples, L1, dual ? L2 : L1, dual);
+    float* ws = (float*)workspace;
+    Packed* pk = (Packed*)(ws + w.packed);
+    const FieldC fc = make_field_c(field);
+    const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
+
+    prep_weights_kernel<<<1, 256, 0, s>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk);
+    const dim3 eg((unsigned)((w.p + 255) / 256), (unsigned)L1);
+    ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p,
+                                              w.p_pad, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4);
+    if (dual) {
+        const dim3 eg2((unsigned)((w.p + 255) / 256), (unsigned)L2);
+        ray_encode_kernel<false><<<eg2, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p,
+                                                    w.p_pad, ws + w.e2, nullptr, nullptr, nullptr);
+    }
+    const int threads = (field->n_samples + 63) / 64 * 64;
+#define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                              \
+    shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                            \
+        fc, 2 * L1, 2 * L2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb,     \
+        sdfs_volume, normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe,             \
+        DUAL ? ws + w.fe2 : nullptr)
+    if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 1024); }
+    else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 1024); }
+#undef LS2FM_SHADE_FWD
+    return ls2fm_launch_status();
+}

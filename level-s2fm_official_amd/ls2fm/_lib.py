@@ -38,7 +38,8 @@ class FieldDesc(Structure):
         ("bound_min", c_float * 3),
         ("bound_max", c_float * 3),
         ("rescale", c_float),
-        ("sdf_scale", c_float),
+        ("scale_mlp", c_float),
+        ("inside", c_int32),
         ("bg_sdf", c_int32),
         ("bg_rad", c_float),
         ("bgcolor", c_float * 3),

@@ -1,0 +1,116 @@
+"""Multi-GPU form of the path: one process per GPU, rays sharded by view / by contiguous ray ranges, ONE exchange
+per optimisation step -- a sum all-reduce of the gradients over RCCL (torch.distributed backend "nccl" on ROCm)
+on the xGMI links.  The reference itself is single-GPU (utils/options.py:110); nothing here is ported.
+
+Sharding rules:
+  * every rank holds full replicas of both hash tables and the MLPs (~100 MiB of 288 GB)
+  * rays split by view when #views >= world, else by contiguous ranges of the flattened [B*R] axis
+  * losses that are *means* over data-dependent masks are reduced as (sum, count) pairs so the result does not
+    depend on the world size
+  * sphere tracing needs one all-reduce(max) of its global trip count to stay identical to the 1-GPU result
+
+Collective shape: the two table gradients (48.8-52.6 MB each, fp32, effectively dense after one batch) go out as
+two large messages as soon as backward returns; all small gradients (MLPs, beta: ~16 k floats) live in ONE flat
+buffer that the fused backward writes directly (no packing kernels), reduced as a third message.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_rays(center: torch.Tensor, ray: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """center, ray [B,R,3] -> this rank's shard.  By view (axis 0) when B divides evenly over the ranks, otherwise
+    by equal contiguous ranges of the flattened ray axis (the trailing remainder goes to the last ranks)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    b, r = center.shape[:2]
+    if world == 1:
+        return center, ray
+    if b >= world and b % world == 0:
+        per = b // world
+        return center[rank * per:(rank + 1) * per], ray[rank * per:(rank + 1) * per]
+    flat_c, flat_r = center.reshape(1, b * r, 3), ray.reshape(1, b * r, 3)
+    bounds = [(b * r * k) // world for k in range(world + 1)]
+    return flat_c[:, bounds[rank]:bounds[rank + 1]], flat_r[:, bounds[rank]:bounds[rank + 1]]
+
+
+def global_mean(local_sum: torch.Tensor, local_count: torch.Tensor) -> torch.Tensor:
+    """mean over all ranks of a masked quantity given the local sum and the local element count"""
+    if not is_distributed():
+        return local_sum / local_count.clamp_min(1)
+    pair = torch.stack([local_sum.reshape(()).float(), local_count.reshape(()).float()])
+    dist.all_reduce(pair)
+    return pair[0] / pair[1].clamp_min(1)
+
+
+def global_max_int(value: int, device) -> int:
+    """e.g. the sphere-tracing trip count K (SDF.py:167 tests a mask over ALL rays)"""
+    if not is_distributed():
+        return int(value)
+    t = torch.tensor([int(value)], device=device, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+class GradAllReducer:
+    """Sum-all-reduce of `.grad` of a parameter list: big tensors individually, small ones through one flat buffer.
+    When the small gradients already are views of one flat buffer (the fused backward allocates them that way,
+    ls2fm.fused.small_grad_buffer) that buffer is reduced in place with no packing at all."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], big_numel: int = 1 << 20, average: bool = False):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.big = [p for p in self.params if p.numel() >= big_numel]
+        self.small = [p for p in self.params if p.numel() < big_numel]
+        self.average = average
+        self._flat: Optional[torch.Tensor] = None
+
+    def _shared_flat(self) -> Optional[torch.Tensor]:
+        from . import fused
+        flat = fused.small_grad_buffer()
+        if flat is None:
+            return None
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        for p in self.small:
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                return None
+        return flat
+
+    def all_reduce(self) -> None:
+        if not is_distributed():
+            return
+        world = dist.get_world_size()
+        handles = [dist.all_reduce(p.grad, async_op=True) for p in self.big if p.grad is not None]
+        flat = self._shared_flat()
+        packed = flat is None
+        if packed:
+            live = [p for p in self.small if p.grad is not None]
+            n = sum(p.numel() for p in live)
+            if self._flat is None or self._flat.numel() != n:
+                self._flat = torch.empty(n, device=live[0].device, dtype=torch.float32) if live else None
+            flat = self._flat
+            at = 0
+            for p in live:
+                flat[at:at + p.numel()].copy_(p.grad.reshape(-1))
+                at += p.numel()
+        if flat is not None and flat.numel():
+            handles.append(dist.all_reduce(flat, async_op=True))
+        for h in handles:
+            h.wait()
+        if packed and flat is not None:
+            at = 0
+            for p in self.small:
+                if p.grad is not None:
+                    p.grad.copy_(flat[at:at + p.numel()].view_as(p.grad))
+                    at += p.numel()
+        if self.average:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.div_(world)

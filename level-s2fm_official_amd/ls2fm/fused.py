@@ -1,27 +1,239 @@
-"""Fused-kernel entry points (filled in as the kernels land).  Until then every predicate says "no" and
-the general autograd-composed form (HIP hash-grid op + torch dense layers) serves all calls."""
+"""Fused-kernel front end: one autograd node for the whole of Renderer.forward, the no-grad SDF
+evaluation and the sphere-tracing root-find loop.  The kernels read the nn.Parameters of the reference-shaped
+modules directly (weight_v / weight_g / bias, the flat hash tables, beta) and return gradients in that
+very parametrisation, so nothing but this one node sits between the optimizer and the HIP code.
+
+Gating: the fused kernels implement the reference's network sizes (hidden 64, 16 features, 2 features per
+level, <= 16 levels, affine radiance decoder) with uniform sampling and no background-sphere `min`.  Anything
+else -- and any call that needs gradients w.r.t. the camera rays -- is served by the general autograd
+composition (HIP hash-grid op + torch dense layers), never by a CPU path.
+"""
 from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+_DISABLE = os.environ.get("LS2FM_DISABLE_FUSED", "0") == "1"
+
+
+# ------------------------------------------------------------------------------------------------ gating
+def _geometry_ok(mlp, in_dim) -> bool:
+    layers = getattr(mlp, "mlp", None)
+    if layers is None or len(layers) != 2 or getattr(mlp, "skip", []):
+        return False
+    l0, l1 = layers
+    return (hasattr(l0, "weight_g") and hasattr(l1, "weight_g")
+            and tuple(l0.weight_v.shape) == (_lib.HIDDEN, in_dim)
+            and tuple(l1.weight_v.shape) == (_lib.FEAT + 1, _lib.HIDDEN))
+
+
+def supported(opt, sdf_field, rad_field=None) -> bool:
+    """True when the fused kernels implement this configuration."""
+    if _DISABLE:
+        return False
+    enc = sdf_field.embed_fn.embedder_obj
+    desc = enc.desc
+    if desc.n_features != 2 or desc.n_levels > _lib.MAX_LEVELS:
+        return False
+    if not _geometry_ok(sdf_field.SDF_MLP, 3 + 2 * desc.n_levels):
+        return False
+    if opt.data.inside == True and opt.data.bg_sdf == True:  # noqa: E712
+        return False
+    if rad_field is None:
+        return True
+    if opt.SDF.VolSDF.volsdf_sampling != False or not 1 <= int(opt.SDF.VolSDF.sample_intvs) <= 512:  # noqa: E712
+        return False
+    dual = opt.Ablate_config.dual_field == True  # noqa: E712
+    if dual:
+        d2 = rad_field.embed_fn.embedder_obj.desc
+        if d2.n_levels != desc.n_levels or not _geometry_ok(rad_field.Geo_enc, 3 + 2 * d2.n_levels):
+            return False
+    dec = rad_field.Rad_dec
+    rad_in = 33 + _lib.FEAT * (2 if dual else 1)
+    shapes = [tuple(layer.weight_v.shape) if hasattr(layer, "weight_v") else None for layer in dec.mlp_radiance]
+    return shapes == [(64, rad_in), (64, 64), (3, 64)] and not dec.hidden_relu
 
 
 def available(field, probe) -> bool:
-    return False
+    return (not _DISABLE) and probe.is_cuda and supported(field.opt, field) and _HAS_SDF_EVAL
 
 
 def can_eval_without_graph(sdf_field, xyz) -> bool:
-    return False
+    if not xyz.is_cuda or not _HAS_SDF_EVAL or not supported(sdf_field.opt, sdf_field):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not xyz.requires_grad and not any(p.requires_grad for p in sdf_field.parameters())
 
 
+def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
+    if not (center.is_cuda and ray.is_cuda) or not supported(opt, sdf_field, rad_field):
+        return False
+    if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad):
+        return False            # pose gradients: general form
+    return True
+
+
+_HAS_SDF_EVAL = False           # flipped on once the fused sdf_eval / sphere_trace kernels are built in
+
+
+# ------------------------------------------------------------------------------------------------ descriptors
+def field_desc(opt, renderer=None) -> _lib.FieldDesc:
+    f = _lib.FieldDesc()
+    for d in range(3):
+        f.bound_min[d] = float(opt.data.bound_min[d])
+        f.bound_max[d] = float(opt.data.bound_max[d])
+    f.rescale = float(opt.SDF.VolSDF.rescale)
+    f.scale_mlp = float(opt.SDF.NN_Init.scale_mlp)
+    f.inside = 1 if opt.data.inside == True else 0  # noqa: E712
+    f.bg_sdf = 1 if (opt.data.inside == True and opt.data.bg_sdf == True) else 0  # noqa: E712
+    f.bg_rad = float(opt.data.bg_rad)
+    bg = renderer.bg_host if renderer is not None else [0.0, 0.0, 0.0]        # host copy: no device sync per call
+    for d in range(3):
+        f.bgcolor[d] = float(bg[d])
+    f.n_samples = int(opt.SDF.VolSDF.sample_intvs)
+    f.dual_field = 1 if opt.Ablate_config.dual_field == True else 0  # noqa: E712
+    return f
+
+
+def _linear_tensors(layer):
+    return [layer.weight_v, layer.weight_g, layer.bias]
+
+
+def param_tensors(sdf_field, rad_field):
+    """flat, fixed-order list of the Parameters the kernels read (order == ls2fm_params)"""
+    ts = [sdf_field.embed_fn.embedder_obj.params]
+    ts += _linear_tensors(sdf_field.SDF_MLP.mlp[0]) + _linear_tensors(sdf_field.SDF_MLP.mlp[1])
+    ts += [sdf_field.beta]
+    dual = rad_field is not None and hasattr(rad_field, "Geo_enc")
+    if dual:
+        ts += [rad_field.embed_fn.embedder_obj.params]
+        ts += _linear_tensors(rad_field.Geo_enc.mlp[0]) + _linear_tensors(rad_field.Geo_enc.mlp[1])
+    if rad_field is not None:
+        for layer in rad_field.Rad_dec.mlp_radiance:
+            ts += _linear_tensors(layer)
+    return ts, dual
+
+
+def _fill_linear(dst, ts, at):
+    dst.weight_v, dst.weight_g, dst.bias = ptr(ts[at]), ptr(ts[at + 1]), ptr(ts[at + 2])
+    return at + 3
+
+
+def _params_struct(ts, dual, beta_speed, with_rad=True, cls=_lib.Params):
+    """ls2fm_params / ls2fm_param_grads over a tensor list laid out like param_tensors()"""
+    s = cls()
+    at = 0
+    s.sdf_table = ptr(ts[at]); at += 1
+    at = _fill_linear(s.sdf_mlp[0], ts, at)
+    at = _fill_linear(s.sdf_mlp[1], ts, at)
+    s.beta = ptr(ts[at]); at += 1
+    if cls is _lib.Params:
+        s.beta_speed = float(beta_speed)
+    if dual:
+        s.rad_table = ptr(ts[at]); at += 1
+        at = _fill_linear(s.geo_mlp[0], ts, at)
+        at = _fill_linear(s.geo_mlp[1], ts, at)
+    if with_rad:
+        for li in range(3):
+            at = _fill_linear(s.rad_mlp[li], ts, at)
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ render
+_SMALL_GRADS = None      # flat buffer holding every small gradient of the latest fused backward
+
+
+def small_grad_buffer():
+    return _SMALL_GRADS
+
+
+def _is_table(p) -> bool:
+    return p.dim() == 1 and p.numel() > 4096
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, center, ray, cfg, *params):
+        fdesc, g1, g2, dual, beta_speed = cfg
+        lib = _lib.load()
+        dev = center.device
+        shape2 = tuple(center.shape[:2])
+        n_rays = shape2[0] * shape2[1]
+        n = fdesc.n_samples
+        c = center.detach().reshape(-1, 3).float().contiguous()
+        d = ray.detach().reshape(-1, 3).float().contiguous()
+        ps = [p.detach().contiguous() for p in params]
+        ws_bytes = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(g1), n_rays)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "ls2fm_render_workspace_bytes")
+        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+        rgb = torch.empty(*shape2, 3, device=dev)
+        sdfs = torch.empty(*shape2, n, 1, device=dev)
+        normals = torch.empty(*shape2, n, 3, device=dev)
+        depth = torch.empty(*shape2, 1, device=dev)
+        nmlp = torch.empty(*shape2, 3, device=dev)
+        pstruct = _params_struct(ps, dual, beta_speed)
+        check(lib.ls2fm_render_fwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
+                                   ctypes.byref(pstruct), ptr(c), ptr(d), n_rays, ptr(rgb), ptr(sdfs), ptr(normals),
+                                   ptr(depth), ptr(nmlp), ptr(ws), stream_ptr()), "ls2fm_render_fwd")
+        ctx.cfg = cfg
+        ctx.ws = ws
+        ctx.n_rays = n_rays
+        ctx.save_for_backward(c, d, *ps)
+        return rgb, sdfs, normals, depth, nmlp
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sdfs, d_normals, d_depth, d_nmlp):
+        fdesc, g1, g2, dual, beta_speed = ctx.cfg
+        lib = _lib.load()
+        c, d, *ps = ctx.saved_tensors
+
+        def prep(t):
+            return None if t is None else t.float().contiguous()
+        d_rgb, d_sdfs, d_normals, d_depth, d_nmlp = map(prep, (d_rgb, d_sdfs, d_normals, d_depth, d_nmlp))
+        # table gradients: zeroed accumulators (atomics).  All small gradients (MLPs, beta) are views of ONE flat
+        # buffer so that a multi-GPU run can all-reduce them as a single message without packing kernels.
+        global _SMALL_GRADS
+        small_total = sum(p.numel() for p in ps if not _is_table(p))
+        flat = torch.empty(small_total, device=c.device, dtype=torch.float32)
+        _SMALL_GRADS = flat
+        grads, at = [], 0
+        for p in ps:
+            if _is_table(p):
+                grads.append(torch.empty_like(p))      # overwritten in full by the LDS-slab scatter
+            else:
+                grads.append(flat[at:at + p.numel()].view(p.shape))
+                at += p.numel()
+        pstruct = _params_struct(ps, dual, beta_speed)
+        gstruct = _params_struct(grads, dual, beta_speed, cls=_lib.ParamGrads)
+        check(lib.ls2fm_render_bwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
+                                   ctypes.byref(pstruct), ptr(c), ptr(d), ctx.n_rays, ptr(d_rgb), ptr(d_sdfs),
+                                   ptr(d_normals), ptr(d_depth), ptr(d_nmlp), ctypes.byref(gstruct), None, None,
+                                   ptr(ctx.ws), stream_ptr()), "ls2fm_render_bwd")
+        return (None, None, None, *grads)       # ctx.ws is kept: backward may run again (retain_graph)
+
+
+def render(renderer, opt, center, ray, sdf_field, rad_field):
+    """Renderer.forward through the fused kernels -> the reference's result dict."""
+    ts, dual = param_tensors(sdf_field, rad_field)
+    fdesc = field_desc(opt, renderer)
+    g1 = sdf_field.embed_fn.embedder_obj.desc
+    g2 = rad_field.embed_fn.embedder_obj.desc if dual else g1
+    cfg = (fdesc, g1, g2, dual, float(sdf_field.beta_speed))
+    rgb, sdfs, normals, depth, nmlp = _Render.apply(center, ray, cfg, *ts)
+    return {"rgb": rgb, "sdfs_volume": sdfs, "normals": normals, "depth_mlp": depth, "normal_mlp": nmlp}
+
+
+# ------------------------------------------------------------------------------------------------ sdf eval / tracing
 def sdf_eval(sdf_field, xyz, want_feat=False):
     raise RuntimeError("fused sdf_eval not built")
 
 
 def sphere_trace(sdf_field, o, d):
     raise RuntimeError("fused sphere_trace not built")
-
-
-def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
-    return False
-
-
-def render(renderer, opt, center, ray, sdf_field, rad_field):
-    raise RuntimeError("fused render not built")

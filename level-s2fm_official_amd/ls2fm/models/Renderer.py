@@ -33,6 +33,7 @@ class Renderer(nn.Module):
         if bg is None:
             bg = opt.data.bgcolor
         self.bgcolor = torch.tensor(np.array(bg), dtype=torch.float32, device=dev)
+        self.bg_host = [float(v) for v in np.array(bg, dtype=np.float64).reshape(-1)]
 
     # ------------------------------------------------------------------ pieces (same math as the fused kernels)
     def composite(self, ray, rgb_samples, density_samples, depth_samples):
@@ -49,7 +50,9 @@ class Renderer(nn.Module):
         n = opt.SDF.VolSDF.sample_intvs
         mid = (torch.arange(n, device=min_d.device, dtype=torch.float32) + 0.5)[None, None, :, None]
         near, far = min_d[..., None, :], max_d[..., None, :]
-        return mid / n * (far - near) + near                    # [B,R,N,1]
+        # tensor / tensor: a true division.  (tensor / python-scalar is lowered to a multiply by the
+        # rounded reciprocal on the GPU, 1 ulp away from the CPU result; the normals amplify that.)
+        return mid / torch.full((), float(n), device=min_d.device) * (far - near) + near       # [B,R,N,1]
 
     def sdf_to_sigma(self, sdf, alpha, beta):
         half_lap = 0.5 * torch.exp(-sdf.abs() / beta)

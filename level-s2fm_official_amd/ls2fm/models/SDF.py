@@ -51,12 +51,13 @@ class SDF(nn.Module):
 
     # ------------------------------------------------------------------ field evaluation
     def _signed(self, feat, xyz):
+        scale = torch.full((), float(self.scale_mlp), device=feat.device)      # true division on every device
         if self.opt.data.inside == True:  # noqa: E712  (opt values may be yaml scalars)
-            sdf = feat[..., :1] / self.scale_mlp
+            sdf = feat[..., :1] / scale
             if self.opt.data.bg_sdf == True:  # noqa: E712
                 sdf = torch.min(sdf, self.opt.data.bg_rad - xyz.norm(dim=-1, keepdim=True))
             return sdf
-        return -feat[..., :1] / self.scale_mlp
+        return -feat[..., :1] / scale
 
     def infer_sdf(self, xyz, mode="ret_sdf"):
         if fused.can_eval_without_graph(self, xyz):
