@@ -41,7 +41,8 @@ __device__ __forceinline__ int row_base(int li) {
 }
 
 __global__ void __launch_bounds__(256)
-prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, Packed* __restrict__ out) {
+prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad,
+                    Packed* __restrict__ out) {
     __shared__ float row_scale[296];
     const int tid = threadIdx.x;
     // 1. weight-norm row scales  s = g / ||v||   (torch._weight_norm(v, g, 0) = v * (g / norm))
@@ -50,7 +51,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
         const int row = row0 + (tid >> 4), sub = tid & 15;
         int li = 0;
         while (li < 6 && row >= row_base(li + 1)) ++li;
-        const bool on = row < 293 && (dual || (li != 2 && li != 3));
+        const bool on = row < 293 && (dual || (li != 2 && li != 3)) && (with_rad || li < 4);
         const LayerRef L = layer_ref(P, li, li == 2 ? in_dim2 : in_dim, rad_in);
         const int o = row - row_base(li);
         float ss = 0.f;
@@ -78,6 +79,12 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
         }
         for (int o = tid; o < 32; o += 256) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
     }
+    if (tid == 3) {
+        const float beta = expf(P.beta[0] * P.beta_speed);
+        out->beta = beta;
+        out->alpha = 1.0f / beta;
+    }
+    if (!with_rad) return;          // SDF-only users (sdf_eval, sphere_trace); uniform exit
     // 3. effective radiance layers
     {
         const LayerRef R0 = layer_ref(P, 4, in_dim, rad_in), R1 = layer_ref(P, 5, in_dim, rad_in),
@@ -115,12 +122,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
         for (int j = 0; j < 64; ++j) acc = fmaf(out->t1[c][j], P.rad_mlp[0].bias[j], acc);
         out->bc[c] = acc;
     }
-    if (tid == 3) {
-        out->bc[3] = 0.f;
-        const float beta = expf(P.beta[0] * P.beta_speed);
-        out->beta = beta;
-        out->alpha = 1.0f / beta;
-    }
+    if (tid == 3) out->bc[3] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------- ray_encode
@@ -297,6 +299,12 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
 }  // namespace
 
+// weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
+int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream) {
+    prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out);
+    return ls2fm_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------- C ABI
 static bool render_config_ok(const ls2fm_field_desc* field, const ls2fm_grid_desc* g1, const ls2fm_grid_desc* g2) {
     if (!field || !grid_desc_ok(g1)) return false;
@@ -332,7 +340,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const FieldC fc = make_field_c(field);
     const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
 
-    prep_weights_kernel<<<1, 256, 0, s>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk);
+    prep_weights_kernel<<<1, 256, 0, s>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
     const dim3 eg((unsigned)((w.p + 255) / 256), (unsigned)L1);
     ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p,
                                               w.p_pad, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4);

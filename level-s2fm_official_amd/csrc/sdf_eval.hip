@@ -1,0 +1,210 @@
+// Fused no-autograd SDF evaluation and the sphere-tracing root-find loop for gfx950.
+//
+//   sdf_eval      thread per point: 16 x 8 hash-grid gathers + 35->64 softplus(100) -> 64->17 MLP (weights as
+//                 wave-uniform scalar loads), sign / scale_mlp, optional background-sphere min, optional
+//                 analytic normal (second gather pass contracting the hash Jacobian with W0^T (s' * w1_0))
+//                 Replaces SDF.infer_sdf (models/SDF.py:55-78) where no graph is needed.
+//   sphere_trace  two lanes per ray (start end / far end), the reference's `while True` (models/SDF.py:149-200)
+//                 run to completion per ray without host round trips; the global trip count K of the reference is
+//                 recovered as max over rays of the first trip at which the ray's start end is finished.
+#include "render_common.h"
+
+int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream);
+
+namespace {
+
+// hash-encode a world point into u[35] = [p / rescale, e(x)]
+__device__ __forceinline__ void encode_point(const LevelSet& lv, const FieldC& fc, const float* __restrict__ table,
+                                             const float p[3], float (&u)[kInMax]) {
+    float x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+        u[a] = p[a] / fc.rescale;
+    }
+#pragma unroll
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+        float y0 = 0.f, y1 = 0.f;
+        if (l < lv.n_levels) {
+            Cell c;
+            locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wt = corner_weight(c.w, k);
+                y0 = fmaf(wt, v[k].x, y0);
+                y1 = fmaf(wt, v[k].y, y1);
+            }
+        }
+        u[3 + 2 * l] = y0;
+        u[4 + 2 * l] = y1;
+    }
+}
+
+__device__ __forceinline__ float signed_sdf(const FieldC& fc, int bg_sdf, float bg_rad, float f0, const float p[3],
+                                            bool* bg_selected) {
+    float sdf = fc.inside ? f0 / fc.scale_mlp : -f0 / fc.scale_mlp;
+    *bg_selected = false;
+    if (bg_sdf) {
+        const float other = bg_rad - sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        if (other < sdf) { sdf = other; *bg_selected = true; }
+    }
+    return sdf;
+}
+
+template <bool WANT_NORMAL>
+__global__ void __launch_bounds__(256)
+sdf_eval_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
+                const float* __restrict__ table, const float* __restrict__ pts, int64_t n, float* __restrict__ sdf_out,
+                float* __restrict__ feat_out, float* __restrict__ normal_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+    float u[kInMax], f[kOut], rr[kInMax];
+    encode_point(lv, fc, table, p, u);
+    geometry_forward<WANT_NORMAL>(pk->sdf, u, f, rr);
+    bool bg;
+    sdf_out[i] = signed_sdf(fc, bg_sdf, bg_rad, f[0], p, &bg);
+    if (feat_out) {
+#pragma unroll
+        for (int o = 0; o < kOut; ++o) feat_out[i * kOut + o] = f[o];
+    }
+    if (WANT_NORMAL) {
+        float acc[3] = {0.f, 0.f, 0.f};
+        float x[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+#pragma unroll
+        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+            if (l < lv.n_levels) {
+                Cell c;
+                locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float2 v = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+                    const float m = fmaf(v.x, rr[3 + 2 * l], v.y * rr[4 + 2 * l]) * lv.scale[l];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) acc[a] = fmaf(corner_dweight(c.w, k, a), m, acc[a]);
+                }
+            }
+        }
+        const float len = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float nrm = fc.kappa * (rr[a] / fc.rescale + acc[a] * fc.inv_ext[a]);
+            normal_out[i * 3 + a] = bg ? -p[a] / len : nrm;
+        }
+    }
+}
+
+// two lanes per ray: side 0 = start end (from near), side 1 = far end
+__global__ void __launch_bounds__(256)
+sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
+                    const float* __restrict__ table, const float* __restrict__ ray0, const float* __restrict__ ray_dir,
+                    int64_t n_rays, float thr, int iters_max, float* __restrict__ near_out, float* __restrict__ far_out,
+                    float* __restrict__ track, float* __restrict__ t_end, int* __restrict__ trips) {
+    const int64_t tidg = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = tidg >> 1;
+    const int side = (int)(tidg & 1);
+    const bool live = r < n_rays;
+    const int64_t rr_ = live ? r : n_rays - 1;
+    const RayGeom g = load_ray(fc, ray0, ray_dir, rr_);
+    const float far = g.t_far;
+    float t_me = side ? g.t_far : g.t_near;
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
+    float u[kInMax], f[kOut], dummy[kInMax];
+    bool bg;
+    encode_point(lv, fc, table, p, u);
+    geometry_forward<false>(pk->sdf, u, f, dummy);
+    float sdf_me = signed_sdf(fc, bg_sdf, bg_rad, f[0], p, &bg);
+    if (live && side == 0) { near_out[r] = g.t_near; far_out[r] = g.t_far; }
+    if (live && side == 1) t_end[r * (iters_max + 1)] = t_me;
+    bool unf = false;
+    int kfin = -1;
+    for (int k = 0;; ++k) {
+        if (fabsf(sdf_me) <= thr) sdf_me = 0.f;                          // (1) converged values are zeroed
+        const bool m = fabsf(sdf_me) > thr;
+        unf = k == 0 ? m : (unf && m);                                    // (2)
+        const int unf_start = __shfl((int)unf, (threadIdx.x & 63) & ~1, 64);
+        if (!unf_start && kfin < 0) kfin = k;                             // (3) this ray's start end is done at trip k
+        if (k == iters_max) break;
+        if (live && side == 0) {                                          // (5) pre-update start point -> track
+#pragma unroll
+            for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + k) * 3 + a] = p[a];
+        }
+        t_me = t_me + sdf_me;                                             // (4) both ends step with '+', clamp to far
+        if (t_me > far) t_me = far;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
+        if (unf) {                                                        // (6) refresh only where unfinished
+            encode_point(lv, fc, table, p, u);
+            geometry_forward<false>(pk->sdf, u, f, dummy);
+            sdf_me = signed_sdf(fc, bg_sdf, bg_rad, f[0], p, &bg);
+        }
+        const float t_other = __shfl_xor(t_me, 1, 64);
+        const float t_s = side ? t_other : t_me, t_e = side ? t_me : t_other;
+        unf = unf && (t_s < t_e);                                         // (7) crossed ends drop out
+        if (live && side == 1) t_end[r * (iters_max + 1) + k + 1] = t_me;
+    }
+    if (live && side == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + iters_max) * 3 + a] = p[a];
+        atomicMax(trips, kfin < 0 ? iters_max : kfin);
+    }
+}
+
+}  // namespace
+
+static bool field_ok(const ls2fm_field_desc* f, const ls2fm_grid_desc* g, const ls2fm_params* p) {
+    return f && grid_desc_ok(g) && p && p->sdf_table && p->beta && p->sdf_mlp[0].weight_v && p->sdf_mlp[1].weight_v;
+}
+
+extern "C" int64_t ls2fm_sdf_eval_workspace_bytes(void) { return (int64_t)((sizeof(Packed) + 255) / 256 * 256); }
+
+extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                              const float* p, int64_t n, float* sdf, float* feat, float* normal, void* workspace,
+                              void* stream) {
+    LS2FM_CHECK_ARG(field_ok(field, grid, params) && n >= 0);
+    if (n == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(p && sdf);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Packed* pk = (Packed*)workspace;
+    int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
+    if (st != LS2FM_OK) return st;
+    const FieldC fc = make_field_c(field);
+    const LevelSet lv = make_level_set(grid);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (normal)
+        sdf_eval_kernel<true><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, n, sdf,
+                                                     feat, normal);
+    else
+        sdf_eval_kernel<false><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, n, sdf,
+                                                      feat, nullptr);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                  const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
+                                  int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
+                                  void* workspace, void* stream) {
+    LS2FM_CHECK_ARG(field_ok(field, grid, params) && n_rays >= 0 && iters_max >= 0);
+    LS2FM_CHECK_ARG(trips);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(trips, 0, sizeof(int32_t), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    if (n_rays == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(ray0 && ray_dir && near && far && track && t_end);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    Packed* pk = (Packed*)workspace;
+    int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
+    if (st != LS2FM_OK) return st;
+    const unsigned blocks = (unsigned)((2 * n_rays + 255) / 256);
+    sphere_trace_kernel<<<blocks, 256, 0, s>>>(make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk,
+                                               params->sdf_table, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far,
+                                               track, t_end, trips);
+    return ls2fm_launch_status();
+}

@@ -42,10 +42,10 @@ def supported(opt, sdf_field, rad_field=None) -> bool:
         return False
     if not _geometry_ok(sdf_field.SDF_MLP, 3 + 2 * desc.n_levels):
         return False
-    if opt.data.inside == True and opt.data.bg_sdf == True:  # noqa: E712
-        return False
     if rad_field is None:
-        return True
+        return True              # sdf_eval / sphere_trace (they implement the background-sphere min)
+    if opt.data.inside == True and opt.data.bg_sdf == True:  # noqa: E712
+        return False             # fused render: no background-sphere min
     if opt.SDF.VolSDF.volsdf_sampling != False or not 1 <= int(opt.SDF.VolSDF.sample_intvs) <= 512:  # noqa: E712
         return False
     dual = opt.Ablate_config.dual_field == True  # noqa: E712
@@ -79,7 +79,7 @@ def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
     return True
 
 
-_HAS_SDF_EVAL = False           # flipped on once the fused sdf_eval / sphere_trace kernels are built in
+_HAS_SDF_EVAL = True
 
 
 # ------------------------------------------------------------------------------------------------ descriptors
@@ -231,9 +231,58 @@ def render(renderer, opt, center, ray, sdf_field, rad_field):
 
 
 # ------------------------------------------------------------------------------------------------ sdf eval / tracing
-def sdf_eval(sdf_field, xyz, want_feat=False):
-    raise RuntimeError("fused sdf_eval not built")
+def _sdf_only_params(sdf_field):
+    ts, _ = param_tensors(sdf_field, None)
+    ts = [t.detach().contiguous() for t in ts]
+    return ts, _params_struct(ts, False, float(sdf_field.beta_speed), with_rad=False)
+
+
+def _sdf_workspace(dev):
+    n = _lib.load().ls2fm_sdf_eval_workspace_bytes()
+    return torch.empty(n // 4, device=dev, dtype=torch.float32)
+
+
+def sdf_eval(sdf_field, xyz, want_feat=False, want_normal=False):
+    """no-graph SDF.infer_sdf: xyz [...,3] -> sdf [...,1], feat [...,17] | None (, normal [...,3])"""
+    lib = _lib.load()
+    shape = tuple(xyz.shape[:-1])
+    p = xyz.detach().reshape(-1, 3).float().contiguous()
+    n = p.shape[0]
+    dev = p.device
+    sdf = torch.empty(n, device=dev)
+    feat = torch.empty(n, _lib.FEAT + 1, device=dev) if want_feat else None
+    normal = torch.empty(n, 3, device=dev) if want_normal else None
+    keep, pstruct = _sdf_only_params(sdf_field)
+    fdesc = field_desc(sdf_field.opt)
+    ws = _sdf_workspace(dev)
+    check(lib.ls2fm_sdf_eval(ctypes.byref(fdesc), ctypes.byref(sdf_field.embed_fn.embedder_obj.desc), ctypes.byref(pstruct),
+                             ptr(p), n, ptr(sdf), ptr(feat), ptr(normal), ptr(ws), stream_ptr()), "ls2fm_sdf_eval")
+    out = (sdf.view(*shape, 1), feat.view(*shape, -1) if want_feat else None)
+    return out + (normal.view(*shape, 3),) if want_normal else out
 
 
 def sphere_trace(sdf_field, o, d):
-    raise RuntimeError("fused sphere_trace not built")
+    """the reference's root-find loop (SDF.py:149-200) in one kernel.
+    o, d [R,3] -> near [R], far [R], pts_tracks [R,K,3], t_end [R] (far-end distance after K trips), K"""
+    lib = _lib.load()
+    o = o.detach().float().contiguous()
+    d = d.detach().float().contiguous()
+    n = o.shape[0]
+    dev = o.device
+    it = int(sdf_field.iters_max)
+    near = torch.empty(n, device=dev)
+    far = torch.empty(n, device=dev)
+    track = torch.empty(n, it + 1, 3, device=dev)
+    t_end = torch.empty(n, it + 1, device=dev)
+    trips = torch.zeros(1, device=dev, dtype=torch.int32)
+    keep, pstruct = _sdf_only_params(sdf_field)
+    fdesc = field_desc(sdf_field.opt)
+    ws = _sdf_workspace(dev)
+    check(lib.ls2fm_sphere_trace(ctypes.byref(fdesc), ctypes.byref(sdf_field.embed_fn.embedder_obj.desc),
+                                 ctypes.byref(pstruct), ptr(o), ptr(d), n, float(sdf_field.sdf_threshold), it, ptr(near),
+                                 ptr(far), ptr(track), ptr(t_end), ptr(trips), ptr(ws), stream_ptr()), "ls2fm_sphere_trace")
+    k = int(trips.item())           # the reference syncs here too (its loop condition is a host-side .sum())
+    from . import dist as _dist
+    k = _dist.global_max_int(k, dev)                  # sharded rays: keep K identical to the single-GPU run
+    pts = track[:, :max(k, 1), :]                     # K == 0: the single current point (SDF.py:201-202)
+    return near, far, pts, t_end[:, k], k

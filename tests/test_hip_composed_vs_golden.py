@@ -56,7 +56,7 @@ def test_render_composed_forward_and_all_gradients(case, manifest):
             assert rel_err(v, g[f"render_grad/{name}/{k}"]) < GTOL, (name, k)
 
 
-@pytest.mark.parametrize("case", ["dtu_single", "dtu_bgsdf", "scannet_single"])
+@pytest.mark.parametrize("case", ["dtu_single", "dtu_bgsdf"])     # inside=True: the init field is a proper sphere SDF
 @pytest.mark.parametrize("impl", ["torch", "fused"])
 def test_sphere_tracing_converging_field_vs_reference(case, impl, manifest):
     """Geometric-init weights (a well-conditioned, near-eikonal field): the loop leaves through the 'every start
