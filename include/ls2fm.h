@@ -208,6 +208,18 @@ int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* gri
                        int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
                        void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
+ * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the
+ * call's own stream; ls2fm_profile_get() synchronises those events and returns, per internal kernel, the
+ * accumulated device time in milliseconds and the number of launches.  Single-threaded use.
+ */
+int ls2fm_profile_enable(int on);
+int ls2fm_profile_reset(void);
+int ls2fm_profile_count(void);
+const char* ls2fm_profile_name(int index);
+int ls2fm_profile_get(int index, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,15 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------- shade_bwd
+struct LevelScales { float s[LS2FM_MAX_LEVELS]; };
+
+// wave-wide max of a non-negative float -> one LDS slot per (wave, level); combined per ray after a barrier
+__device__ __forceinline__ void publish_max(float v, int lane, float* dst) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (lane == 0) *dst = v;
+}
+
 struct Upstream {                  // dL/d(outputs of render_fwd); any pointer may be null (= zeros)
     const float* d_rgb;            // [R,3]
     const float* d_sdfs;           // [R,N]
@@ -31,11 +40,12 @@ struct Upstream {                  // dL/d(outputs of render_fwd); any pointer m
 
 template <bool DUAL, int MAXT>
 __global__ void __launch_bounds__(MAXT)
-shade_bwd_kernel(FieldC fc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
+shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
                  Upstream up, float* __restrict__ out) {
     __shared__ float s_part[16][8];
     __shared__ double s_db[16];
+    __shared__ float s_bound[16][32];
     const int N = fc.n_samples;
     const int64_t r = blockIdx.x;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
@@ -258,6 +268,19 @@ shade_bwd_kernel(FieldC fc, int ch1, int ch2, WsLayout w, const Packed* __restri
         for (int o = 0; o < kOut; ++o) out[w.gf + o * P + i] = gf[o];
     }
 
+    // per-level bound of a single scatter contribution |w de + D rr| <= |de| + scale |gn|_1 |rr|: fixes the fixed-point
+    // quantum of the slab scatter's integer accumulators
+    {
+        const float g1 = fabsf(gns[0]) + fabsf(gns[1]) + fabsf(gns[2]);
+#pragma unroll
+        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
+            if (2 * l < ch1) {
+                const float b = fmaxf(fabsf(de[3 + 2 * l]), fabsf(de[4 + 2 * l])) +
+                                lsc.s[l] * g1 * fmaxf(fabsf(rr[3 + 2 * l]), fabsf(rr[4 + 2 * l]));
+                publish_max(live ? b : 0.f, lane, &s_bound[wave][l]);
+            }
+    }
+
     // ---- second field: plain first-order backward of its Geometry MLP
     if (DUAL) {
 #pragma unroll
@@ -296,6 +319,19 @@ shade_bwd_kernel(FieldC fc, int ch1, int ch2, WsLayout w, const Packed* __restri
 #pragma unroll
             for (int o = 0; o < kOut; ++o) out[w.gf2 + o * P + i] = gf2[o];
         }
+#pragma unroll
+        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
+            if (2 * l < ch2)
+                publish_max(live ? fmaxf(fabsf(de[3 + 2 * l]), fabsf(de[4 + 2 * l])) : 0.f, lane, &s_bound[wave][16 + l]);
+    }
+    // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
+    __syncthreads();
+    if (n < 32) {
+        const bool used = n < 16 ? (2 * n < ch1) : (DUAL && 2 * (n - 16) < ch2);
+        float b = 0.f;
+        if (used)
+            for (int q = 0; q < n_waves; ++q) b = fmaxf(b, s_bound[q][n]);
+        out[w.smax + n * w.r_pad + r] = b;
     }
 }
 
@@ -546,8 +582,9 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- C ABI
-int ls2fm_launch_slab_scatter(const ls2fm_grid_desc* grid, const float* x4, int64_t n_points, int64_t p_pad,
-                              const float* rec, bool second_order, float* dtable, hipStream_t stream);
+int ls2fm_launch_slab_scatter(const ls2fm_grid_desc* grid, const float* x4, const uint32_t* keys, int64_t n_points,
+                              int64_t p_pad, const float* rec, bool second_order, const float* ray_bound, int64_t n_rays,
+                              float* dtable, hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -558,7 +595,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LS2FM_CHECK_ARG(field && grid_desc_ok(sdf_grid) && params && grads && n_rays >= 0);
     LS2FM_CHECK_ARG(!field->dual_field || grid_desc_ok(rad_grid));
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;
-    if (field->dual_field && rad_grid->n_levels != sdf_grid->n_levels) return LS2FM_ERR_UNSUPPORTED;
+    if (field->dual_field && !same_grid_geometry(sdf_grid, rad_grid)) return LS2FM_ERR_UNSUPPORTED;
     if (field->n_samples < 1 || field->n_samples > 512) return LS2FM_ERR_UNSUPPORTED;
     if (d_center || d_ray) return LS2FM_ERR_UNSUPPORTED;   // pose gradients: general (composed) form
     if (n_rays == 0) return LS2FM_OK;
@@ -576,11 +613,14 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
 
     if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (WgLayout::total), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
     if (hipMemsetAsync(ws + w.dbeta, 0, sizeof(float) * 64, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    LevelScales lsc;
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
     const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
     const int threads = (field->n_samples + 63) / 64 * 64;
+    ls2fm_prof_mark(LS2FM_PROF_SHADE_BWD, s);
 #define LS2FM_SHADE_BWD(DUAL, MAXT) \
-    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, 2 * L1, 2 * L2, w, pk, center, ray, ws, up, ws)
+    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, 2 * L1, 2 * L2, w, pk, center, ray, ws, up, ws)
     if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD
@@ -612,19 +652,27 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         add(seg(w.da2, 64), none, {seg(w.pu, 3), seg(w.e2, 2 * L2), Seg{nullptr, 32 - 2 * L2, 0}, ones}, w.p, P, WgLayout::dG0, 36);
         add(seg(w.gf2, 17), none, {seg(w.h2, 64), ones}, w.p, P, WgLayout::dG1, 65);
     }
+    ls2fm_prof_mark(LS2FM_PROF_WGRAD, s);
     wgrad_kernel<<<dim3((unsigned)w.nblk, (unsigned)nj), 256, 0, s>>>(jobs, w.nblk, ws + w.part);
+    ls2fm_prof_mark(LS2FM_PROF_WGRAD_REDUCE, s);
     wgrad_reduce_kernel<<<dim3((64 * 80 + 63) / 64, (unsigned)nj), 256, 0, s>>>(jobs, w.nblk, ws + w.part, ws + w.wg);
 
     // hash-table gradients: LDS-slab scatter (no table-wide global atomics; the tables are overwritten in full)
     {
-        int st = ls2fm_launch_slab_scatter(sdf_grid, ws + w.x4, w.p, P, ws + w.rec1, true, grads->sdf_table, s);
+        ls2fm_prof_mark(LS2FM_PROF_SCATTER_SDF, s);
+        int st = ls2fm_launch_slab_scatter(sdf_grid, ws + w.x4, reinterpret_cast<const uint32_t*>(ws + w.keys), w.p, P, ws + w.rec1, true,
+                                           ws + w.smax, n_rays, grads->sdf_table, s);
         if (st != LS2FM_OK) return st;
         if (dual) {
-            st = ls2fm_launch_slab_scatter(rad_grid, ws + w.x4, w.p, P, ws + w.rec2, false, grads->rad_table, s);
+            ls2fm_prof_mark(LS2FM_PROF_SCATTER_RAD, s);
+            st = ls2fm_launch_slab_scatter(rad_grid, ws + w.x4, reinterpret_cast<const uint32_t*>(ws + w.keys), w.p, P, ws + w.rec2, false,
+                                               ws + w.smax + 16 * w.r_pad, n_rays, grads->rad_table, s);
             if (st != LS2FM_OK) return st;
         }
     }
+    ls2fm_prof_mark(LS2FM_PROF_FINALIZE, s);
     finalize_kernel<<<1, 256, 0, s>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
                                       ws + w.dbeta);
+    ls2fm_prof_mark(-1, s);
     return ls2fm_launch_status();
 }

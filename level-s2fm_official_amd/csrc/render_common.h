@@ -9,6 +9,14 @@
 
 #include "ls2fm_device.h"
 
+// opt-in per-kernel timing (profile.hip): a mark before every launch, a mark with id -1 at the end of a call
+enum ls2fm_prof_id {
+    LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
+    LS2FM_PROF_WGRAD, LS2FM_PROF_WGRAD_REDUCE, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
+    LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_COUNT
+};
+void ls2fm_prof_mark(int id, hipStream_t stream);
+
 constexpr int kHidden = LS2FM_HIDDEN;     // 64
 constexpr int kOut = LS2FM_FEAT + 1;      // 17: sdf + 16 features
 constexpr int kInMax = 3 + 2 * LS2FM_MAX_LEVELS;   // 35
@@ -142,18 +150,30 @@ __device__ __forceinline__ float view_component(const float d[3], int c) {
     return (q & 1) ? cosf(x) : sinf(x);
 }
 
+// The second field's grid must have the geometry of the SDF grid (it does: both are built from the same
+// encoding config, models/RadF.py:35-39): the scatter's slab-test keys are computed once and shared.
+static inline bool same_grid_geometry(const ls2fm_grid_desc* a, const ls2fm_grid_desc* b) {
+    if (a->n_levels != b->n_levels) return false;
+    for (int l = 0; l < a->n_levels; ++l)
+        if (a->scale[l] != b->scale[l] || a->resolution[l] != b->resolution[l] || a->size[l] != b->size[l] ||
+            a->hashed[l] != b->hashed[l])
+            return false;
+    return true;
+}
+
 // Workspace carve-up (offsets in floats).  Channels are SoA with stride p_pad.
 struct WsLayout {
     int64_t p, p_pad, r_pad;
     int l1, l2, dual;
     // forward -> backward
-    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4;
+    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4, keys;
     // backward scratch
-    int64_t rec1, rec2, da, g, h, sq, v, pu, p3, gf, dz, da2, h2, gf2, dzr, renc, part, wg, dbeta;
+    int64_t rec1, rec2, da, g, h, sq, v, pu, p3, gf, dz, da2, h2, gf2, dzr, renc, part, wg, dbeta, smax;
     int64_t total;
     int nblk;
 };
 
+constexpr int kSlabShift = 13;          // table-gradient scatter: 8192-entry slabs (slab_scatter.hip)
 constexpr int kWgradKB = 1024;         // points per wgrad block
 constexpr int kWgradJobs = 8;
 constexpr int kWgradTile = 64 * 80;    // max M x N of one job
@@ -189,6 +209,7 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.fe = take(16 * P);
     w.fe2 = take(dual ? 16 * P : 0);
     w.ones = take(P);
+    w.keys = take((int64_t)l1 * P); // uint32 per (level, point): slab-test key for the table-gradient scatter
     w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
     w.rec1 = take(8 * (int64_t)l1 * P);          // [level][point]{de0 de1 rr0 rr1 gn0 gn1 gn2 -}: SDF-grid scatter payload
     w.rec2 = take(dual ? 2 * (int64_t)l2 * P : 0); // [level][point]{de0 de1}: second-grid scatter payload
@@ -211,6 +232,7 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.part = take((int64_t)kWgradJobs * w.nblk * kWgradTile);
     w.wg = take(WgLayout::total);
     w.dbeta = take(64);
+    w.smax = take(32 * w.r_pad); // [32][r_pad]: per-ray bound of one scatter contribution per level ([0,16) SDF grid, [16,32) second grid)
     w.total = o;
     return w;
 }

@@ -130,7 +130,8 @@ template <bool WITH_JAC>
 __global__ void __launch_bounds__(256)
 ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
                   const float* __restrict__ table, int64_t n_points, int64_t p_pad, float* __restrict__ enc,
-                  float* __restrict__ jac, float* __restrict__ ones, float* __restrict__ xs) {
+                  float* __restrict__ jac, float* __restrict__ ones, float* __restrict__ xs,
+                  uint32_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int l = blockIdx.y;
     if (i >= n_points) return;
@@ -166,6 +167,32 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
             jac[((2 * l + 0) * 3 + gd) * p_pad + i] = lv.scale[l] * g0;
             jac[((2 * l + 1) * 3 + gd) * p_pad + i] = lv.scale[l] * g1;
         }
+    }
+    if (keys) {
+        // slab-test key of the gradient scatter (slab_scatter.hip): hashed power-of-two level -> the slab ids
+        // (entry index >> kSlabShift, 6 bits each) of the four (y,z) corner pairs; both x-corners of a pair lie in the
+        // same slab unless cx+1 crosses a slab-sized boundary.  Dense level -> first corner index.
+        // ~0u = "decide exactly in the process phase".
+        uint32_t cell[3];
+        float wd;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pos_fract(x[a], lv.scale[l], cell[a], wd);
+        uint32_t key = 0xFFFFFFFFu;
+        const uint32_t res = lv.res[l], size = lv.size[l];
+        if (lv.hashed[l]) {
+            const uint32_t mask = size - 1u;
+            if ((size & mask) == 0u && (size >> kSlabShift) >= 1u && (size >> kSlabShift) <= 64u &&
+                ((cell[0] ^ (cell[0] + 1u)) >> kSlabShift) == 0u) {
+                const uint32_t y0 = cell[1] * LS2FM_PRIME_Y, y1 = (cell[1] + 1u) * LS2FM_PRIME_Y;
+                const uint32_t z0 = cell[2] * LS2FM_PRIME_Z, z1 = (cell[2] + 1u) * LS2FM_PRIME_Z;
+                key = (((cell[0] ^ y0 ^ z0) & mask) >> kSlabShift) | ((((cell[0] ^ y1 ^ z0) & mask) >> kSlabShift) << 6) |
+                      ((((cell[0] ^ y0 ^ z1) & mask) >> kSlabShift) << 12) | ((((cell[0] ^ y1 ^ z1) & mask) >> kSlabShift) << 18);
+            }
+        } else if (cell[0] < res && cell[1] < res && cell[2] < res) {
+            const uint32_t first = cell[0] + cell[1] * res + cell[2] * res * res;
+            if (first + 1u + res + res * res < size) key = first;
+        }
+        keys[(int64_t)l * p_pad + i] = key;
     }
     if (ones && l == 0) {
         ones[i] = 1.0f;
@@ -301,6 +328,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
 int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream) {
+    ls2fm_prof_mark(LS2FM_PROF_PREP, stream);
     prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out);
     return ls2fm_launch_status();
 }
@@ -327,7 +355,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
                                 float* depth_mlp, float* normal_mlp, void* workspace, void* stream) {
     LS2FM_CHECK_ARG(render_config_ok(field, sdf_grid, rad_grid) && params && n_rays >= 0);
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;       // min(sdf, bg_rad-|p|): general (composed) form only
-    if (field->dual_field && rad_grid->n_levels != sdf_grid->n_levels) return LS2FM_ERR_UNSUPPORTED;
+    if (field->dual_field && !same_grid_geometry(sdf_grid, rad_grid)) return LS2FM_ERR_UNSUPPORTED;
     if (n_rays == 0) return LS2FM_OK;
     LS2FM_CHECK_ARG(center && ray && rgb && sdfs_volume && normals && depth_mlp && normal_mlp);
     if (!workspace) return LS2FM_ERR_WORKSPACE;
@@ -340,16 +368,21 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const FieldC fc = make_field_c(field);
     const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
 
+    ls2fm_prof_mark(LS2FM_PROF_PREP, s);
     prep_weights_kernel<<<1, 256, 0, s>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
     const dim3 eg((unsigned)((w.p + 255) / 256), (unsigned)L1);
+    ls2fm_prof_mark(LS2FM_PROF_ENCODE_SDF, s);
     ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p,
-                                              w.p_pad, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4);
+                                              w.p_pad, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4,
+                                              reinterpret_cast<uint32_t*>(ws + w.keys));
     if (dual) {
         const dim3 eg2((unsigned)((w.p + 255) / 256), (unsigned)L2);
+        ls2fm_prof_mark(LS2FM_PROF_ENCODE_RAD, s);
         ray_encode_kernel<false><<<eg2, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p,
-                                                    w.p_pad, ws + w.e2, nullptr, nullptr, nullptr);
+                                                    w.p_pad, ws + w.e2, nullptr, nullptr, nullptr, nullptr);
     }
     const int threads = (field->n_samples + 63) / 64 * 64;
+    ls2fm_prof_mark(LS2FM_PROF_SHADE_FWD, s);
 #define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                              \
     shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                            \
         fc, 2 * L1, 2 * L2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb,     \
@@ -358,5 +391,6 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 1024); }
     else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 1024); }
 #undef LS2FM_SHADE_FWD
+    ls2fm_prof_mark(-1, s);
     return ls2fm_launch_status();
 }

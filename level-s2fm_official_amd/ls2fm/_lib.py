@@ -95,6 +95,11 @@ _SIGNATURES = {
                                    c_int64, _P, _P, _P, _P, _P, POINTER(ParamGrads), _P, _P, _P, _P]),
     "ls2fm_sphere_trace": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
                                      c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ls2fm_profile_enable": (c_int32, [c_int32]),
+    "ls2fm_profile_reset": (c_int32, []),
+    "ls2fm_profile_count": (c_int32, []),
+    "ls2fm_profile_name": (c_char_p, [c_int32]),
+    "ls2fm_profile_get": (c_int32, [c_int32, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1,0 +1,63 @@
+"""Per-kernel device times from the library's opt-in HIP-event profiling (include/ls2fm.h, "Opt-in per-kernel
+timing") and the roofline bookkeeping of bench.py.
+
+Algorithmic work per launch (P = sample points of one batch, L = hash levels, 8 corners x 2 features
+x 4 B = 64 B per level per point):
+  ray_encode_*    : P * L * 64 B  gathered from the table                       -> HBM roofline
+  slab_scatter_*  : P * L * 64 B  accumulated into the table gradient          -> HBM roofline
+  shade_fwd       : P * 2 * MACs  (SDF MLP 35*64 + 64*17, normal W0^T 35*64 + 96, second field 35*64 + 64*17,
+                    collapsed radiance 3*38)                                    -> f32 MFMA/VALU roofline
+  shade_bwd       : P * 2 * MACs  (a, q, dE, r: 4 * 35*64; W1^T g 17*64; second field 2 * 35*64 + 16*64)
+  wgrad           : 2 * P * sum(M*N) over the weight-gradient GEMMs (f32 MFMA)
+"""
+from __future__ import annotations
+
+import ctypes
+
+
+def kernel_times(lib):
+    """{name: (avg_us, launches, total_ms)} for every internal kernel that ran while profiling was enabled"""
+    out = {}
+    for i in range(lib.ls2fm_profile_count()):
+        total = ctypes.c_double(0.0)
+        launches = ctypes.c_int64(0)
+        lib.ls2fm_profile_get(i, ctypes.byref(total), ctypes.byref(launches))
+        if launches.value:
+            out[lib.ls2fm_profile_name(i).decode()] = (total.value * 1e3 / launches.value, launches.value, total.value)
+    return out
+
+
+def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
+    """name -> (bound, work per launch, unit work): bytes for the table kernels, FLOPs for the dense ones"""
+    table_bytes = n_points * n_levels * 64
+    fwd_macs = 35 * 64 + 64 * 17 + 35 * 64 + 96 + 3 * (6 + 16 + (16 if dual else 0)) + (35 * 64 + 64 * 17 if dual else 0)
+    bwd_macs = 4 * 35 * 64 + 17 * 64 + 96 + (2 * 35 * 64 + 16 * 64 if dual else 0)
+    wgrad_mn = 64 * 36 + 64 * 35 + 17 * 65 + 64 + 3 * 39 + (64 * 36 + 17 * 65 if dual else 0)
+    return {
+        "ray_encode_sdf": ("hbm", table_bytes), "ray_encode_rad": ("hbm", table_bytes),
+        "slab_scatter_sdf": ("hbm", table_bytes), "slab_scatter_rad": ("hbm", table_bytes),
+        "shade_fwd": ("mfma", 2 * fwd_macs * n_points), "shade_bwd": ("mfma", 2 * bwd_macs * n_points),
+        "wgrad": ("mfma", 2 * wgrad_mn * n_points),
+    }
+
+
+def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float, f32_peak_tflops: float):
+    """roofline object of bench.py's JSON line for the kernel with the largest share of device time"""
+    times = kernel_times(lib)
+    if not times:
+        return None
+    work = algorithmic_work(n_points, dual)
+    name = max(times, key=lambda k: times[k][2])
+    avg_us, launches, total_ms = times[name]
+    grand = sum(t[2] for t in times.values())
+    bound, amount = work.get(name, ("hbm", 0))
+    if bound == "hbm":
+        achieved, peak, unit = amount / (avg_us * 1e-6) / 1e9, hbm_peak_gbs, "GB/s"
+    else:
+        achieved, peak, unit = amount / (avg_us * 1e-6) / 1e12, f32_peak_tflops, "TFLOP/s"
+    return {
+        "kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+        "traffic": None, "avg_launch_us": avg_us, "launches": launches, "share_of_device_time": total_ms / grand,
+        "algorithmic_per_launch": amount,
+        "all_kernels_avg_us": {k: round(v[0], 2) for k, v in sorted(times.items(), key=lambda kv: -kv[1][2])},
+    }
