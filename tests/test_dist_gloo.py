@@ -1,0 +1,92 @@
+"""world_size-2 CPU (gloo) coverage of the multi-GPU form of the path: ray sharding, the gradient all-reduce (big tensors
++ the flat small-gradient buffer), world-size-invariant masked means and the sphere-tracing trip-count reduction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ls2fm import dist as ldist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert ldist.is_distributed()
+        # ---- sharding: by view when the views divide evenly, otherwise contiguous ray ranges
+        g = torch.Generator().manual_seed(0)
+        center = torch.randn(4, 6, 3, generator=g)
+        ray = torch.randn(4, 6, 3, generator=g)
+        c, r = ldist.shard_rays(center, ray)
+        assert c.shape == (2, 6, 3) and torch.equal(c, center[rank * 2:(rank + 1) * 2])
+        c3, r3 = ldist.shard_rays(center[:3], ray[:3])            # 3 views over 2 ranks -> flattened ranges
+        assert c3.shape[0] == 1 and c3.shape[1] == 9
+        assert torch.equal(c3[0], center[:3].reshape(-1, 3)[rank * 9:(rank + 1) * 9])
+        # every ray is owned by exactly one rank
+        owned = torch.zeros(18)
+        owned[rank * 9:(rank + 1) * 9] = 1
+        dist.all_reduce(owned)
+        assert torch.equal(owned, torch.ones(18))
+
+        # ---- gradient all-reduce: one big tensor + several small ones
+        big = torch.nn.Parameter(torch.zeros(1 << 20))
+        smalls = [torch.nn.Parameter(torch.zeros(64, 35)), torch.nn.Parameter(torch.zeros(64, 1)),
+                  torch.nn.Parameter(torch.zeros(1))]
+        big.grad = torch.full_like(big, float(rank + 1))
+        for k, p in enumerate(smalls):
+            p.grad = torch.full_like(p, float((rank + 1) * (k + 2)))
+        red = ldist.GradAllReducer([big, *smalls])
+        red.all_reduce()
+        assert torch.equal(big.grad, torch.full_like(big, 3.0))
+        for k, p in enumerate(smalls):
+            assert torch.equal(p.grad, torch.full_like(p, 3.0 * (k + 2)))
+        # the fused backward's flat small-gradient buffer is reduced in place, without packing
+        from ls2fm import fused
+        flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        fused._SMALL_GRADS = flat
+        a, b = torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))
+        a.grad, b.grad = flat[:6].view(2, 3), flat[6:]
+        ldist.GradAllReducer([a, b]).all_reduce()
+        assert torch.equal(flat, torch.arange(10, dtype=torch.float32) * 3)
+        assert a.grad.data_ptr() == flat.data_ptr()
+        fused._SMALL_GRADS = None
+
+        # ---- masked mean is world-size invariant (sum / count all-reduced separately)
+        vals = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+        mask = torch.tensor([1, 1, 1, 1, 0, 1], dtype=torch.bool)           # unbalanced between the two halves
+        lo, hi = rank * 3, rank * 3 + 3
+        m = ldist.global_mean(vals[lo:hi][mask[lo:hi]].sum(), mask[lo:hi].sum())
+        assert abs(m.item() - vals[mask].mean().item()) < 1e-6
+        assert ldist.global_max_int(3 + 4 * rank, "cpu") == 7
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_single_process_paths_are_noops():
+    c, r = torch.zeros(2, 4, 3), torch.ones(2, 4, 3)
+    assert ldist.shard_rays(c, r, rank=0, world=1)[0] is c
+    assert not ldist.is_distributed()
+    assert ldist.global_max_int(5, "cpu") == 5
+    assert ldist.global_mean(torch.tensor(6.0), torch.tensor(3)).item() == 2.0
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    ldist.GradAllReducer([p]).all_reduce()
+    assert torch.equal(p.grad, torch.ones(3))
