@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/ls2fm.h"
 
@@ -15,9 +16,13 @@
 #define LS2FM_CHECK_ARG(cond) \
     do { if (!(cond)) return LS2FM_ERR_INVALID_ARGUMENT; } while (0)
 
-static inline int ls2fm_launch_status() {
-    return hipGetLastError() == hipSuccess ? LS2FM_OK : LS2FM_ERR_LAUNCH;
+static inline int ls2fm_launch_status_at(const char* file, int line) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return LS2FM_OK;
+    fprintf(stderr, "libls2fm_hip: %s (%s:%d)\n", hipGetErrorString(e), file, line);   // fail loudly
+    return LS2FM_ERR_LAUNCH;
 }
+#define ls2fm_launch_status() ls2fm_launch_status_at(__FILE__, __LINE__)
 
 // Per-level constants, passed by value in the kernel argument segment (scalar registers).
 struct LevelSet {

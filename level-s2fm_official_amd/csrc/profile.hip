@@ -11,44 +11,56 @@ namespace {
 
 const char* const kNames[LS2FM_PROF_COUNT] = {
     "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "wgrad", "wgrad_reduce",
-    "slab_scatter_sdf", "slab_scatter_rad", "finalize", "sdf_eval", "sphere_trace"};
+    "slab_scatter_sdf", "slab_scatter_rad", "finalize", "sdf_eval", "sphere_trace", "bin_build"};
 
-struct Mark { int id; hipEvent_t ev; };
+struct Span { int id; hipEvent_t a, b; };
 
 std::mutex g_mu;
 bool g_enabled = false;
-std::vector<Mark> g_marks;
+std::vector<Span> g_spans;
 std::vector<hipEvent_t> g_pool;
 double g_total_ms[LS2FM_PROF_COUNT] = {};
 int64_t g_launches[LS2FM_PROF_COUNT] = {};
 
+hipEvent_t take_event() {
+    hipEvent_t ev = nullptr;
+    if (!g_pool.empty()) { ev = g_pool.back(); g_pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+    return ev;
+}
+
 void resolve_locked() {
-    for (size_t i = 0; i + 1 < g_marks.size(); ++i) {
-        const int id = g_marks[i].id;
-        if (id < 0 || id >= LS2FM_PROF_COUNT) continue;
-        if (hipEventSynchronize(g_marks[i + 1].ev) != hipSuccess) continue;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_marks[i].ev, g_marks[i + 1].ev) == hipSuccess) {
-            g_total_ms[id] += ms;
-            g_launches[id] += 1;
+    for (const Span& sp : g_spans) {
+        if (sp.a && sp.b && sp.id >= 0 && sp.id < LS2FM_PROF_COUNT && hipEventSynchronize(sp.b) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { g_total_ms[sp.id] += ms; g_launches[sp.id] += 1; }
         }
+        if (sp.a) g_pool.push_back(sp.a);
+        if (sp.b) g_pool.push_back(sp.b);
     }
-    for (const Mark& m : g_marks) g_pool.push_back(m.ev);
-    g_marks.clear();
+    g_spans.clear();
 }
 
 }  // namespace
 
-// id >= 0: a kernel of that id is about to be enqueued on `stream`; id < 0: end of the current call
-void ls2fm_prof_mark(int id, hipStream_t stream) {
+void ls2fm_prof_begin(int id, hipStream_t stream) {
     if (!g_enabled) return;
     std::lock_guard<std::mutex> lock(g_mu);
-    hipEvent_t ev;
-    if (!g_pool.empty()) { ev = g_pool.back(); g_pool.pop_back(); }
-    else if (hipEventCreate(&ev) != hipSuccess) return;
-    (void)hipEventRecord(ev, stream);
-    g_marks.push_back({id, ev});
-    if (g_marks.size() > 1u << 16) resolve_locked();          // bound the backlog (synchronises)
+    Span sp{id, take_event(), nullptr};
+    if (sp.a) (void)hipEventRecord(sp.a, stream);
+    g_spans.push_back(sp);
+}
+
+void ls2fm_prof_end(int id, hipStream_t stream) {
+    if (!g_enabled) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (size_t k = g_spans.size(); k-- > 0;)
+        if (g_spans[k].id == id && !g_spans[k].b) {
+            g_spans[k].b = take_event();
+            if (g_spans[k].b) (void)hipEventRecord(g_spans[k].b, stream);
+            break;
+        }
+    if (g_spans.size() > (1u << 15)) resolve_locked();          // bound the backlog (synchronises)
 }
 
 extern "C" int ls2fm_profile_enable(int on) {

@@ -248,13 +248,14 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         }
     }
     if (live) {
-        // scatter payload of the SDF grid: one 32-byte record per (level, point)
+        // scatter payload of the SDF grid: one 64-byte record (one cache line half) per (level, point)
 #pragma unroll
         for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
             if (2 * l < ch1) {
-                float4* dst = reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + i) * 8);
-                dst[0] = make_float4(de[3 + 2 * l], de[4 + 2 * l], rr[3 + 2 * l], rr[4 + 2 * l]);
-                dst[1] = make_float4(gns[0], gns[1], gns[2], 0.f);
+                float4* dst = reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + i) * 16);
+                dst[0] = make_float4(x[0], x[1], x[2], 0.f);
+                dst[1] = make_float4(de[3 + 2 * l], de[4 + 2 * l], rr[3 + 2 * l], rr[4 + 2 * l]);
+                dst[2] = make_float4(gns[0], gns[1], gns[2], 0.f);
             }
 #pragma unroll
         for (int k = 0; k < kInMax; ++k) out[w.v + k * P + i] = v[k];
@@ -314,8 +315,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         if (live) {
 #pragma unroll
             for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
-                if (2 * l < ch2)
-                    *reinterpret_cast<float2*>(out + w.rec2 + ((int64_t)l * P + i) * 2) = make_float2(de[3 + 2 * l], de[4 + 2 * l]);
+                if (2 * l < ch2) {
+                    float4* dst = reinterpret_cast<float4*>(out + w.rec2 + ((int64_t)l * P + i) * 8);
+                    dst[0] = make_float4(x[0], x[1], x[2], 0.f);
+                    dst[1] = make_float4(de[3 + 2 * l], de[4 + 2 * l], 0.f, 0.f);
+                }
 #pragma unroll
             for (int o = 0; o < kOut; ++o) out[w.gf2 + o * P + i] = gf2[o];
         }
@@ -582,9 +586,11 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- C ABI
-int ls2fm_launch_slab_scatter(const ls2fm_grid_desc* grid, const float* x4, const uint32_t* keys, int64_t n_points,
-                              int64_t p_pad, const float* rec, bool second_order, const float* ray_bound, int64_t n_rays,
-                              float* dtable, hipStream_t stream);
+int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, int64_t n_points, int64_t p_pad, float* bins_ws,
+                           hipStream_t stream);
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, int64_t p_pad, const float* rec,
+                                 bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
+                                 hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -616,14 +622,28 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
+    // fork 1: the per-slab item lists depend on the forward's keys only -> built on the side stream under shade_bwd
+    SideCtx sc;
+    const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
+                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+    hipStream_t gs = forked ? sc.side : s;
+    ls2fm_prof_begin(LS2FM_PROF_BIN, gs);
+    {
+        const int st = ls2fm_launch_bin_build(sdf_grid, reinterpret_cast<const uint32_t*>(ws + w.keys), w.p, P, ws + w.bins, gs);
+        if (st != LS2FM_OK) return st;
+    }
+    ls2fm_prof_end(LS2FM_PROF_BIN, gs);
+    if (forked && hipEventRecord(sc.mid, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
+
     const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
     const int threads = (field->n_samples + 63) / 64 * 64;
-    ls2fm_prof_mark(LS2FM_PROF_SHADE_BWD, s);
+    ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
 #define LS2FM_SHADE_BWD(DUAL, MAXT) \
     shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, 2 * L1, 2 * L2, w, pk, center, ray, ws, up, ws)
     if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD
+    ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
 
     // weight-gradient GEMMs over all sample points
     WJobs jobs;
@@ -652,27 +672,37 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         add(seg(w.da2, 64), none, {seg(w.pu, 3), seg(w.e2, 2 * L2), Seg{nullptr, 32 - 2 * L2, 0}, ones}, w.p, P, WgLayout::dG0, 36);
         add(seg(w.gf2, 17), none, {seg(w.h2, 64), ones}, w.p, P, WgLayout::dG1, 65);
     }
-    ls2fm_prof_mark(LS2FM_PROF_WGRAD, s);
-    wgrad_kernel<<<dim3((unsigned)w.nblk, (unsigned)nj), 256, 0, s>>>(jobs, w.nblk, ws + w.part);
-    ls2fm_prof_mark(LS2FM_PROF_WGRAD_REDUCE, s);
-    wgrad_reduce_kernel<<<dim3((64 * 80 + 63) / 64, (unsigned)nj), 256, 0, s>>>(jobs, w.nblk, ws + w.part, ws + w.wg);
+    // fork 2: weight-gradient GEMM -> reduce -> finalize run on the side stream, concurrently with the table scatters
+    if (forked && (hipEventRecord(sc.fork, s) != hipSuccess || hipStreamWaitEvent(sc.side, sc.fork, 0) != hipSuccess))
+        return LS2FM_ERR_LAUNCH;
+    ls2fm_prof_begin(LS2FM_PROF_WGRAD, gs);
+    wgrad_kernel<<<dim3((unsigned)w.nblk, (unsigned)nj), 256, 0, gs>>>(jobs, w.nblk, ws + w.part);
+    ls2fm_prof_end(LS2FM_PROF_WGRAD, gs);
+    ls2fm_prof_begin(LS2FM_PROF_WGRAD_REDUCE, gs);
+    wgrad_reduce_kernel<<<dim3((64 * 80 + 63) / 64, (unsigned)nj), 256, 0, gs>>>(jobs, w.nblk, ws + w.part, ws + w.wg);
+    ls2fm_prof_end(LS2FM_PROF_WGRAD_REDUCE, gs);
+    ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
+    finalize_kernel<<<1, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
+                                       ws + w.dbeta);
+    ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
+    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
 
-    // hash-table gradients: LDS-slab scatter (no table-wide global atomics; the tables are overwritten in full)
+    // hash-table gradients: LDS-owned slabs walking their binned item lists (bin_scatter.hip); tables overwritten in full
+    if (forked && hipStreamWaitEvent(s, sc.mid, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;         // item lists ready
     {
-        ls2fm_prof_mark(LS2FM_PROF_SCATTER_SDF, s);
-        int st = ls2fm_launch_slab_scatter(sdf_grid, ws + w.x4, reinterpret_cast<const uint32_t*>(ws + w.keys), w.p, P, ws + w.rec1, true,
-                                           ws + w.smax, n_rays, grads->sdf_table, s);
+        ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
+        int st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, P, ws + w.rec1, true, ws + w.smax, n_rays,
+                                              grads->sdf_table, s);
+        ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
         if (st != LS2FM_OK) return st;
         if (dual) {
-            ls2fm_prof_mark(LS2FM_PROF_SCATTER_RAD, s);
-            st = ls2fm_launch_slab_scatter(rad_grid, ws + w.x4, reinterpret_cast<const uint32_t*>(ws + w.keys), w.p, P, ws + w.rec2, false,
-                                               ws + w.smax + 16 * w.r_pad, n_rays, grads->rad_table, s);
+            ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
+            st = ls2fm_launch_slab_accumulate(rad_grid, ws + w.bins, w.p, P, ws + w.rec2, false, ws + w.smax + 16 * w.r_pad,
+                                              n_rays, grads->rad_table, s);
+            ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
             if (st != LS2FM_OK) return st;
         }
     }
-    ls2fm_prof_mark(LS2FM_PROF_FINALIZE, s);
-    finalize_kernel<<<1, 256, 0, s>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
-                                      ws + w.dbeta);
-    ls2fm_prof_mark(-1, s);
+    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();
 }

@@ -13,9 +13,14 @@
 enum ls2fm_prof_id {
     LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
     LS2FM_PROF_WGRAD, LS2FM_PROF_WGRAD_REDUCE, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
-    LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_COUNT
+    LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_BIN, LS2FM_PROF_COUNT
 };
-void ls2fm_prof_mark(int id, hipStream_t stream);
+void ls2fm_prof_begin(int id, hipStream_t stream);      // bracket one kernel launch on the stream it is enqueued on
+void ls2fm_prof_end(int id, hipStream_t stream);
+
+// internal fork/join (streams.hip)
+struct SideCtx { hipStream_t side; hipEvent_t fork, mid, join; };
+bool ls2fm_side_stream(SideCtx* out);
 
 constexpr int kHidden = LS2FM_HIDDEN;     // 64
 constexpr int kOut = LS2FM_FEAT + 1;      // 17: sdf + 16 features
@@ -161,6 +166,8 @@ static inline bool same_grid_geometry(const ls2fm_grid_desc* a, const ls2fm_grid
     return true;
 }
 
+int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points);
+
 // Workspace carve-up (offsets in floats).  Channels are SoA with stride p_pad.
 struct WsLayout {
     int64_t p, p_pad, r_pad;
@@ -168,7 +175,7 @@ struct WsLayout {
     // forward -> backward
     int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4, keys;
     // backward scratch
-    int64_t rec1, rec2, da, g, h, sq, v, pu, p3, gf, dz, da2, h2, gf2, dzr, renc, part, wg, dbeta, smax;
+    int64_t rec1, rec2, bins, da, g, h, sq, v, pu, p3, gf, dz, da2, h2, gf2, dzr, renc, part, wg, dbeta, smax;
     int64_t total;
     int nblk;
 };
@@ -211,8 +218,9 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.ones = take(P);
     w.keys = take((int64_t)l1 * P); // uint32 per (level, point): slab-test key for the table-gradient scatter
     w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
-    w.rec1 = take(8 * (int64_t)l1 * P);          // [level][point]{de0 de1 rr0 rr1 gn0 gn1 gn2 -}: SDF-grid scatter payload
-    w.rec2 = take(dual ? 2 * (int64_t)l2 * P : 0); // [level][point]{de0 de1}: second-grid scatter payload
+    w.rec1 = take(16 * (int64_t)l1 * P);         // [level][point]{x y z - | de0 de1 rr0 rr1 | gn0 gn1 gn2 - | pad}: 64-byte scatter payload (SDF grid)
+    w.rec2 = take(dual ? 8 * (int64_t)l2 * P : 0); // [level][point]{x y z - | de0 de1 - -}: 32-byte scatter payload (second grid)
+    w.bins = take(ls2fm_bins_workspace_floats(l1, w.p));   // per-slab item lists of the scatter (bin_scatter.hip)
     w.da = take(64 * P);
     w.g = take(64 * P);
     w.h = take(64 * P);

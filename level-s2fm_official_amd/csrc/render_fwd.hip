@@ -126,14 +126,20 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
 }
 
 // ------------------------------------------------------------------------------------------- ray_encode
+// Block -> (level, point chunk) mapping is XCD-aware: workgroup b is observed to run on XCD b % 8, and each XCD has a
+// private 4 MiB L2 -- exactly one 2^19-entry level of one table.  All workgroups of one XCD therefore work on the same
+// level at a time (levels xcd, xcd + 8, ...), so a level's table slice is fetched into ONE L2 once instead of into all
+// eight.  This is a speed choice only; any placement gives the same result.
 template <bool WITH_JAC>
 __global__ void __launch_bounds__(256)
 ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
-                  const float* __restrict__ table, int64_t n_points, int64_t p_pad, float* __restrict__ enc,
-                  float* __restrict__ jac, float* __restrict__ ones, float* __restrict__ xs,
-                  uint32_t* __restrict__ keys) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int l = blockIdx.y;
+                  const float* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks,
+                  float* __restrict__ enc, float* __restrict__ jac, float* __restrict__ ones,
+                  float* __restrict__ xs, uint32_t* __restrict__ keys) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int l = xcd + 8 * (j / n_chunks);
+    if (l >= lv.n_levels) return;
+    const int64_t i = (int64_t)(j % n_chunks) * 256 + threadIdx.x;
     if (i >= n_points) return;
     const int64_t r = i / fc.n_samples;
     const int n = (int)(i - r * fc.n_samples);
@@ -152,8 +158,9 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
         y0 = fmaf(wt, v[k].x, y0);
         y1 = fmaf(wt, v[k].y, y1);
     }
-    enc[(2 * l + 0) * p_pad + i] = y0;
-    enc[(2 * l + 1) * p_pad + i] = y1;
+    // streaming outputs: non-temporal so they do not evict the table slice from the XCD's L2
+    __builtin_nontemporal_store(y0, enc + (2 * l + 0) * p_pad + i);
+    __builtin_nontemporal_store(y1, enc + (2 * l + 1) * p_pad + i);
     if (WITH_JAC) {
 #pragma unroll
         for (int gd = 0; gd < 3; ++gd) {
@@ -164,8 +171,8 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
                 g0 = fmaf(dw, v[k].x, g0);
                 g1 = fmaf(dw, v[k].y, g1);
             }
-            jac[((2 * l + 0) * 3 + gd) * p_pad + i] = lv.scale[l] * g0;
-            jac[((2 * l + 1) * 3 + gd) * p_pad + i] = lv.scale[l] * g1;
+            __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+            __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
         }
     }
     if (keys) {
@@ -328,8 +335,9 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
 int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream) {
-    ls2fm_prof_mark(LS2FM_PROF_PREP, stream);
+    ls2fm_prof_begin(LS2FM_PROF_PREP, stream);
     prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out);
+    ls2fm_prof_end(LS2FM_PROF_PREP, stream);
     return ls2fm_launch_status();
 }
 
@@ -368,21 +376,31 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const FieldC fc = make_field_c(field);
     const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
 
-    ls2fm_prof_mark(LS2FM_PROF_PREP, s);
-    prep_weights_kernel<<<1, 256, 0, s>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
-    const dim3 eg((unsigned)((w.p + 255) / 256), (unsigned)L1);
-    ls2fm_prof_mark(LS2FM_PROF_ENCODE_SDF, s);
-    ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p,
-                                              w.p_pad, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4,
+    // fork: the single-workgroup weight prep (latency bound) overlaps with the wide hash-grid gather
+    SideCtx sc;
+    const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
+                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+    hipStream_t ps = forked ? sc.side : s;
+    ls2fm_prof_begin(LS2FM_PROF_PREP, ps);
+    prep_weights_kernel<<<1, 256, 0, ps>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
+    ls2fm_prof_end(LS2FM_PROF_PREP, ps);
+    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    const int n_chunks = (int)((w.p + 255) / 256);
+    const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
+    ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
+    ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
+                                              n_chunks, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4,
                                               reinterpret_cast<uint32_t*>(ws + w.keys));
+    ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
     if (dual) {
-        const dim3 eg2((unsigned)((w.p + 255) / 256), (unsigned)L2);
-        ls2fm_prof_mark(LS2FM_PROF_ENCODE_RAD, s);
-        ray_encode_kernel<false><<<eg2, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p,
-                                                    w.p_pad, ws + w.e2, nullptr, nullptr, nullptr, nullptr);
+        ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
+        ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,
+                                                   n_chunks, ws + w.e2, nullptr, nullptr, nullptr, nullptr);
+        ls2fm_prof_end(LS2FM_PROF_ENCODE_RAD, s);
     }
+    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     const int threads = (field->n_samples + 63) / 64 * 64;
-    ls2fm_prof_mark(LS2FM_PROF_SHADE_FWD, s);
+    ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
 #define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                              \
     shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                            \
         fc, 2 * L1, 2 * L2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb,     \
@@ -391,6 +409,6 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 1024); }
     else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 1024); }
 #undef LS2FM_SHADE_FWD
-    ls2fm_prof_mark(-1, s);
+    ls2fm_prof_end(LS2FM_PROF_SHADE_FWD, s);
     return ls2fm_launch_status();
 }

@@ -179,14 +179,14 @@ extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_de
     const FieldC fc = make_field_c(field);
     const LevelSet lv = make_level_set(grid);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    ls2fm_prof_mark(LS2FM_PROF_SDF_EVAL, s);
+    ls2fm_prof_begin(LS2FM_PROF_SDF_EVAL, s);
     if (normal)
         sdf_eval_kernel<true><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, n, sdf,
                                                      feat, normal);
     else
         sdf_eval_kernel<false><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, n, sdf,
                                                       feat, nullptr);
-    ls2fm_prof_mark(-1, s);
+    ls2fm_prof_end(LS2FM_PROF_SDF_EVAL, s);
     return ls2fm_launch_status();
 }
 
@@ -205,10 +205,10 @@ extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_gri
     int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
     if (st != LS2FM_OK) return st;
     const unsigned blocks = (unsigned)((2 * n_rays + 255) / 256);
-    ls2fm_prof_mark(LS2FM_PROF_SPHERE_TRACE, s);
+    ls2fm_prof_begin(LS2FM_PROF_SPHERE_TRACE, s);
     sphere_trace_kernel<<<blocks, 256, 0, s>>>(make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk,
                                                params->sdf_table, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far,
                                                track, t_end, trips);
-    ls2fm_prof_mark(-1, s);
+    ls2fm_prof_end(LS2FM_PROF_SPHERE_TRACE, s);
     return ls2fm_launch_status();
 }

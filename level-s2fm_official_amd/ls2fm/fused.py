@@ -19,6 +19,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 _DISABLE = os.environ.get("LS2FM_DISABLE_FUSED", "0") == "1"
+_POISON = os.environ.get("LS2FM_POISON_WS", "0") == "1"
 
 
 # ------------------------------------------------------------------------------------------------ gating
@@ -173,6 +174,8 @@ class _Render(torch.autograd.Function):
         if ws_bytes < 0:
             check(int(ws_bytes), "ls2fm_render_workspace_bytes")
         ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+        if _POISON:
+            ws.fill_(float("nan"))          # debug: any read of a workspace word that was never written shows up as NaN
         rgb = torch.empty(*shape2, 3, device=dev)
         sdfs = torch.empty(*shape2, n, 1, device=dev)
         normals = torch.empty(*shape2, n, 3, device=dev)
