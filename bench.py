@@ -52,7 +52,8 @@ def randomize(modules, seed=0):
 
 
 def loss_head(ret):
-    """10^3 L1(rgb, 0.5) + 10^2 L1(|n|, 1) + smoothL1(depth)   (weights: options/LevelS2fM.yaml:102-107)"""
+    """10^3 L1(rgb, 0.5) + 10^2 L1(|n|, 1) + smoothL1(depth)   (weights: options/LevelS2fM.yaml:102-107)
+    plain-torch form: used by the CPU baseline leg and by --torch-loss"""
     rgb = (ret["rgb"] - 0.5).abs().mean()
     eik = (ret["normals"].norm(dim=-1) - 1.0).abs().mean()
     dep = torch.nn.functional.smooth_l1_loss(ret["depth_mlp"], torch.zeros_like(ret["depth_mlp"]))
@@ -104,6 +105,10 @@ def main():
     ap.add_argument("--dataset", default="ETH3D")
     ap.add_argument("--single-field", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="time hipGraph replays of the whole step (ls2fm.graph.CapturedStep) instead of eager launches; "
+                         "measured slower than eager on ROCm 7.2 for this step (graph branches serialise), so off by default")
+    ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,11 +143,31 @@ def main():
     params = list(sdf.parameters()) + list(rad.parameters())
     reducer = GradAllReducer(params) if world > 1 else None
 
-    def step():
+    from ls2fm.losses import RenderLossHead
+    from ls2fm.graph import CapturedStep
+    head = RenderLossHead(dev, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0)           # same three terms and weights as loss_head()
+    rgb_gt = torch.full((1, args.rays, 3), 0.5, device=dev)
+    depth_ref = torch.zeros(1, args.rays, device=dev)
+
+    def render_step():
+        """Renderer.forward -> loss head -> backward: every parameter's .grad is (re)written"""
         for p in params:
             p.grad = None
         ret = ren.forward(opt, center, ray, sdf, rad)
-        loss_head(ret).backward()
+        if args.torch_loss:
+            loss = loss_head(ret)
+        else:
+            loss = head.terms(ret, rgb_gt, d_points=depth_ref)[1]
+        loss.backward()
+        return loss
+
+    captured = CapturedStep(render_step) if args.graph else None
+
+    def step(eager=False):
+        if captured is None or eager:
+            render_step()
+        else:
+            captured.replay()
         if reducer is not None:
             reducer.all_reduce()
 
@@ -153,18 +178,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    has_prof = hasattr(lib, "ls2fm_profile_enable")
-    if has_prof:
-        lib.ls2fm_profile_reset()
-        lib.ls2fm_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if has_prof:
-        lib.ls2fm_profile_enable(0)
+    # per-kernel device times (roofline): the same K steps launched eagerly with the library's HIP-event profiler on
+    # (events cannot be read back from inside a graph replay); also gives the eager step time
+    lib.ls2fm_profile_reset()
+    lib.ls2fm_profile_enable(1)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step(eager=True)
+    barrier()
+    dt_eager = time.perf_counter() - t1
+    lib.ls2fm_profile_enable(0)
+    has_prof = True
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -181,6 +212,8 @@ def main():
         "metric": "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "launch": "hipGraph replay of the whole step" if args.graph else "eager",
+        "eager_profiled_ms_per_step": dt_eager / args.steps * 1e3,
         "config": {"workload": f"{args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
                                f"{'dual' if dual else 'single'} field, L16/F2/T19 hash grid, fwd+loss+bwd"
                                + (", RCCL grad all-reduce" if world > 1 else ""),

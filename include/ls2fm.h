@@ -209,6 +209,36 @@ int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* gri
                        void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Loss head over the renderer's outputs: the scalar terms the reference's stages form
+ * right after Renderer.forward, in one kernel each way instead of ~35 launch-bound PyTorch kernels.
+ * Replaces: rgb L1 `l1_loss(rgb, rgbs_gt)` (pipelines/Camera.py:535); eikonal `l1_loss(norm(normals[mask]), 1)`
+ * (Initialization.py:257-258, BA.py:193-194); depth consistency `smooth_l1_loss(d_points[mask_finish],
+ * depth_mlp[mask_finish])`, 0 when the mask is empty (Camera.py:520-532); masked MSE behind PSNR (Camera.py:533);
+ * the 10^w weighted sum of summarize_loss (BA.py:206-218).
+ *   rgb, rgb_gt [n_rays,3]; normals [n_rays,n_samples,3]; depth [n_rays] (depth_mlp); depth_ref [n_rays] or NULL
+ *   (sphere-traced d_points; NULL = no DC term); mask_* uint8 [n_rays] or NULL (= every ray): mask_eik selects the rays
+ *   whose samples enter the eikonal mean, mask_dc = mask_finish, mask_mse = mask_bg.
+ *   weights float[3] (DEVICE) = 10^w of (rgb, eikonal, DC).
+ *   terms float[6] (DEVICE, overwritten) = {rgb L1 mean, eikonal mean, DC mean, masked MSE, weighted total, total again}.
+ *   sums double[8] (DEVICE, overwritten) = {S|rgb-gt|, n, S| |n|-1 |, n, S smooth_l1, n, S (rgb-gt)^2, n}: kept by the
+ *   caller for the backward, and what a sharded run all-reduces for global normalisation.  Deterministic (fixed-order
+ *   fp64 partials).  The workspace (ls2fm_loss_head_workspace_bytes) is zero-filled ONCE by the caller and reusable.
+ * ls2fm_loss_head_bwd: d_terms float[5] = upstream gradient of `terms`, d_total float[1] = an additional upstream gradient
+ * of the weighted total alone (either may be NULL = zeros, not both); writes (overwrites) d_rgb [n_rays,3],
+ * d_normals [n_rays,n_samples,3], d_depth [n_rays] and, if non-NULL, d_depth_ref [n_rays].  Needs the `sums` of the
+ * matching forward.
+ */
+int64_t ls2fm_loss_head_workspace_bytes(void);
+int ls2fm_loss_head_fwd(const float* rgb, const float* rgb_gt, const float* normals, const float* depth,
+                        const float* depth_ref, const uint8_t* mask_eik, const uint8_t* mask_dc, const uint8_t* mask_mse,
+                        int64_t n_rays, int32_t n_samples, const float* weights, float* terms, double* sums, void* workspace,
+                        void* stream);
+int ls2fm_loss_head_bwd(const float* rgb, const float* rgb_gt, const float* normals, const float* depth,
+                        const float* depth_ref, const uint8_t* mask_eik, const uint8_t* mask_dc, const uint8_t* mask_mse,
+                        int64_t n_rays, int32_t n_samples, const float* weights, const float* d_terms, const float* d_total,
+                        float* d_rgb, float* d_normals, float* d_depth, float* d_depth_ref, const double* sums, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the
  * call's own stream; ls2fm_profile_get() synchronises those events and returns, per internal kernel, the

@@ -110,17 +110,39 @@ bin_pass_kernel(LevelSet lv, const uint32_t* __restrict__ keys, int64_t n_points
     }
 }
 
-// exclusive prefix of the per-(level, bin) counts into absolute item offsets; zeroes the fill cursors
-__global__ void __launch_bounds__(64)
+// exclusive prefix of the per-(level, bin) counts into absolute item offsets; zeroes the fill cursors.
+// one wave per level (72 bins = lanes + 8 spill lanes), level totals combined through LDS
+__device__ __forceinline__ int wave_scan_incl_int(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * LS2FM_MAX_LEVELS)
 bin_scan_kernel(int n_levels, BinMeta bm) {
-    if (threadIdx.x != 0) return;
-    int run = 0;
-    for (int l = 0; l < n_levels; ++l)
-        for (int b = 0; b < kBins; ++b) {
-            bm.start[l * kBins + b] = run;
-            run += bm.count[l * kBins + b];
-            bm.cursor[l * kBins + b] = 0;
-        }
+    __shared__ int level_total[LS2FM_MAX_LEVELS];
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const bool on = l < n_levels;
+    const int c0 = on ? bm.count[l * kBins + lane] : 0;
+    const int c1 = (on && lane < kBins - 64) ? bm.count[l * kBins + 64 + lane] : 0;
+    const int i0 = wave_scan_incl_int(c0, lane);
+    const int t0 = __shfl(i0, 63, 64);
+    const int i1 = wave_scan_incl_int(c1, lane);
+    const int t1 = __shfl(i1, 63, 64);
+    if (lane == 0) level_total[l] = t0 + t1;
+    __syncthreads();
+    if (!on) return;
+    int before = 0;
+    for (int q = 0; q < l; ++q) before += level_total[q];
+    bm.start[l * kBins + lane] = before + i0 - c0;
+    bm.cursor[l * kBins + lane] = 0;
+    if (lane < kBins - 64) {
+        bm.start[l * kBins + 64 + lane] = before + t0 + i1 - c1;
+        bm.cursor[l * kBins + 64 + lane] = 0;
+    }
 }
 
 struct SlabPlan {
@@ -316,7 +338,7 @@ int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, in
     const LevelSet lv = make_level_set(grid);
     const dim3 g((unsigned)((n_points + kBinTile - 1) / kBinTile), (unsigned)grid->n_levels);
     bin_pass_kernel<false><<<g, kBinThreads, 0, stream>>>(lv, keys, n_points, p_pad, bm);
-    bin_scan_kernel<<<1, 64, 0, stream>>>(grid->n_levels, bm);
+    bin_scan_kernel<<<1, 64 * LS2FM_MAX_LEVELS, 0, stream>>>(grid->n_levels, bm);
     bin_pass_kernel<true><<<g, kBinThreads, 0, stream>>>(lv, keys, n_points, p_pad, bm);
     return ls2fm_launch_status();
 }

@@ -95,6 +95,10 @@ _SIGNATURES = {
                                    c_int64, _P, _P, _P, _P, _P, POINTER(ParamGrads), _P, _P, _P, _P]),
     "ls2fm_sphere_trace": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
                                      c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ls2fm_loss_head_workspace_bytes": (c_int64, []),
+    "ls2fm_loss_head_fwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
+    "ls2fm_loss_head_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P,
+                                      _P]),
     "ls2fm_profile_enable": (c_int32, [c_int32]),
     "ls2fm_profile_reset": (c_int32, []),
     "ls2fm_profile_count": (c_int32, []),

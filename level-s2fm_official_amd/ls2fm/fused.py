@@ -163,6 +163,7 @@ class _Render(torch.autograd.Function):
     def forward(ctx, center, ray, cfg, *params):
         fdesc, g1, g2, dual, beta_speed = cfg
         lib = _lib.load()
+        ctx.set_materialize_grads(False)        # unused outputs reach backward as None -> NULL upstream, no zero fills
         dev = center.device
         shape2 = tuple(center.shape[:2])
         n_rays = shape2[0] * shape2[1]

@@ -1,0 +1,39 @@
+"""HIP-graph capture of a whole optimisation step.
+
+The reference's stage loops (Initialization.py:149-179, BA.py:117-182, rendering_refine.py:78-96) run
+``Renderer.forward -> losses -> loss.backward()`` eagerly: at 1024 rays x 128 samples the device work is ~1 ms and the
+Python / launch overhead between the ~15 kernels of the fused path is of the same order.  ``CapturedStep`` records the
+step once into a hipGraph (the library's internal fork/join onto its side stream is captured as graph branches) and
+replays it with one launch.
+
+    step = CapturedStep(lambda: loss_fn(renderer.forward(opt, center, ray, sdf, rad)).backward() ...)
+    for it in range(n): new rays -> center.copy_(...), ray.copy_(...); step.replay(); optimizer.step()
+
+Contract (the usual one for graphs): the closure reads its inputs from tensors that keep their address (update them in
+place between replays), performs no host synchronisation (`.item()`, data-dependent Python control flow), and the
+tensors it produces -- including the parameters' ``.grad`` -- are rewritten in place by every replay.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class CapturedStep:
+    def __init__(self, fn, warmup: int = 3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ls2fm.graph.CapturedStep needs the GPU (no CPU path)")
+        self.fn = fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up off the default stream: allocator pools, lazy library state
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs
