@@ -36,7 +36,25 @@ constexpr int kRecB0 = 35;
 constexpr int kRecW1 = 36;
 constexpr int kMlpFloats = kHidden * kRecStride + 32;      // + b1[17] (padded)
 
+// MFMA-operand-ordered copies of the geometry MLP weights for v_mfma_f32_16x16x4_f32 (lane = 16 g + jl supplies
+// A[i = jl][k = g]).  Internal input order k': 0..31 encoding channels, 32..34 p / rescale, 35 constant 1 (bias column).
+struct MfmaField {
+    float w0a[4][9][64];       // layer 0 as A operand:            W0'[16m + jl][k' = 4t + g]          [m][t][lane]
+    float w1a[4][4][64];       // layer 1 rows 1..16 as A operand: W1[1 + jl][16m + 4g + r]            [m][r][lane]
+};
+struct MfmaW {                 // sdf .. w10 is one contiguous block (staged into LDS by the shade kernels), then geo
+    MfmaField sdf;
+    float w0ta[3][4][4][64];   // SDF layer 0 transposed:          W0'[16m + 4g + r][k' = 16mk + jl]   [mk][m][r][lane], 0 for k' >= 35
+    float w10[4][4][64];       // SDF W1[0][16m + 4g + r]                                              [m][r][lane]
+    MfmaField geo;
+    float b1a[2][4][64];       // b1[1 + 4g + r]                                                       [field][r][lane]
+    float b10[4];              // b1[0] per field
+};
+constexpr int kMfmaFieldFloats = 4 * 9 * 64 + 4 * 4 * 64;                     // 3328
+constexpr int kMfmaSdfFloats = kMfmaFieldFloats + 3 * 4 * 4 * 64 + 4 * 4 * 64;  // 7424
+
 struct Packed {
+    MfmaW mw;
     float sdf[kMlpFloats];
     float geo[kMlpFloats];
     float wc[3][68];        // collapsed radiance decoder: cols [0,3) p  [3,6) n  [6,33) view  [33,49) f  [49,65) f2
@@ -245,3 +263,8 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.total = o;
     return w;
 }
+
+// shade_fwd.hip
+int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
+                           int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
+                           float* depth_mlp, float* normal_mlp, hipStream_t s);

@@ -78,6 +78,34 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             dst[idx] = val;
         }
         for (int o = tid; o < 32; o += 256) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
+        // MFMA-operand-ordered copies (shade kernels): see MfmaW
+        auto w0p = [&](int j, int kp) -> float {
+            if (kp < 32) return 3 + kp < ind ? L0.v[j * ind + 3 + kp] * s0[j] : 0.f;
+            if (kp < 35) return L0.v[j * ind + (kp - 32)] * s0[j];
+            return kp == 35 ? L0.b[j] : 0.f;
+        };
+        MfmaW& mw = out->mw;
+        for (int idx = tid; idx < 4 * 9 * 64; idx += 256) {
+            const int m = idx / (9 * 64), t = (idx / 64) % 9, ln = idx & 63;
+            (which ? mw.geo : mw.sdf).w0a[m][t][ln] = w0p(16 * m + (ln & 15), 4 * t + (ln >> 4));
+        }
+        for (int idx = tid; idx < 4 * 4 * 64; idx += 256) {
+            const int m = idx / 256, r = (idx / 64) & 3, ln = idx & 63;
+            const int hid = 16 * m + 4 * (ln >> 4) + r;
+            (which ? mw.geo : mw.sdf).w1a[m][r][ln] = L1.v[(1 + (ln & 15)) * kHidden + hid] * s1[1 + (ln & 15)];
+            if (which == 0) {
+                mw.w10[m][r][ln] = L1.v[hid] * s1[0];
+                for (int mk = 0; mk < 3; ++mk) {
+                    const int kp = 16 * mk + (ln & 15);
+                    mw.w0ta[mk][m][r][ln] = kp < 35 ? w0p(hid, kp) : 0.f;
+                }
+            }
+        }
+        {
+            const int r = tid >> 6, ln = tid & 63;
+            mw.b1a[which][r][ln] = L1.b[1 + 4 * (ln >> 4) + r];
+        }
+        if (tid == 0) mw.b10[which] = L1.b[0];
     }
     if (tid == 3) {
         const float beta = expf(P.beta[0] * P.beta_speed);
@@ -207,129 +235,6 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
     }
 }
 
-// ------------------------------------------------------------------------------------------- shade_fwd
-// Block = one ray, thread = one sample (blockDim = 64 * ceil(N / 64)).
-template <bool DUAL, int MAXT>
-__global__ void __launch_bounds__(MAXT)
-shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, const float* __restrict__ center,
-                 const float* __restrict__ ray, int64_t p_pad, const float* __restrict__ E1,
-                 const float* __restrict__ J1, const float* __restrict__ E2, float* __restrict__ rgb_out,
-                 float* __restrict__ sdfs_out, float* __restrict__ normals_out, float* __restrict__ depth_out,
-                 float* __restrict__ nm_out, float* __restrict__ SDFV, float* __restrict__ NRM,
-                 float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2) {
-    __shared__ float s_part[16][10];     // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
-    __shared__ float s_view[3];
-    const int N = fc.n_samples;
-    const int64_t r = blockIdx.x;
-    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
-    const bool live = n < N;
-    const int64_t i = r * N + (live ? n : N - 1);
-    const RayGeom g = load_ray(fc, center, ray, r);
-    const float t = sample_depth(g, live ? n : N - 1, N);
-    const float t_next = sample_depth(g, (live ? n : N - 1) + 1, N);
-    float p[3], x[3];
-    sample_position(fc, g, t, p, x);
-
-    // view-embedding part of the radiance decoder, once per ray (wave 0)
-    if (wave == 0) {
-        const float e = lane < kView ? view_component(g.d, lane) : 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float s = wave_sum(lane < kView ? pk->wc[c][6 + lane] * e : 0.f);
-            if (lane == 0) s_view[c] = s + pk->bc[c];
-        }
-    }
-
-    float u[kInMax], f[kOut], rr[kInMax];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) u[a] = p[a] / fc.rescale;
-#pragma unroll
-    for (int c = 0; c < kInMax - 3; ++c) u[3 + c] = c < ch1 ? E1[c * p_pad + i] : 0.f;
-    geometry_forward<true>(pk->sdf, u, f, rr);
-    const float sdf = fc.inside ? f[0] / fc.scale_mlp : -f[0] / fc.scale_mlp;
-    // analytic normal: n = kappa * (d u / d p)^T r
-    float nrm[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < kInMax - 3; ++c) acc = fmaf(c < ch1 ? J1[(c * 3 + a) * p_pad + i] : 0.f, rr[3 + c], acc);
-        nrm[a] = fc.kappa * (rr[a] / fc.rescale + acc * fc.inv_ext[a]);
-    }
-    float f2[kOut];
-    if (DUAL) {
-#pragma unroll
-        for (int c = 0; c < kInMax - 3; ++c) u[3 + c] = c < ch2 ? E2[c * p_pad + i] : 0.f;
-        geometry_forward<false>(pk->geo, u, f2, rr);
-    }
-    __syncthreads();          // s_view ready
-    float col[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float z = s_view[c];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) z = fmaf(pk->wc[c][a], p[a], z);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) z = fmaf(pk->wc[c][3 + a], nrm[a], z);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) z = fmaf(pk->wc[c][33 + m], f[1 + m], z);
-        if (DUAL) {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) z = fmaf(pk->wc[c][49 + m], f2[1 + m], z);
-        }
-        col[c] = 1.0f / (1.0f + expf(-z));
-    }
-    const float sigma = sigma_of(sdf, pk->alpha, pk->beta);
-
-    if (live) {
-        sdfs_out[i] = sdf;
-        SDFV[i] = sdf;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            normals_out[i * 3 + a] = nrm[a];
-            NRM[a * p_pad + i] = nrm[a];
-            RGBS[a * p_pad + i] = col[a];
-        }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) FE[m * p_pad + i] = f[1 + m];
-        if (DUAL) {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) FE2[m * p_pad + i] = f2[1 + m];
-        }
-    }
-
-    // composite (Renderer.py:33-49): N-1 intervals, exclusive prefix of sigma*delta
-    const float ray_len = sqrtf(g.d[0] * g.d[0] + g.d[1] * g.d[1] + g.d[2] * g.d[2]);
-    const bool interval = n < N - 1;
-    const float tau = interval ? sigma * ((t_next - t) * ray_len) : 0.f;
-    const float incl = wave_scan_incl(tau, lane);
-    if (lane == 63) s_part[wave][0] = incl;
-    __syncthreads();
-    float before = incl - tau;
-    for (int w = 0; w < wave; ++w) before += s_part[w][0];
-    const float wgt = interval ? expf(-before) * (1.0f - expf(-tau)) : 0.f;
-    float sums[8] = {wgt * col[0], wgt * col[1], wgt * col[2], wgt * t, wgt * nrm[0], wgt * nrm[1], wgt * nrm[2], wgt};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float s = wave_sum(sums[q]);
-        if (lane == 0) s_part[wave][1 + q] = s;
-    }
-    __syncthreads();
-    if (n == N - 1) {         // the last sample's thread owns t_last / n_last and writes the ray outputs
-        float tot[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            tot[q] = 0.f;
-            for (int w = 0; w < n_waves; ++w) tot[q] += s_part[w][1 + q];
-        }
-        const float rest = 1.0f - tot[7];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rgb_out[r * 3 + c] = tot[c] + rest * fc.bg[c];
-        depth_out[r] = tot[3] + rest * t;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) nm_out[r * 3 + a] = tot[4 + a] + rest * nrm[a];
-    }
-}
 
 }  // namespace
 
@@ -399,16 +304,9 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
         ls2fm_prof_end(LS2FM_PROF_ENCODE_RAD, s);
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
-    const int threads = (field->n_samples + 63) / 64 * 64;
     ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
-#define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                              \
-    shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                            \
-        fc, 2 * L1, 2 * L2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb,     \
-        sdfs_volume, normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe,             \
-        DUAL ? ws + w.fe2 : nullptr)
-    if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 1024); }
-    else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 1024); }
-#undef LS2FM_SHADE_FWD
+    ls2fm_launch_shade_fwd(fc, dual, 2 * L1, 2 * L2, pk, center, ray, n_rays, w, ws, rgb, sdfs_volume, normals, depth_mlp,
+                           normal_mlp, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_FWD, s);
     return ls2fm_launch_status();
 }

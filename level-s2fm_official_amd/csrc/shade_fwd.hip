@@ -1,0 +1,324 @@
+// shade_fwd: per-sample field evaluation + per-ray compositing of Renderer.forward on the matrix cores.
+//
+//   workgroup = one ray (its N samples are the N dimension of every GEMM), wave = 64 samples = four 16-column tiles.
+//   Everything is kept TRANSPOSED, [feature x sample], so that the accumulator tile of one v_mfma_f32_16x16x4_f32
+//   (lane 16 g + jl holds rows 4 g + r, column jl) is directly the B operand of the next GEMM over that feature
+//   dimension (k-slot g <-> row 4 g + r): the whole chain
+//        A1 = W0' U          (64 x 36) x (36 x S)     U = [32 encoding channels ; p / rescale ; 1]  (bias folded in)
+//        H  = softplus_100(A1), S1 = softplus'
+//        F  = W1[1..16] H    (16 x 64) x (64 x S)     sdf row W1[0] H: 16 FMAs per lane + 2 cross-lane adds
+//        R  = W0'^T (S1 . w1_0)   (48 x 64) x (64 x S)  -> analytic normal n = kappa (dU/dp)^T R      
+//        [second field: A1, H, F only]
+//   runs out of registers with no LDS staging; the MFMA-ordered weight copies come from prep_weights (L2-resident, one
+//   coalesced 256-B load per operand).  The per-sample scalars (sdf, normal, colour) are then transposed through LDS to
+//   one-thread-per-sample order for the transmittance scan (Renderer.py:33-49).
+// fp32 MFMA = exact fp32 products and sums (no reduced-precision path); only the summation order differs from the
+// scalar-FMA oracle.
+#include "render_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sum over the four 16-lane groups (g = 0..3) of a wave: every lane ends with the total
+__device__ __forceinline__ float sum_over_groups(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <bool DUAL, int MAXT>
+__global__ void __launch_bounds__(MAXT, 2)
+shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, const float* __restrict__ center,
+                 const float* __restrict__ ray, int64_t p_pad, const float* __restrict__ E1,
+                 const float* __restrict__ J1, const float* __restrict__ E2, float* __restrict__ rgb_out,
+                 float* __restrict__ sdfs_out, float* __restrict__ normals_out, float* __restrict__ depth_out,
+                 float* __restrict__ nm_out, float* __restrict__ SDFV, float* __restrict__ NRM,
+                 float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2) {
+    __shared__ float s_part[MAXT / 64][10];     // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
+    __shared__ float s_view[3];
+    __shared__ float s_x[MAXT][8];              // per sample: sdf, normal(3), colour(3)
+    __shared__ float s_w[kMfmaSdfFloats];       // MFMA-ordered weights of the field being evaluated (29 KB)
+    const int N = fc.n_samples;
+    const int64_t r = blockIdx.x;
+    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    const int jl = lane & 15, g = lane >> 4;
+    const RayGeom gm = load_ray(fc, center, ray, r);
+    const MfmaW& mw = pk->mw;
+    {   // stage the SDF field's operand-ordered weights: one coalesced pass, then 256-B ds_reads per operand
+        const float4* src = reinterpret_cast<const float4*>(&mw.sdf);
+        float4* dst = reinterpret_cast<float4*>(s_w);
+        for (int q = n; q < kMfmaSdfFloats / 4; q += blockDim.x) dst[q] = src[q];
+    }
+    const float* __restrict__ s_w0a = s_w;                                   // [m][t][lane]
+    const float* __restrict__ s_w1a = s_w + 4 * 9 * 64;                      // [m][r][lane]
+    const float* __restrict__ s_w0ta = s_w + kMfmaFieldFloats;               // [mk][m][r][lane]
+    const float* __restrict__ s_w10 = s_w0ta + 3 * 4 * 4 * 64;               // [m][r][lane]
+
+    // view-embedding part of the radiance decoder, once per ray (wave 0)
+    if (wave == 0) {
+        const float e = lane < kView ? view_component(gm.d, lane) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = wave_sum(lane < kView ? pk->wc[c][6 + lane] * e : 0.f);
+            if (lane == 0) s_view[c] = s + pk->bc[c];
+        }
+    }
+
+    // ---- this lane's four samples (column jl of the wave's four tiles)
+    int64_t is[4];
+    float pw[4][3];
+    bool live_c[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ns = 64 * wave + 16 * c + jl;
+        live_c[c] = ns < N;
+        const int nn = live_c[c] ? ns : N - 1;
+        is[c] = r * N + nn;
+        float x[3];
+        sample_position(fc, gm, sample_depth(gm, nn, N), pw[c], x);
+    }
+
+    // ---- B operands of layer 0: ub[t][c] = U[k' = 4t + g][sample c]
+    float ub[9][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ub[t][c] = (4 * t + g) < ch1 ? E1[(int64_t)(4 * t + g) * p_pad + is[c]] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ub[8][c] = g < 3 ? (g == 0 ? pw[c][0] : (g == 1 ? pw[c][1] : pw[c][2])) / fc.rescale : 1.0f;
+
+    __syncthreads();          // weights staged
+
+    // ---- SDF field
+    f32x4 racc[3][4], facc[4];
+    float f0p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) facc[c][q] = mw.b1a[0][q][lane];
+#pragma unroll
+        for (int mk = 0; mk < 3; ++mk) racc[mk][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float a = s_w0a[(m * 9 + t) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
+        }
+        float ga[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float w10 = s_w10[(m * 4 + q) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float h, s1, s2;
+                softplus100(acc[c][q], h, s1, s2);
+                acc[c][q] = h;
+                ga[c][q] = s1 * w10;
+                f0p[c] = fmaf(w10, h, f0p[c]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a1 = s_w1a[(m * 4 + q) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) facc[c] = mfma4(a1, acc[c][q], facc[c]);
+        }
+#pragma unroll
+        for (int mk = 0; mk < 3; ++mk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float at = s_w0ta[((mk * 4 + m) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) racc[mk][c] = mfma4(at, ga[c][q], racc[mk][c]);
+            }
+    }
+
+    // sdf and the analytic normal  n = kappa (R_p / rescale + inv_ext . J^T R_enc)
+    float sdf[4], nrm[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float f0 = sum_over_groups(f0p[c]) + mw.b10[0];
+        sdf[c] = fc.inside ? f0 / fc.scale_mlp : -f0 / fc.scale_mlp;
+        float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 16 * mk + 4 * g + q;
+                if (ch < ch1) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) part[a] = fmaf(J1[(int64_t)(ch * 3 + a) * p_pad + is[c]], racc[mk][c][q], part[a]);
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = part[a] * fc.inv_ext[a];
+            if (g == 0) v += racc[2][c][a] / fc.rescale;          // rows 32..34 = the p / rescale inputs (group 0)
+            nrm[c][a] = fc.kappa * sum_over_groups(v);
+        }
+        if (live_c[c]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) FE[(int64_t)(4 * g + q) * p_pad + is[c]] = facc[c][q];
+        }
+    }
+
+    // ---- second field (Geometry_feat of RadF): features only
+    f32x4 facc2[4];
+    if (DUAL) {
+        __syncthreads();      // every wave is done with the SDF weights
+        {
+            const float4* src = reinterpret_cast<const float4*>(&mw.geo);
+            float4* dst = reinterpret_cast<float4*>(s_w);
+            for (int q = n; q < kMfmaFieldFloats / 4; q += blockDim.x) dst[q] = src[q];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ub[t][c] = (4 * t + g) < ch2 ? E2[(int64_t)(4 * t + g) * p_pad + is[c]] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) facc2[c][q] = mw.b1a[1][q][lane];
+        __syncthreads();      // second field's weights staged
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float a = s_w0a[(m * 9 + t) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a1 = s_w1a[(m * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) facc2[c] = mfma4(a1, softplus100_value(acc[c][q]), facc2[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (live_c[c]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) FE2[(int64_t)(4 * g + q) * p_pad + is[c]] = facc2[c][q];
+            }
+    }
+    __syncthreads();          // s_view ready
+
+    // ---- collapsed radiance decoder: z = Wc [p, n, view, f, f2] + bc ; this lane's feature slice, then the group sum
+    float wf[3][4], wf2[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wf[k][q] = pk->wc[k][33 + 4 * g + q];
+            wf2[k][q] = DUAL ? pk->wc[k][49 + 4 * g + q] : 0.f;
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float col[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float zp = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                zp = fmaf(wf[k][q], facc[c][q], zp);
+                if (DUAL) zp = fmaf(wf2[k][q], facc2[c][q], zp);
+            }
+            float z = s_view[k] + sum_over_groups(zp);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) z = fmaf(pk->wc[k][a], pw[c][a], z);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) z = fmaf(pk->wc[k][3 + a], nrm[c][a], z);
+            col[k] = 1.0f / (1.0f + expf(-z));
+        }
+        if (g == 0) {
+            float* dst = s_x[64 * wave + 16 * c + jl];
+            dst[0] = sdf[c];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { dst[1 + a] = nrm[c][a]; dst[4 + a] = col[a]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- one thread per sample from here on
+    const bool live = n < N;
+    const int64_t i = r * N + (live ? n : N - 1);
+    const float t = sample_depth(gm, live ? n : N - 1, N);
+    const float t_next = sample_depth(gm, (live ? n : N - 1) + 1, N);
+    const float sdf_n = s_x[n][0];
+    const float nrm_n[3] = {s_x[n][1], s_x[n][2], s_x[n][3]};
+    const float col_n[3] = {s_x[n][4], s_x[n][5], s_x[n][6]};
+    const float sigma = sigma_of(sdf_n, pk->alpha, pk->beta);
+    if (live) {
+        sdfs_out[i] = sdf_n;
+        SDFV[i] = sdf_n;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            normals_out[i * 3 + a] = nrm_n[a];
+            NRM[a * p_pad + i] = nrm_n[a];
+            RGBS[a * p_pad + i] = col_n[a];
+        }
+    }
+
+    // composite (Renderer.py:33-49): N-1 intervals, exclusive prefix of sigma*delta
+    const float ray_len = sqrtf(gm.d[0] * gm.d[0] + gm.d[1] * gm.d[1] + gm.d[2] * gm.d[2]);
+    const bool interval = n < N - 1;
+    const float tau = interval ? sigma * ((t_next - t) * ray_len) : 0.f;
+    const float incl = wave_scan_incl(tau, lane);
+    if (lane == 63) s_part[wave][0] = incl;
+    __syncthreads();
+    float before = incl - tau;
+    for (int w = 0; w < wave; ++w) before += s_part[w][0];
+    const float wgt = interval ? expf(-before) * (1.0f - expf(-tau)) : 0.f;
+    float sums[8] = {wgt * col_n[0], wgt * col_n[1], wgt * col_n[2], wgt * t, wgt * nrm_n[0], wgt * nrm_n[1], wgt * nrm_n[2], wgt};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float s = wave_sum(sums[q]);
+        if (lane == 0) s_part[wave][1 + q] = s;
+    }
+    __syncthreads();
+    if (n == N - 1) {         // the last sample's thread owns t_last / n_last and writes the ray outputs
+        float tot[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            tot[q] = 0.f;
+            for (int w = 0; w < n_waves; ++w) tot[q] += s_part[w][1 + q];
+        }
+        const float rest = 1.0f - tot[7];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb_out[r * 3 + c] = tot[c] + rest * fc.bg[c];
+        depth_out[r] = tot[3] + rest * t;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nm_out[r * 3 + a] = tot[4 + a] + rest * nrm_n[a];
+    }
+}
+
+}  // namespace
+
+int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
+                           int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
+                           float* depth_mlp, float* normal_mlp, hipStream_t s) {
+    const int threads = (fc.n_samples + 63) / 64 * 64;
+#define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                                \
+    shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                              \
+        fc, ch1, ch2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb, sdfs_volume, \
+        normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe, DUAL ? ws + w.fe2 : nullptr)
+    if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 512); }
+    else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 512); }
+#undef LS2FM_SHADE_FWD
+    return LS2FM_OK;
+}
