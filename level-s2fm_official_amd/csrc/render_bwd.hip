@@ -20,325 +20,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------- shade_bwd
-struct LevelScales { float s[LS2FM_MAX_LEVELS]; };
-
-// wave-wide max of a non-negative float -> one LDS slot per (wave, level); combined per ray after a barrier
-__device__ __forceinline__ void publish_max(float v, int lane, float* dst) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    if (lane == 0) *dst = v;
-}
-
-struct Upstream {                  // dL/d(outputs of render_fwd); any pointer may be null (= zeros)
-    const float* d_rgb;            // [R,3]
-    const float* d_sdfs;           // [R,N]
-    const float* d_normals;        // [R,N,3]
-    const float* d_depth;          // [R]
-    const float* d_nm;             // [R,3]
-};
-
-template <bool DUAL, int MAXT>
-__global__ void __launch_bounds__(MAXT)
-shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
-                 const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
-                 Upstream up, float* __restrict__ out) {
-    __shared__ float s_part[16][8];
-    __shared__ double s_db[16];
-    __shared__ float s_bound[16][32];
-    const int N = fc.n_samples;
-    const int64_t r = blockIdx.x;
-    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
-    const bool live = n < N;
-    const int nn = live ? n : N - 1;
-    const int64_t i = r * N + nn;
-    const int64_t P = w.p_pad;
-    const RayGeom g = load_ray(fc, center, ray, r);
-    const float t = sample_depth(g, nn, N);
-    const float t_next = sample_depth(g, nn + 1, N);
-    const float t_last = sample_depth(g, N - 1, N);
-    float p[3], x[3];
-    sample_position(fc, g, t, p, x);
-    const float ray_len = sqrtf(g.d[0] * g.d[0] + g.d[1] * g.d[1] + g.d[2] * g.d[2]);
-
-    // ---- upstream gradients of the ray outputs
-    float g_rgb[3], g_nm[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        g_rgb[c] = up.d_rgb ? up.d_rgb[r * 3 + c] : 0.f;
-        g_nm[c] = up.d_nm ? up.d_nm[r * 3 + c] : 0.f;
-    }
-    const float g_dep = up.d_depth ? up.d_depth[r] : 0.f;
-
-    // ---- forward per-sample values saved by shade_fwd
-    const float sdf = fws[w.sdfv + i];
-    float nrm[3], col[3], n_last[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        nrm[a] = fws[w.nrm + a * P + i];
-        col[a] = fws[w.rgbs + a * P + i];
-        n_last[a] = fws[w.nrm + a * P + r * N + N - 1];
-    }
-    const float alpha = pk->alpha, beta = pk->beta;
-    const float lap = 0.5f * expf(-fabsf(sdf) / beta);
-    const float sigma = alpha * (sdf >= 0.f ? lap : 1.0f - lap);
-
-    // ---- composite forward quantities (same scans as shade_fwd)
-    const bool interval = n < N - 1;
-    const float delta = (t_next - t) * ray_len;
-    const float tau = interval ? sigma * delta : 0.f;
-    const float incl = wave_scan_incl(tau, lane);
-    if (lane == 63) s_part[wave][0] = incl;
-    __syncthreads();
-    float before = incl - tau;
-    for (int q = 0; q < wave; ++q) before += s_part[q][0];
-    const float trans = expf(-before), ex = expf(-tau);
-    const float wgt = interval ? trans * (1.0f - ex) : 0.f;
-
-    // ---- composite backward:  L = sum_i w_i (V_i - B) + B ;  dL/dtau_k = U_k T_k e^{-tau_k} - sum_{i>k} U_i w_i
-    float b_term = g_dep * t_last, v_term = g_dep * t;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        b_term = fmaf(g_rgb[c], fc.bg[c], b_term);
-        b_term = fmaf(g_nm[c], n_last[c], b_term);
-        v_term = fmaf(g_rgb[c], col[c], v_term);
-        v_term = fmaf(g_nm[c], nrm[c], v_term);
-    }
-    const float u_w = interval ? (v_term - b_term) * wgt : 0.f;
-    const float incl_uw = wave_scan_incl(u_w, lane);
-    const float wsum_w = wave_sum(wgt);
-    if (lane == 63) s_part[wave][1] = incl_uw;
-    if (lane == 0) s_part[wave][2] = wsum_w;
-    __syncthreads();
-    float uw_total = 0.f, opacity = 0.f, uw_before = 0.f;
-    for (int q = 0; q < n_waves; ++q) {
-        uw_total += s_part[q][1];
-        opacity += s_part[q][2];
-        if (q < wave) uw_before += s_part[q][1];
-    }
-    const float suffix = uw_total - (incl_uw + uw_before);
-    const float d_tau = interval ? (v_term - b_term) * trans * ex - suffix : 0.f;
-    const float g_sigma = d_tau * delta;
-    const float rest = 1.0f - opacity;
-
-    // ---- per-sample upstream of colour, normal, sdf
-    float gc[3], gn[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        gc[a] = wgt * g_rgb[a];
-        float v = wgt * g_nm[a];
-        if (n == N - 1) v += rest * g_nm[a];
-        if (live && up.d_normals) v += up.d_normals[i * 3 + a];
-        gn[a] = live ? v : 0.f;
-    }
-    float g_sdf = (live && up.d_sdfs) ? up.d_sdfs[i] : 0.f;
-
-    // ---- sigma backward (+ d beta)
-    {
-        const float abs_s = fabsf(sdf);
-        const float dsig_ds = sdf != 0.f ? -alpha * lap / beta : 0.f;
-        g_sdf = fmaf(g_sigma, dsig_ds, g_sdf);
-        const float inv_b2 = 1.0f / (beta * beta);
-        const float dsig_db = sdf >= 0.f ? lap * (abs_s * inv_b2 / beta - inv_b2)
-                                         : -(1.0f - lap) * inv_b2 - lap * abs_s * inv_b2 / beta;
-        // d beta is one scalar summed over every sample with heavy cancellation: accumulate it in fp64
-        double db = (double)g_sigma * (double)dsig_db;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) db += __shfl_xor(db, o, 64);
-        if (lane == 0) s_db[wave] = db;
-    }
-
-    // ---- collapsed radiance decoder backward
-    float dz[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dz[c] = gc[c] * col[c] * (1.0f - col[c]);
-    float gf[kOut], gf2[kOut];
-    gf[0] = fc.kappa * g_sdf;
-    gf2[0] = 0.f;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            s1 = fmaf(pk->wc[c][33 + m], dz[c], s1);
-            if (DUAL) s2 = fmaf(pk->wc[c][49 + m], dz[c], s2);
-        }
-        gf[1 + m] = s1;
-        gf2[1 + m] = s2;
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gn[a] = fmaf(pk->wc[c][3 + a], dz[c], gn[a]);
-    // per-ray sums of dz (view-embedding columns of the decoder) and the d beta total
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float s = wave_sum(dz[c]);
-        if (lane == 0) s_part[wave][4 + c] = s;
-    }
-    __syncthreads();
-    if (n < 3) {
-        float s = 0.f;
-        for (int q = 0; q < n_waves; ++q) s += s_part[q][4 + n];
-        out[w.dzr + n * w.r_pad + r] = s;
-    }
-    if (n == 3) {
-        double s = 0.0;
-        for (int q = 0; q < n_waves; ++q) s += s_db[q];
-        atomicAdd(reinterpret_cast<double*>(out + w.dbeta), s);
-    }
-    if (n < kView) out[w.renc + n * w.r_pad + r] = view_component(g.d, n);
-
-    // ---- SDF MLP backward with the double-backward terms of the normal path (A.4)
-    float u[kInMax], v[kInMax], de[kInMax], rr[kInMax];
-    float gns[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float gnk = fc.kappa * gn[a];
-        u[a] = p[a] / fc.rescale;
-        v[a] = gnk / fc.rescale;
-        gns[a] = gnk * fc.inv_ext[a];
-    }
-#pragma unroll
-    for (int c = 0; c < kInMax - 3; ++c) {
-        const bool on = c < ch1;
-        u[3 + c] = on ? fws[w.e1 + c * P + i] : 0.f;
-        float acc = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) acc = fmaf(on ? fws[w.j1 + (c * 3 + a) * P + i] : 0.f, gns[a], acc);
-        v[3 + c] = acc;
-    }
-#pragma unroll
-    for (int k = 0; k < kInMax; ++k) { de[k] = 0.f; rr[k] = 0.f; }
-    {
-        const float* __restrict__ rec = pk->sdf;
-#pragma unroll 1
-        for (int j = 0; j < kHidden; ++j) {
-            const float* __restrict__ wj = rec + j * kRecStride;
-            float a0 = wj[kRecB0], a1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-            for (int k = 0; k + 1 < kInMax; k += 2) {
-                a0 = fmaf(wj[k], u[k], a0);
-                a1 = fmaf(wj[k + 1], u[k + 1], a1);
-                q0 = fmaf(wj[k], v[k], q0);
-                q1 = fmaf(wj[k + 1], v[k + 1], q1);
-            }
-            a0 = fmaf(wj[kInMax - 1], u[kInMax - 1], a0);
-            q0 = fmaf(wj[kInMax - 1], v[kInMax - 1], q0);
-            float h, s1, s2;
-            softplus100(a0 + a1, h, s1, s2);
-            const float q = q0 + q1;
-            float tj = 0.f;
-#pragma unroll
-            for (int o = 0; o < kOut; ++o) tj = fmaf(wj[kRecW1 + o], gf[o], tj);
-            const float w10 = wj[kRecW1];
-            const float da = fmaf(s1, tj, s2 * w10 * q);
-            const float gj = s1 * w10;
-#pragma unroll
-            for (int k = 0; k < kInMax; ++k) {
-                de[k] = fmaf(wj[k], da, de[k]);
-                rr[k] = fmaf(wj[k], gj, rr[k]);
-            }
-            if (live) {
-                out[w.da + j * P + i] = da;
-                out[w.g + j * P + i] = gj;
-                out[w.h + j * P + i] = h;
-                out[w.sq + j * P + i] = s1 * q;
-            }
-        }
-    }
-    if (live) {
-        // scatter payload of the SDF grid: one 64-byte record (one cache line half) per (level, point)
-#pragma unroll
-        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
-            if (2 * l < ch1) {
-                float4* dst = reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + i) * 16);
-                dst[0] = make_float4(x[0], x[1], x[2], 0.f);
-                dst[1] = make_float4(de[3 + 2 * l], de[4 + 2 * l], rr[3 + 2 * l], rr[4 + 2 * l]);
-                dst[2] = make_float4(gns[0], gns[1], gns[2], 0.f);
-            }
-#pragma unroll
-        for (int k = 0; k < kInMax; ++k) out[w.v + k * P + i] = v[k];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            out[w.pu + a * P + i] = u[a];
-            out[w.p3 + a * P + i] = p[a];
-            out[w.dz + a * P + i] = dz[a];
-        }
-#pragma unroll
-        for (int o = 0; o < kOut; ++o) out[w.gf + o * P + i] = gf[o];
-    }
-
-    // per-level bound of a single scatter contribution |w de + D rr| <= |de| + scale |gn|_1 |rr|: fixes the fixed-point
-    // quantum of the slab scatter's integer accumulators
-    {
-        const float g1 = fabsf(gns[0]) + fabsf(gns[1]) + fabsf(gns[2]);
-#pragma unroll
-        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
-            if (2 * l < ch1) {
-                const float b = fmaxf(fabsf(de[3 + 2 * l]), fabsf(de[4 + 2 * l])) +
-                                lsc.s[l] * g1 * fmaxf(fabsf(rr[3 + 2 * l]), fabsf(rr[4 + 2 * l]));
-                publish_max(live ? b : 0.f, lane, &s_bound[wave][l]);
-            }
-    }
-
-    // ---- second field: plain first-order backward of its Geometry MLP
-    if (DUAL) {
-#pragma unroll
-        for (int c = 0; c < kInMax - 3; ++c) u[3 + c] = c < ch2 ? fws[w.e2 + c * P + i] : 0.f;
-#pragma unroll
-        for (int k = 0; k < kInMax; ++k) de[k] = 0.f;
-        const float* __restrict__ rec = pk->geo;
-#pragma unroll 1
-        for (int j = 0; j < kHidden; ++j) {
-            const float* __restrict__ wj = rec + j * kRecStride;
-            float a0 = wj[kRecB0], a1 = 0.f;
-#pragma unroll
-            for (int k = 0; k + 1 < kInMax; k += 2) {
-                a0 = fmaf(wj[k], u[k], a0);
-                a1 = fmaf(wj[k + 1], u[k + 1], a1);
-            }
-            a0 = fmaf(wj[kInMax - 1], u[kInMax - 1], a0);
-            float h, s1, s2;
-            softplus100(a0 + a1, h, s1, s2);
-            float tj = 0.f;
-#pragma unroll
-            for (int o = 1; o < kOut; ++o) tj = fmaf(wj[kRecW1 + o], gf2[o], tj);
-            const float da = s1 * tj;
-#pragma unroll
-            for (int k = 0; k < kInMax; ++k) de[k] = fmaf(wj[k], da, de[k]);
-            if (live) {
-                out[w.da2 + j * P + i] = da;
-                out[w.h2 + j * P + i] = h;
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
-                if (2 * l < ch2) {
-                    float4* dst = reinterpret_cast<float4*>(out + w.rec2 + ((int64_t)l * P + i) * 8);
-                    dst[0] = make_float4(x[0], x[1], x[2], 0.f);
-                    dst[1] = make_float4(de[3 + 2 * l], de[4 + 2 * l], 0.f, 0.f);
-                }
-#pragma unroll
-            for (int o = 0; o < kOut; ++o) out[w.gf2 + o * P + i] = gf2[o];
-        }
-#pragma unroll
-        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l)
-            if (2 * l < ch2)
-                publish_max(live ? fmaxf(fabsf(de[3 + 2 * l]), fabsf(de[4 + 2 * l])) : 0.f, lane, &s_bound[wave][16 + l]);
-    }
-    // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
-    __syncthreads();
-    if (n < 32) {
-        const bool used = n < 16 ? (2 * n < ch1) : (DUAL && 2 * (n - 16) < ch2);
-        float b = 0.f;
-        if (used)
-            for (int q = 0; q < n_waves; ++q) b = fmaxf(b, s_bound[q][n]);
-        out[w.smax + n * w.r_pad + r] = b;
-    }
-}
-
 // ------------------------------------------------------------------------------------------- wgrad (MFMA)
 struct Seg { const float* base; int rows; int pad; };
 struct WJob {
@@ -636,13 +317,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (forked && hipEventRecord(sc.mid, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
 
     const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
-    const int threads = (field->n_samples + 63) / 64 * 64;
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-#define LS2FM_SHADE_BWD(DUAL, MAXT) \
-    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, 2 * L1, 2 * L2, w, pk, center, ray, ws, up, ws)
-    if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
-    else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
-#undef LS2FM_SHADE_BWD
+    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
 
     // weight-gradient GEMMs over all sample points

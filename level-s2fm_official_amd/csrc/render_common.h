@@ -50,11 +50,27 @@ struct MfmaW {                 // sdf .. w10 is one contiguous block (staged int
     float b1a[2][4][64];       // b1[1 + 4g + r]                                                       [field][r][lane]
     float b10[4];              // b1[0] per field
 };
+// backward: per-field contiguous blocks (staged into LDS by shade_bwd)
+struct MfmaBwdSdf {
+    float w0a[4][9][64];       // as MfmaField::w0a
+    float w1ta[4][5][64];      // layer 1 transposed as A operand: W1[o = 4t + g][16m + jl], 0 for o > 16    [m][t][lane]
+    float w0ta[2][4][4][64];   // as MfmaW::w0ta, encoding rows only (mk < 2)
+    float w10[4][4][64];
+};
+struct MfmaBwdGeo {
+    float w0a[4][9][64];
+    float w1ta[4][4][64];      // W1[o = 1 + 4t + g][16m + jl]                                              [m][t][lane]
+    float w0ta[2][4][4][64];   // W0'[16m + 4g + r][k' = 16mk + jl]
+};
+constexpr int kMfmaBwdSdfFloats = sizeof(MfmaBwdSdf) / 4;   // 6656
+constexpr int kMfmaBwdGeoFloats = sizeof(MfmaBwdGeo) / 4;   // 5376
 constexpr int kMfmaFieldFloats = 4 * 9 * 64 + 4 * 4 * 64;                     // 3328
 constexpr int kMfmaSdfFloats = kMfmaFieldFloats + 3 * 4 * 4 * 64 + 4 * 4 * 64;  // 7424
 
 struct Packed {
     MfmaW mw;
+    MfmaBwdSdf bs;
+    MfmaBwdGeo bg;
     float sdf[kMlpFloats];
     float geo[kMlpFloats];
     float wc[3][68];        // collapsed radiance decoder: cols [0,3) p  [3,6) n  [6,33) view  [33,49) f  [49,65) f2
@@ -263,6 +279,21 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.total = o;
     return w;
 }
+
+struct LevelScales { float s[LS2FM_MAX_LEVELS]; };
+
+struct Upstream {                  // dL/d(outputs of render_fwd); any pointer may be null (= zeros)
+    const float* d_rgb;            // [R,3]
+    const float* d_sdfs;           // [R,N]
+    const float* d_normals;        // [R,N,3]
+    const float* d_depth;          // [R]
+    const float* d_nm;             // [R,3]
+};
+
+// shade_bwd.hip
+int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
+                           const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
+                           const Upstream& up, hipStream_t s);
 
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,

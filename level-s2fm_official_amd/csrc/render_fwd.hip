@@ -105,6 +105,32 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             const int r = tid >> 6, ln = tid & 63;
             mw.b1a[which][r][ln] = L1.b[1 + 4 * (ln >> 4) + r];
         }
+        // backward copies
+        for (int idx = tid; idx < 4 * 9 * 64; idx += 256) {
+            const int m = idx / (9 * 64), t = (idx / 64) % 9, ln = idx & 63;
+            const float v = w0p(16 * m + (ln & 15), 4 * t + (ln >> 4));
+            if (which) out->bg.w0a[m][t][ln] = v; else out->bs.w0a[m][t][ln] = v;
+        }
+        for (int idx = tid; idx < 4 * 5 * 64; idx += 256) {
+            const int m = idx / (5 * 64), t = (idx / 64) % 5, ln = idx & 63;
+            const int hid = 16 * m + (ln & 15);
+            if (which) {
+                if (t < 4) out->bg.w1ta[m][t][ln] = L1.v[(1 + 4 * t + (ln >> 4)) * kHidden + hid] * s1[1 + 4 * t + (ln >> 4)];
+            } else {
+                const int o = 4 * t + (ln >> 4);
+                out->bs.w1ta[m][t][ln] = o < kOut ? L1.v[o * kHidden + hid] * s1[o] : 0.f;
+            }
+        }
+        for (int idx = tid; idx < 2 * 4 * 4 * 64; idx += 256) {
+            const int mk = idx / 1024, m = (idx / 256) & 3, r = (idx / 64) & 3, ln = idx & 63;
+            const int hid = 16 * m + 4 * (ln >> 4) + r;
+            const float v = w0p(hid, 16 * mk + (ln & 15));
+            if (which) out->bg.w0ta[mk][m][r][ln] = v;
+            else {
+                out->bs.w0ta[mk][m][r][ln] = v;
+                if (mk == 0) out->bs.w10[m][r][ln] = L1.v[hid] * s1[0];
+            }
+        }
         if (tid == 0) mw.b10[which] = L1.b[0];
     }
     if (tid == 3) {

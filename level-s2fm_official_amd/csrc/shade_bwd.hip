@@ -1,0 +1,457 @@
+// shade_bwd: backward of the per-ray compositing and of the per-sample fields, including the analytic double backward
+// of the normal path, on the matrix cores.
+//
+//   1. one thread per sample: composite backward (prefix + suffix scans), sigma / beta, collapsed radiance decoder ->
+//      per-sample upstream vectors dz (3), g_n (3), g_sdf, handed to the MFMA lanes through LDS
+//   2. wave = 64 samples as 16-column tiles, two tiles per pass; everything TRANSPOSED [feature x sample] exactly as in
+//      shade_fwd.hip, so accumulator tiles feed the next GEMM without staging:
+//        A  = W0' U,  Q = W0' V                   V = d(inputs)/dp contracted with the normal's upstream (A.4)
+//        T  = W1^T GF                              GF = upstream of the 17 MLP outputs
+//        DA = S1 . T + S2 . w1_0 . Q,  GJ = S1 . w1_0         (elementwise on accumulator registers)
+//        DE = W0'^T DA,  RR = W0'^T GJ            (encoding rows only: the payload of the table-gradient scatter)
+//        second field: A2, T2 = W1g^T GF2, DA2 = S1 . T2, DE2 = W0g'^T DA2
+//      and the per-sample operands of the weight-gradient GEMMs (wgrad kernel) are stored from the accumulator layout.
+// MFMA-ordered weights are staged into LDS once per workgroup.  fp32 MFMA: exact fp32 products / sums.
+#include "render_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int NC = 2;          // 16-sample column tiles per pass (two passes per wave)
+
+template <bool DUAL, int MAXT>
+__global__ void __launch_bounds__(MAXT, 2)
+shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
+                 const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
+                 Upstream up, float* __restrict__ out) {
+    __shared__ float s_part[MAXT / 64][8];
+    __shared__ double s_db[MAXT / 64];
+    __shared__ int s_bound[32];                  // per-level max of a single scatter contribution (bits of a float >= 0)
+    __shared__ float s_y[MAXT][8];               // per sample: dz(3), g_n(3), g_sdf
+    __shared__ float s_w[kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB)
+    const int N = fc.n_samples;
+    const int64_t r = blockIdx.x;
+    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    const int jl = lane & 15, g = lane >> 4;
+    const int64_t P = w.p_pad;
+    const uint32_t P32 = (uint32_t)w.p_pad;
+    const float* __restrict__ f_e1 = fws + w.e1;
+    const float* __restrict__ f_j1 = fws + w.j1;
+    const float* __restrict__ f_e2 = fws + w.e2;
+    float* __restrict__ o_v = out + w.v;
+    float* __restrict__ o_gf = out + w.gf;
+    float* __restrict__ o_da = out + w.da;
+    float* __restrict__ o_g = out + w.g;
+    float* __restrict__ o_h = out + w.h;
+    float* __restrict__ o_sq = out + w.sq;
+    float* __restrict__ o_da2 = out + w.da2;
+    float* __restrict__ o_h2 = out + w.h2;
+    float* __restrict__ o_gf2 = out + w.gf2;
+    const RayGeom gm = load_ray(fc, center, ray, r);
+    {   // stage the SDF field's operand-ordered weights (consumed after the barriers of part 1)
+        const float4* src = reinterpret_cast<const float4*>(&pk->bs);
+        float4* dst = reinterpret_cast<float4*>(s_w);
+        for (int q = n; q < kMfmaBwdSdfFloats / 4; q += blockDim.x) dst[q] = src[q];
+    }
+    if (n < 32) s_bound[n] = 0;
+
+    // =========================================================================== 1. one thread per sample
+    {
+        const bool live = n < N;
+        const int nn = live ? n : N - 1;
+        const int64_t i = r * N + nn;
+        const float t = sample_depth(gm, nn, N);
+        const float t_next = sample_depth(gm, nn + 1, N);
+        const float t_last = sample_depth(gm, N - 1, N);
+        const float ray_len = sqrtf(gm.d[0] * gm.d[0] + gm.d[1] * gm.d[1] + gm.d[2] * gm.d[2]);
+        float g_rgb[3], g_nm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g_rgb[c] = up.d_rgb ? up.d_rgb[r * 3 + c] : 0.f;
+            g_nm[c] = up.d_nm ? up.d_nm[r * 3 + c] : 0.f;
+        }
+        const float g_dep = up.d_depth ? up.d_depth[r] : 0.f;
+        // forward per-sample values saved by shade_fwd
+        const float sdf = fws[w.sdfv + i];
+        float nrm[3], col[3], n_last[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            nrm[a] = fws[w.nrm + a * P + i];
+            col[a] = fws[w.rgbs + a * P + i];
+            n_last[a] = fws[w.nrm + a * P + r * N + N - 1];
+        }
+        const float alpha = pk->alpha, beta = pk->beta;
+        const float lap = 0.5f * expf(-fabsf(sdf) / beta);
+        const float sigma = alpha * (sdf >= 0.f ? lap : 1.0f - lap);
+        // composite forward quantities (same scans as shade_fwd)
+        const bool interval = n < N - 1;
+        const float delta = (t_next - t) * ray_len;
+        const float tau = interval ? sigma * delta : 0.f;
+        const float incl = wave_scan_incl(tau, lane);
+        if (lane == 63) s_part[wave][0] = incl;
+        __syncthreads();
+        float before = incl - tau;
+        for (int q = 0; q < wave; ++q) before += s_part[q][0];
+        const float trans = expf(-before), ex = expf(-tau);
+        const float wgt = interval ? trans * (1.0f - ex) : 0.f;
+        // composite backward:  L = sum_i w_i (V_i - B) + B ;  dL/dtau_k = U_k T_k e^{-tau_k} - sum_{i>k} U_i w_i
+        float b_term = g_dep * t_last, v_term = g_dep * t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            b_term = fmaf(g_rgb[c], fc.bg[c], b_term);
+            b_term = fmaf(g_nm[c], n_last[c], b_term);
+            v_term = fmaf(g_rgb[c], col[c], v_term);
+            v_term = fmaf(g_nm[c], nrm[c], v_term);
+        }
+        const float u_w = interval ? (v_term - b_term) * wgt : 0.f;
+        const float incl_uw = wave_scan_incl(u_w, lane);
+        const float wsum_w = wave_sum(wgt);
+        if (lane == 63) s_part[wave][1] = incl_uw;
+        if (lane == 0) s_part[wave][2] = wsum_w;
+        __syncthreads();
+        float uw_total = 0.f, opacity = 0.f, uw_before = 0.f;
+        for (int q = 0; q < n_waves; ++q) {
+            uw_total += s_part[q][1];
+            opacity += s_part[q][2];
+            if (q < wave) uw_before += s_part[q][1];
+        }
+        const float suffix = uw_total - (incl_uw + uw_before);
+        const float d_tau = interval ? (v_term - b_term) * trans * ex - suffix : 0.f;
+        const float g_sigma = d_tau * delta;
+        const float rest = 1.0f - opacity;
+        // per-sample upstream of colour, normal, sdf
+        float gc[3], gn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            gc[a] = wgt * g_rgb[a];
+            float v = wgt * g_nm[a];
+            if (n == N - 1) v += rest * g_nm[a];
+            if (live && up.d_normals) v += up.d_normals[i * 3 + a];
+            gn[a] = live ? v : 0.f;
+        }
+        float g_sdf = (live && up.d_sdfs) ? up.d_sdfs[i] : 0.f;
+        {   // sigma backward (+ d beta)
+            const float abs_s = fabsf(sdf);
+            const float dsig_ds = sdf != 0.f ? -alpha * lap / beta : 0.f;
+            g_sdf = fmaf(g_sigma, dsig_ds, g_sdf);
+            const float inv_b2 = 1.0f / (beta * beta);
+            const float dsig_db = sdf >= 0.f ? lap * (abs_s * inv_b2 / beta - inv_b2)
+                                             : -(1.0f - lap) * inv_b2 - lap * abs_s * inv_b2 / beta;
+            // d beta is one scalar summed over every sample with heavy cancellation: accumulate it in fp64
+            double db = (double)g_sigma * (double)dsig_db;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) db += __shfl_xor(db, o, 64);
+            if (lane == 0) s_db[wave] = db;
+        }
+        // collapsed radiance decoder backward
+        float dz[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dz[c] = gc[c] * col[c] * (1.0f - col[c]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gn[a] = fmaf(pk->wc[c][3 + a], dz[c], gn[a]);
+        // per-ray sums of dz (view-embedding columns of the decoder) and the d beta total
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = wave_sum(dz[c]);
+            if (lane == 0) s_part[wave][4 + c] = s;
+        }
+        float* y = s_y[n];
+        y[0] = dz[0]; y[1] = dz[1]; y[2] = dz[2];
+        y[3] = gn[0]; y[4] = gn[1]; y[5] = gn[2];
+        y[6] = g_sdf;
+        __syncthreads();          // s_part, s_db, s_y, s_w, s_bound ready
+        if (n < 3) {
+            float s = 0.f;
+            for (int q = 0; q < n_waves; ++q) s += s_part[q][4 + n];
+            out[w.dzr + n * w.r_pad + r] = s;
+        }
+        if (n == 3) {
+            double s = 0.0;
+            for (int q = 0; q < n_waves; ++q) s += s_db[q];
+            atomicAdd(reinterpret_cast<double*>(out + w.dbeta), s);
+        }
+        if (n < kView) out[w.renc + n * w.r_pad + r] = view_component(gm.d, n);
+    }
+
+    // =========================================================================== 2. MFMA lanes
+    const float* __restrict__ s_w0a = s_w;                              // [m][t][lane]
+    const float* __restrict__ s_w1ta = s_w + 4 * 9 * 64;                // [m][5][lane]
+    const float* __restrict__ s_w0ta = s_w1ta + 4 * 5 * 64;             // [mk][m][r][lane]
+    const float* __restrict__ s_w10 = s_w0ta + 2 * 4 * 4 * 64;          // [m][r][lane]
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        uint32_t is[NC];                  // point index (32-bit offsets: uniform base + VGPR offset addressing)
+        bool live_c[NC];
+        float pw[NC][3], xg[NC][3], dz[NC][3], gns[NC][3], gnk[NC][3], gsdf[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const int sl = 64 * wave + 16 * (NC * half + cc) + jl;       // sample slot in the workgroup
+            live_c[cc] = sl < N;
+            const int nn = live_c[cc] ? sl : N - 1;
+            is[cc] = (uint32_t)(r * N + nn);
+            sample_position(fc, gm, sample_depth(gm, nn, N), pw[cc], xg[cc]);
+            const float* y = s_y[sl];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                dz[cc][a] = y[a];
+                gnk[cc][a] = fc.kappa * y[3 + a];
+                gns[cc][a] = gnk[cc][a] * fc.inv_ext[a];
+            }
+            gsdf[cc] = y[6];
+        }
+        // ---- B operands: u, v (rows k' = 4t + g) and the MLP-output upstream gf (rows o = 4t + g)
+        float ub[9][NC], vb[9][NC], gfb[5][NC];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+                const int ch = 4 * t + g;
+                const bool on = ch < ch1;
+                ub[t][cc] = on ? f_e1[(uint32_t)ch * P32 + is[cc]] : 0.f;
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc = fmaf(on ? f_j1[(uint32_t)(ch * 3 + a) * P32 + is[cc]] : 0.f, gns[cc][a], acc);
+                vb[t][cc] = acc;
+            }
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
+            const float kg = g == 0 ? gnk[cc][0] : (g == 1 ? gnk[cc][1] : gnk[cc][2]);
+            ub[8][cc] = g < 3 ? pg / fc.rescale : 1.0f;
+            vb[8][cc] = g < 3 ? kg / fc.rescale : 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int o = 4 * t + g;                                  // gf[0] = kappa g_sdf ; gf[1 + m] = Wc[:, 33 + m]^T dz
+                float v = 0.f;
+                if (o == 0) v = fc.kappa * gsdf[cc];
+                else if (o < kOut) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v = fmaf(pk->wc[k][32 + o], dz[cc][k], v);
+                }
+                gfb[t][cc] = v;
+            }
+        }
+        // per-sample operands of the weight-gradient GEMMs that exist only in this layout
+        const float g1[NC] = {fabsf(gns[0][0]) + fabsf(gns[0][1]) + fabsf(gns[0][2]),
+                              fabsf(gns[1][0]) + fabsf(gns[1][1]) + fabsf(gns[1][2])};
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+            if (live_c[cc]) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int kp = 4 * t + g;                             // k' -> the reference's input column
+                    if (kp < 35) o_v[(uint32_t)(kp < 32 ? 3 + kp : kp - 32) * P32 + is[cc]] = vb[t][cc];
+                }
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (4 * t + g < kOut) o_gf[(uint32_t)(4 * t + g) * P32 + is[cc]] = gfb[t][cc];
+                if (g < 3) {
+                    const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
+                    (out + w.pu)[(uint32_t)g * P32 + is[cc]] = pg / fc.rescale;
+                    (out + w.p3)[(uint32_t)g * P32 + is[cc]] = pg;
+                    (out + w.dz)[(uint32_t)g * P32 + is[cc]] = g == 0 ? dz[cc][0] : (g == 1 ? dz[cc][1] : dz[cc][2]);
+                }
+            }
+
+        // ---- SDF field
+        f32x4 de[2][NC], rr[2][NC];
+#pragma unroll
+        for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) { de[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; rr[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+        for (int m = 0; m < 4; ++m) {
+            f32x4 aa[NC], qq[NC], tt[NC];
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) { aa[cc] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[cc] = aa[cc]; tt[cc] = aa[cc]; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float a = s_w0a[(m * 9 + t) * 64 + lane];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    aa[cc] = mfma4(a, ub[t][cc], aa[cc]);
+                    qq[cc] = mfma4(a, vb[t][cc], qq[cc]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const float a = s_w1ta[(m * 5 + t) * 64 + lane];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) tt[cc] = mfma4(a, gfb[t][cc], tt[cc]);
+            }
+            float da[NC][4], gj[NC][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float w10 = s_w10[(m * 4 + q) * 64 + lane];
+                const uint32_t row = (uint32_t)(16 * m + 4 * g + q) * P32;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    float h, s1, s2;
+                    softplus100(aa[cc][q], h, s1, s2);
+                    da[cc][q] = fmaf(s1, tt[cc][q], s2 * w10 * qq[cc][q]);
+                    gj[cc][q] = s1 * w10;
+                    if (live_c[cc]) {
+                        o_da[row + is[cc]] = da[cc][q];
+                        o_g[row + is[cc]] = gj[cc][q];
+                        o_h[row + is[cc]] = h;
+                        o_sq[row + is[cc]] = s1 * qq[cc][q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float at = s_w0ta[((mk * 4 + m) * 4 + q) * 64 + lane];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        de[mk][cc] = mfma4(at, da[cc][q], de[mk][cc]);
+                        rr[mk][cc] = mfma4(at, gj[cc][q], rr[mk][cc]);
+                    }
+                }
+        }
+        // scatter payload of the SDF grid: one 64-byte record per (level, point); this lane owns rows 16 mk + 4 g + {0..3}
+        // = levels 8 mk + 2 g and 8 mk + 2 g + 1.  Per-level bound of a single contribution |w de + D rr| <=
+        // |de| + scale |g_n|_1 |rr| fixes the fixed-point quantum of the slab accumulators.
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+            for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+                for (int hv = 0; hv < 2; ++hv) {
+                    const int l = 8 * mk + 2 * g + hv;
+                    if (2 * l < ch1 && live_c[cc]) {
+                        const float d0 = de[mk][cc][2 * hv], d1 = de[mk][cc][2 * hv + 1];
+                        const float r0 = rr[mk][cc][2 * hv], r1 = rr[mk][cc][2 * hv + 1];
+                        float4* dst = reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + is[cc]) * 16);
+                        dst[0] = make_float4(xg[cc][0], xg[cc][1], xg[cc][2], 0.f);
+                        dst[1] = make_float4(d0, d1, r0, r1);
+                        dst[2] = make_float4(gns[cc][0], gns[cc][1], gns[cc][2], 0.f);
+                        const float b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[l] * g1[cc] * fmaxf(fabsf(r0), fabsf(r1));
+                        atomicMax(&s_bound[l], __float_as_int(b));
+                    }
+                }
+
+        // ---- second field: plain first-order backward of its Geometry MLP
+        if (DUAL) {
+            __syncthreads();      // every wave is done with the SDF weights
+            {
+                const float4* src = reinterpret_cast<const float4*>(&pk->bg);
+                float4* dst = reinterpret_cast<float4*>(s_w);
+                for (int q = n; q < kMfmaBwdGeoFloats / 4; q += blockDim.x) dst[q] = src[q];
+            }
+            const float* __restrict__ g_w1ta = s_w + 4 * 9 * 64;        // [m][4][lane]
+            const float* __restrict__ g_w0ta = g_w1ta + 4 * 4 * 64;     // [mk][m][r][lane]
+            float gf2b[4][NC];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) ub[t][cc] = (4 * t + g) < ch2 ? f_e2[(uint32_t)(4 * t + g) * P32 + is[cc]] : 0.f;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v = fmaf(pk->wc[k][49 + 4 * t + g], dz[cc][k], v);
+                    gf2b[t][cc] = v;
+                    if (live_c[cc]) o_gf2[(uint32_t)(1 + 4 * t + g) * P32 + is[cc]] = v;
+                }
+                if (live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
+            }
+            __syncthreads();      // second field's weights staged
+            f32x4 de2[2][NC];
+#pragma unroll
+            for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) de2[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int m = 0; m < 4; ++m) {
+                f32x4 aa[NC], tt[NC];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) { aa[cc] = f32x4{0.f, 0.f, 0.f, 0.f}; tt[cc] = aa[cc]; }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float a = s_w0a[(m * 9 + t) * 64 + lane];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) aa[cc] = mfma4(a, ub[t][cc], aa[cc]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = g_w1ta[(m * 4 + t) * 64 + lane];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) tt[cc] = mfma4(a, gf2b[t][cc], tt[cc]);
+                }
+                float da[NC][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t row = (uint32_t)(16 * m + 4 * g + q) * P32;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        float h, s1, s2;
+                        softplus100(aa[cc][q], h, s1, s2);
+                        da[cc][q] = s1 * tt[cc][q];
+                        if (live_c[cc]) {
+                            o_da2[row + is[cc]] = da[cc][q];
+                            o_h2[row + is[cc]] = h;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float at = g_w0ta[((mk * 4 + m) * 4 + q) * 64 + lane];
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) de2[mk][cc] = mfma4(at, da[cc][q], de2[mk][cc]);
+                    }
+            }
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+                for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+                    for (int hv = 0; hv < 2; ++hv) {
+                        const int l = 8 * mk + 2 * g + hv;
+                        if (2 * l < ch2 && live_c[cc]) {
+                            const float d0 = de2[mk][cc][2 * hv], d1 = de2[mk][cc][2 * hv + 1];
+                            float4* dst = reinterpret_cast<float4*>(out + w.rec2 + ((int64_t)l * P + is[cc]) * 8);
+                            dst[0] = make_float4(xg[cc][0], xg[cc][1], xg[cc][2], 0.f);
+                            dst[1] = make_float4(d0, d1, 0.f, 0.f);
+                            atomicMax(&s_bound[16 + l], __float_as_int(fmaxf(fabsf(d0), fabsf(d1))));
+                        }
+                    }
+            if (half == 0) {      // restore the SDF weights for the second pass
+                __syncthreads();
+                const float4* src = reinterpret_cast<const float4*>(&pk->bs);
+                float4* dst = reinterpret_cast<float4*>(s_w);
+                for (int q = n; q < kMfmaBwdSdfFloats / 4; q += blockDim.x) dst[q] = src[q];
+                __syncthreads();
+            }
+        }
+    }
+    // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
+    __syncthreads();
+    if (n < 32) out[w.smax + n * w.r_pad + r] = __int_as_float(s_bound[n]);
+}
+
+}  // namespace
+
+int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
+                           const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
+                           const Upstream& up, hipStream_t s) {
+    const int threads = (fc.n_samples + 63) / 64 * 64;
+#define LS2FM_SHADE_BWD(DUAL, MAXT) \
+    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws)
+    if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
+    else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
+#undef LS2FM_SHADE_BWD
+    return LS2FM_OK;
+}
