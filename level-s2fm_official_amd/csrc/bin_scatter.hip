@@ -330,11 +330,12 @@ int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points) {
     return 3 * LS2FM_MAX_LEVELS * kBins + 64 + 5 * (int64_t)n_levels * n_points + 64;
 }
 
+size_t ls2fm_bin_counts_bytes() { return sizeof(int) * LS2FM_MAX_LEVELS * kBins; }
+
 // count -> scan -> fill of the per-slab item lists (geometry only: shared by both grids)
 int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, int64_t n_points, int64_t p_pad, float* bins_ws,
                            hipStream_t stream) {
-    const BinMeta bm = make_bin_meta(bins_ws);
-    if (hipMemsetAsync(bm.count, 0, sizeof(int) * LS2FM_MAX_LEVELS * kBins, stream) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    const BinMeta bm = make_bin_meta(bins_ws);              // counts: zeroed by the caller (ls2fm_bin_counts_bytes)
     const LevelSet lv = make_level_set(grid);
     const dim3 g((unsigned)((n_points + kBinTile - 1) / kBinTile), (unsigned)grid->n_levels);
     bin_pass_kernel<false><<<g, kBinThreads, 0, stream>>>(lv, keys, n_points, p_pad, bm);
@@ -354,7 +355,7 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     plan.headroom_bits = 4;                  // 8 corners per point (+1)
     while ((1ll << (plan.headroom_bits - 4)) < n_points) ++plan.headroom_bits;
     const int64_t r_pad = (n_rays + 63) / 64 * 64;
-    int total = 0;
+    int total = 0, zero_lo = -1, zero_hi = -1;
     const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/64)
     for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
         plan.first[l] = total;
@@ -369,11 +370,16 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
             if (parts < 1) parts = 1;
         }
         plan.parts[l] = parts;
-        if (parts > 1) {      // atomically flushed level: zero it first
-            if (hipMemsetAsync(dtable + 2ull * grid->offset[l], 0, sizeof(float) * 2ull * grid->size[l], stream) != hipSuccess)
-                return LS2FM_ERR_LAUNCH;
+        if (parts > 1) {      // atomically flushed level: zeroed first (one memset over the range of such levels)
+            if (zero_lo < 0) zero_lo = l;
+            zero_hi = l;
         }
         total += slabs * parts;
+    }
+    if (zero_lo >= 0) {       // levels in between that have a sole owner are overwritten afterwards anyway
+        const size_t first = grid->offset[zero_lo], last = (size_t)grid->offset[zero_hi] + grid->size[zero_hi];
+        if (hipMemsetAsync(dtable + 2ull * first, 0, sizeof(float) * 2ull * (last - first), stream) != hipSuccess)
+            return LS2FM_ERR_LAUNCH;
     }
     const LevelSet lv = make_level_set(grid);
     if (second_order)

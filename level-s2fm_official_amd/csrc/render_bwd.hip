@@ -269,6 +269,7 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 // ------------------------------------------------------------------------------------------- C ABI
 int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, int64_t n_points, int64_t p_pad, float* bins_ws,
                            hipStream_t stream);
+size_t ls2fm_bin_counts_bytes();
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, int64_t p_pad, const float* rec,
                                  bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
                                  hipStream_t stream);
@@ -298,8 +299,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
     const int64_t P = w.p_pad;
 
-    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (WgLayout::total), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
-    if (hipMemsetAsync(ws + w.dbeta, 0, sizeof(float) * 64, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    // one memset: reduced weight gradients, the d beta accumulator and the bin counters are adjacent in the workspace
+    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.bins - w.wg) + ls2fm_bin_counts_bytes(), s) != hipSuccess)
+        return LS2FM_ERR_LAUNCH;
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 

@@ -255,7 +255,6 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
     w.rec1 = take(16 * (int64_t)l1 * P);         // [level][point]{x y z - | de0 de1 rr0 rr1 | gn0 gn1 gn2 - | pad}: 64-byte scatter payload (SDF grid)
     w.rec2 = take(dual ? 8 * (int64_t)l2 * P : 0); // [level][point]{x y z - | de0 de1 - -}: 32-byte scatter payload (second grid)
-    w.bins = take(ls2fm_bins_workspace_floats(l1, w.p));   // per-slab item lists of the scatter (bin_scatter.hip)
     w.da = take(64 * P);
     w.g = take(64 * P);
     w.h = take(64 * P);
@@ -275,6 +274,8 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.part = take((int64_t)kWgradJobs * w.nblk * kWgradTile);
     w.wg = take(WgLayout::total);
     w.dbeta = take(64);
+    // bin meta (counts first) directly after wg / dbeta: one memset zeroes all three (render_bwd.hip)
+    w.bins = take(ls2fm_bins_workspace_floats(l1, w.p));   // per-slab item lists of the scatter (bin_scatter.hip)
     w.smax = take(32 * w.r_pad); // [32][r_pad]: per-ray bound of one scatter contribution per level ([0,16) SDF grid, [16,32) second grid)
     w.total = o;
     return w;

@@ -72,8 +72,42 @@ def can_eval_without_graph(sdf_field, xyz) -> bool:
     return not xyz.requires_grad and not any(p.requires_grad for p in sdf_field.parameters())
 
 
+class _Plan:
+    """Everything about one (renderer, SDF field, radiance field, opt) combination that does not change from call to
+    call: the gating verdict, the descriptor structs, the parameter list.  Rebuilding these costs ~0.2 ms of Python
+    per step -- as much as the device work of a kernel -- so they are cached and keyed on the option values read."""
+    __slots__ = ("key", "ok", "cfg", "ts", "ws_bytes", "pkey", "pstruct")
+
+
+_PLANS = {}
+
+
+def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
+    ident = (id(renderer), id(sdf_field), id(rad_field))
+    key = (int(opt.SDF.VolSDF.sample_intvs), opt.Ablate_config.dual_field == True, opt.data.inside == True,  # noqa: E712
+           opt.data.bg_sdf == True, opt.SDF.VolSDF.volsdf_sampling != False, _DISABLE)  # noqa: E712
+    pl = _PLANS.get(ident)
+    if pl is not None and pl.key == key:
+        return pl
+    pl = _Plan()
+    pl.key = key
+    pl.ok = supported(opt, sdf_field, rad_field)
+    pl.cfg = pl.ts = pl.pkey = pl.pstruct = None
+    pl.ws_bytes = {}
+    if pl.ok:
+        ts, dual = param_tensors(sdf_field, rad_field)
+        g1 = sdf_field.embed_fn.embedder_obj.desc
+        g2 = rad_field.embed_fn.embedder_obj.desc if dual else g1
+        pl.cfg = (field_desc(opt, renderer), g1, g2, dual, float(sdf_field.beta_speed), pl)
+        pl.ts = ts
+    if len(_PLANS) > 64:
+        _PLANS.clear()
+    _PLANS[ident] = pl
+    return pl
+
+
 def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
-    if not (center.is_cuda and ray.is_cuda) or not supported(opt, sdf_field, rad_field):
+    if not (center.is_cuda and ray.is_cuda) or not _plan(renderer, opt, sdf_field, rad_field).ok:
         return False
     if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad):
         return False            # pose gradients: general form
@@ -161,7 +195,7 @@ def _is_table(p) -> bool:
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, center, ray, cfg, *params):
-        fdesc, g1, g2, dual, beta_speed = cfg
+        fdesc, g1, g2, dual, beta_speed, plan = cfg
         lib = _lib.load()
         ctx.set_materialize_grads(False)        # unused outputs reach backward as None -> NULL upstream, no zero fills
         dev = center.device
@@ -170,10 +204,20 @@ class _Render(torch.autograd.Function):
         n = fdesc.n_samples
         c = center.detach().reshape(-1, 3).float().contiguous()
         d = ray.detach().reshape(-1, 3).float().contiguous()
-        ps = [p.detach().contiguous() for p in params]
-        ws_bytes = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(g1), n_rays)
-        if ws_bytes < 0:
-            check(int(ws_bytes), "ls2fm_render_workspace_bytes")
+        ps = params                             # nn.Parameters: contiguous fp32 by construction (checked in the plan key)
+        pkey = tuple([p.data_ptr() for p in ps])
+        if plan.pkey != pkey:                   # pointers only change when a module is re-created / moved
+            for p in ps:
+                if not (p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda):
+                    raise RuntimeError("ls2fm: fused render needs contiguous fp32 GPU parameters")
+            plan.pstruct = _params_struct(ps, dual, beta_speed)
+            plan.pkey = pkey
+        ws_bytes = plan.ws_bytes.get(n_rays)
+        if ws_bytes is None:
+            ws_bytes = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(g1), n_rays)
+            if ws_bytes < 0:
+                check(int(ws_bytes), "ls2fm_render_workspace_bytes")
+            plan.ws_bytes[n_rays] = ws_bytes
         ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
         if _POISON:
             ws.fill_(float("nan"))          # debug: any read of a workspace word that was never written shows up as NaN
@@ -182,19 +226,20 @@ class _Render(torch.autograd.Function):
         normals = torch.empty(*shape2, n, 3, device=dev)
         depth = torch.empty(*shape2, 1, device=dev)
         nmlp = torch.empty(*shape2, 3, device=dev)
-        pstruct = _params_struct(ps, dual, beta_speed)
+        pstruct = plan.pstruct
         check(lib.ls2fm_render_fwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), n_rays, ptr(rgb), ptr(sdfs), ptr(normals),
                                    ptr(depth), ptr(nmlp), ptr(ws), stream_ptr()), "ls2fm_render_fwd")
         ctx.cfg = cfg
         ctx.ws = ws
         ctx.n_rays = n_rays
+        ctx.pstruct = pstruct
         ctx.save_for_backward(c, d, *ps)
         return rgb, sdfs, normals, depth, nmlp
 
     @staticmethod
     def backward(ctx, d_rgb, d_sdfs, d_normals, d_depth, d_nmlp):
-        fdesc, g1, g2, dual, beta_speed = ctx.cfg
+        fdesc, g1, g2, dual, beta_speed, _ = ctx.cfg
         lib = _lib.load()
         c, d, *ps = ctx.saved_tensors
 
@@ -214,7 +259,7 @@ class _Render(torch.autograd.Function):
             else:
                 grads.append(flat[at:at + p.numel()].view(p.shape))
                 at += p.numel()
-        pstruct = _params_struct(ps, dual, beta_speed)
+        pstruct = ctx.pstruct
         gstruct = _params_struct(grads, dual, beta_speed, cls=_lib.ParamGrads)
         check(lib.ls2fm_render_bwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), ctx.n_rays, ptr(d_rgb), ptr(d_sdfs),
@@ -225,12 +270,8 @@ class _Render(torch.autograd.Function):
 
 def render(renderer, opt, center, ray, sdf_field, rad_field):
     """Renderer.forward through the fused kernels -> the reference's result dict."""
-    ts, dual = param_tensors(sdf_field, rad_field)
-    fdesc = field_desc(opt, renderer)
-    g1 = sdf_field.embed_fn.embedder_obj.desc
-    g2 = rad_field.embed_fn.embedder_obj.desc if dual else g1
-    cfg = (fdesc, g1, g2, dual, float(sdf_field.beta_speed))
-    rgb, sdfs, normals, depth, nmlp = _Render.apply(center, ray, cfg, *ts)
+    pl = _plan(renderer, opt, sdf_field, rad_field)
+    rgb, sdfs, normals, depth, nmlp = _Render.apply(center, ray, pl.cfg, *pl.ts)
     return {"rgb": rgb, "sdfs_volume": sdfs, "normals": normals, "depth_mlp": depth, "normal_mlp": nmlp}
 
 
