@@ -242,7 +242,9 @@ int ls2fm_loss_head_bwd(const float* rgb, const float* rgb_gt, const float* norm
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the
  * call's own stream; ls2fm_profile_get() synchronises those events and returns, per internal kernel, the
- * accumulated device time in milliseconds and the number of launches.  Single-threaded use.
+ * accumulated device time in milliseconds and the number of launches.  While enabled, the calls launch their kernels
+ * serially on `stream` (the internal side-stream overlap is off) so that each span is the kernel's own duration.
+ * Single-threaded use.
  */
 int ls2fm_profile_enable(int on);
 int ls2fm_profile_reset(void);

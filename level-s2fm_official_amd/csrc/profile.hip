@@ -12,7 +12,7 @@ namespace {
 const char* const kNames[LS2FM_PROF_COUNT] = {
     "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "wgrad", "wgrad_reduce",
     "slab_scatter_sdf", "slab_scatter_rad", "finalize", "sdf_eval", "sphere_trace", "bin_build", "loss_head_fwd",
-    "loss_head_bwd"};
+    "loss_head_bwd", "wgrad_mlp"};
 
 struct Span { int id; hipEvent_t a, b; };
 
@@ -76,6 +76,8 @@ extern "C" int ls2fm_profile_reset(void) {
     for (int i = 0; i < LS2FM_PROF_COUNT; ++i) { g_total_ms[i] = 0.0; g_launches[i] = 0; }
     return LS2FM_OK;
 }
+
+bool ls2fm_prof_enabled() { return g_enabled; }
 
 extern "C" int ls2fm_profile_count(void) { return LS2FM_PROF_COUNT; }
 

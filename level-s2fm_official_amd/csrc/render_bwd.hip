@@ -2,146 +2,21 @@
 // path.  Replaces what loss.backward() traverses for Renderer.forward:
 // composite / sigma / radiance / Geometry MLPs / SDF.gradient's create_graph graph / tcnn backward kernels.
 //
-//   shade_bwd     block per ray, lane per sample: composite backward (prefix + suffix scans), sigma and
-//                 radiance backward, then the SDF MLP backward with the extra double-backward terms; per-sample
-//                 operands of the weight-gradient GEMMs are written as SoA channels
-//   wgrad         dW = A[M x P] * B[N x P]^T  with P = all sample points as the contraction axis:
-//                 f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32) from LDS-staged tiles, split over P, partials to HBM
-//   wgrad_reduce  sum of the split-P partials
-//   slab scatter  (slab_scatter.hip) LDS-owned slabs of the table gradient, no table-wide global atomics; for the SDF
+//   shade_bwd     (shade_bwd.hip) composite / sigma / decoder backward per sample, then the MLP backward chains as
+//                 transposed f32 MFMA GEMMs; writes the scatter payload records and the small per-sample upstream vectors
+//   bin build     (bin_scatter.hip) per-slab item lists, on the side stream under shade_bwd
+//   wgrad_mlp     (wgrad_mlp.hip) weight gradients of both Geometry MLPs and of the decoder columns on the matrix cores,
+//                 re-deriving the hidden-layer operands instead of reading them back from HBM; partials + fixed-order sum
+//   slab scatter  (bin_scatter.hip) LDS-owned slabs of the table gradient, no table-wide global atomics; for the SDF
 //                 grid the first-order (trilinear) and double-backward (derivative-weight) terms in one add
 //   finalize      un-collapse the radiance chain, weight-norm backward, d beta
 #include <cstdlib>
-#include <initializer_list>
 
 #include "render_common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------- wgrad (MFMA)
-struct Seg { const float* base; int rows; int pad; };
-struct WJob {
-    Seg a[2];
-    Seg b[5];
-    int m, n;             // live rows of A (<= 64) and of B (<= 80)
-    int64_t k, ld;        // contraction length and channel stride
-    int out_off, out_ld;  // destination inside the reduced-gradient buffer
-};
-struct WJobs { WJob job[kWgradJobs]; };
-
-constexpr int kTileK = 64;
-constexpr int kLdsLd = kTileK + 2;      // row stride == 2 (mod 32) banks: conflict-free MFMA operand reads
-
-template <int NSEG>
-__device__ __forceinline__ const float* seg_row(const Seg (&s)[NSEG], int row, int64_t ld) {
-    int base = 0;
-#pragma unroll
-    for (int q = 0; q < NSEG; ++q) {
-        if (row < base + s[q].rows) return s[q].base ? s[q].base + (int64_t)(row - base) * ld : nullptr;   // null base: zero rows
-        base += s[q].rows;
-    }
-    return nullptr;
-}
-
-__global__ void __launch_bounds__(256)
-wgrad_kernel(WJobs jobs, int nblk, float* __restrict__ part) {
-    __shared__ float As[64 * kLdsLd];
-    __shared__ float Bs[80 * kLdsLd];
-    const WJob& J = jobs.job[blockIdx.y];
-    const int64_t k_begin = (int64_t)blockIdx.x * kWgradKB;
-    if (k_begin >= J.k) return;
-    const int64_t k_end = k_begin + kWgradKB < J.k ? k_begin + kWgradKB : J.k;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_tiles = (J.n + 15) / 16;
-    f32x4 acc[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Staging is software pipelined through registers: the global loads of tile t+1 are in flight while the
-    // MFMAs consume tile t from LDS (each row of a tile is one coalesced 256-byte segment).
-    const int lrow = tid >> 4, lcol = (tid & 15) * 4;
-    const float* src_row[9];
-#pragma unroll
-    for (int pass = 0; pass < 9; ++pass) {
-        const int row = pass * 16 + lrow;                     // 0..143: A rows 0..63, then B rows 0..79
-        const int rr = row < 64 ? row : row - 64;
-        src_row[pass] = nullptr;
-        if (row < 64) { if (rr < J.m) src_row[pass] = seg_row<2>(J.a, rr, J.ld); }
-        else          { if (rr < J.n) src_row[pass] = seg_row<5>(J.b, rr, J.ld); }
-    }
-    float4 stage[9];
-    auto load_stage = [&](int64_t kt) {
-#pragma unroll
-        for (int pass = 0; pass < 9; ++pass) {
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src_row[pass]) {
-                val = *reinterpret_cast<const float4*>(src_row[pass] + kt + lcol);
-                const int64_t k0 = kt + lcol;
-                if (k0 + 0 >= J.k) val.x = 0.f;
-                if (k0 + 1 >= J.k) val.y = 0.f;
-                if (k0 + 2 >= J.k) val.z = 0.f;
-                if (k0 + 3 >= J.k) val.w = 0.f;
-            }
-            stage[pass] = val;
-        }
-    };
-    load_stage(k_begin);
-    for (int64_t kt = k_begin; kt < k_end; kt += kTileK) {
-#pragma unroll
-        for (int pass = 0; pass < 9; ++pass) {
-            const int row = pass * 16 + lrow;
-            float* dst = (row < 64 ? As + row * kLdsLd : Bs + (row - 64) * kLdsLd) + lcol;
-            *reinterpret_cast<float2*>(dst) = make_float2(stage[pass].x, stage[pass].y);
-            *reinterpret_cast<float2*>(dst + 2) = make_float2(stage[pass].z, stage[pass].w);
-        }
-        __syncthreads();
-        if (kt + kTileK < k_end) load_stage(kt + kTileK);
-        if (wave * 16 < J.m) {
-            const float* a_base = As + (wave * 16 + (lane & 15)) * kLdsLd + (lane >> 4);
-            const float* b_base = Bs + (lane & 15) * kLdsLd + (lane >> 4);
-#pragma unroll 4
-            for (int ks = 0; ks < kTileK / 4; ++ks) {
-                const float a = a_base[ks * 4];
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-                    if (q < n_tiles)
-                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_base[q * 16 * kLdsLd + ks * 4], acc[q], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    // D layout (16x16): column = lane & 15, row = 4 * (lane >> 4) + reg
-    float* dst = part + ((int64_t)blockIdx.y * nblk + blockIdx.x) * kWgradTile;
-#pragma unroll
-    for (int q = 0; q < 5; ++q)
-        if (q < n_tiles) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                dst[(wave * 16 + 4 * (lane >> 4) + reg) * 80 + q * 16 + (lane & 15)] = acc[q][reg];
-        }
-}
-
-__global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(WJobs jobs, int nblk, const float* __restrict__ part, float* __restrict__ wg) {
-    // 64 output elements per workgroup, 4 threads per element striding over the split-P partials
-    __shared__ float s_sum[4][64];
-    const WJob& J = jobs.job[blockIdx.y];
-    const int sub = threadIdx.x >> 6, el = threadIdx.x & 63;
-    const int e = blockIdx.x * 64 + el;
-    const int mi = e / 80, ni = e % 80;
-    const bool on = mi < J.m && ni < J.n;
-    const int live_blocks = (int)((J.k + kWgradKB - 1) / kWgradKB);
-    float s = 0.f;
-    if (on)
-        for (int b = sub; b < live_blocks; b += 4)
-            s += part[((int64_t)blockIdx.y * nblk + b) * kWgradTile + mi * 80 + ni];
-    s_sum[sub][el] = s;
-    __syncthreads();
-    if (sub == 0 && on)     // two jobs may target the same matrix (dW0): a + b == b + a, still deterministic
-        atomicAdd(wg + J.out_off + mi * J.out_ld + ni, (s_sum[0][el] + s_sum[1][el]) + (s_sum[2][el] + s_sum[3][el]));
-}
 
 // ------------------------------------------------------------------------------------------- finalize
 // weight-norm backward of a whole layer:  W = (g/||v||) v  ->  dg = <dW,v>/||v|| ; dv = (g/||v||) dW - g <dW,v>/||v||^3 v.
@@ -323,42 +198,12 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
 
-    // weight-gradient GEMMs over all sample points
-    WJobs jobs;
-    for (int q = 0; q < kWgradJobs; ++q) jobs.job[q] = WJob{};
-    auto seg = [&](int64_t off, int rows) { return Seg{ws + off, rows, 0}; };
-    int nj = 0;
-    auto add = [&](Seg a0, Seg a1, std::initializer_list<Seg> bs, int64_t k, int64_t ld, int out_off, int out_ld) {
-        WJob& J = jobs.job[nj++];
-        J.a[0] = a0; J.a[1] = a1;
-        int q = 0;
-        J.n = 0;
-        for (const Seg& b : bs) { J.b[q++] = b; J.n += b.rows; }
-        J.m = a0.rows + a1.rows;
-        J.k = k; J.ld = ld; J.out_off = out_off; J.out_ld = out_ld;
-    };
-    const Seg none{nullptr, 0, 0};
-    const Seg ones = seg(w.ones, 1);
-    add(seg(w.da, 64), none, {seg(w.pu, 3), seg(w.e1, 2 * L1), Seg{nullptr, 32 - 2 * L1, 0}, ones}, w.p, P, WgLayout::dW0, 36);
-    add(seg(w.g, 64), none, {seg(w.v, 35)}, w.p, P, WgLayout::dW0, 36);
-    add(seg(w.gf, 17), none, {seg(w.h, 64), ones}, w.p, P, WgLayout::dW1, 65);
-    add(ones, none, {seg(w.sq, 64)}, w.p, P, WgLayout::dW1r0, 64);
-    add(seg(w.dz, 3), none, {seg(w.p3, 3), seg(w.nrm, 3), seg(w.fe, 16), dual ? seg(w.fe2, 16) : Seg{nullptr, 16, 0}, ones},
-        w.p, P, WgLayout::dWc, 39);
-    add(seg(w.dzr, 3), none, {seg(w.renc, 27)}, n_rays, w.r_pad, WgLayout::dWv, 27);
-    if (dual) {
-        add(seg(w.da2, 64), none, {seg(w.pu, 3), seg(w.e2, 2 * L2), Seg{nullptr, 32 - 2 * L2, 0}, ones}, w.p, P, WgLayout::dG0, 36);
-        add(seg(w.gf2, 17), none, {seg(w.h2, 64), ones}, w.p, P, WgLayout::dG1, 65);
-    }
     // fork 2: weight-gradient GEMM -> reduce -> finalize run on the side stream, concurrently with the table scatters
     if (forked && (hipEventRecord(sc.fork, s) != hipSuccess || hipStreamWaitEvent(sc.side, sc.fork, 0) != hipSuccess))
         return LS2FM_ERR_LAUNCH;
-    ls2fm_prof_begin(LS2FM_PROF_WGRAD, gs);
-    wgrad_kernel<<<dim3((unsigned)w.nblk, (unsigned)nj), 256, 0, gs>>>(jobs, w.nblk, ws + w.part);
-    ls2fm_prof_end(LS2FM_PROF_WGRAD, gs);
-    ls2fm_prof_begin(LS2FM_PROF_WGRAD_REDUCE, gs);
-    wgrad_reduce_kernel<<<dim3((64 * 80 + 63) / 64, (unsigned)nj), 256, 0, gs>>>(jobs, w.nblk, ws + w.part, ws + w.wg);
-    ls2fm_prof_end(LS2FM_PROF_WGRAD_REDUCE, gs);
+    ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, gs);
+    ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
+    ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, gs);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     finalize_kernel<<<1, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
                                        ws + w.dbeta);

@@ -14,8 +14,9 @@ enum ls2fm_prof_id {
     LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
     LS2FM_PROF_WGRAD, LS2FM_PROF_WGRAD_REDUCE, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
     LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_BIN, LS2FM_PROF_LOSS_FWD,
-    LS2FM_PROF_LOSS_BWD, LS2FM_PROF_COUNT
+    LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_COUNT
 };
+bool ls2fm_prof_enabled();
 void ls2fm_prof_begin(int id, hipStream_t stream);      // bracket one kernel launch on the stream it is enqueued on
 void ls2fm_prof_end(int id, hipStream_t stream);
 
@@ -210,15 +211,13 @@ struct WsLayout {
     // forward -> backward
     int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4, keys;
     // backward scratch
-    int64_t rec1, rec2, bins, da, g, h, sq, v, pu, p3, gf, dz, da2, h2, gf2, dzr, renc, part, wg, dbeta, smax;
+    int64_t rec1, rec2, bins, v, p3, gf, dz, gf2, dzr, renc, mpart, wg, dbeta, smax;
     int64_t total;
-    int nblk;
 };
 
 constexpr int kSlabShift = 13;          // table-gradient scatter: 8192-entry slabs (slab_scatter.hip)
-constexpr int kWgradKB = 1024;         // points per wgrad block
-constexpr int kWgradJobs = 8;
-constexpr int kWgradTile = 64 * 80;    // max M x N of one job
+constexpr int kWgradMlpBlocks = 512;   // persistent workgroups of wgrad_mlp (2 per CU)
+int64_t ls2fm_wgrad_mlp_part_floats(int dual);
 
 // reduced raw weight gradients (floats)
 struct WgLayout {
@@ -255,23 +254,15 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
     w.rec1 = take(16 * (int64_t)l1 * P);         // [level][point]{x y z - | de0 de1 rr0 rr1 | gn0 gn1 gn2 - | pad}: 64-byte scatter payload (SDF grid)
     w.rec2 = take(dual ? 8 * (int64_t)l2 * P : 0); // [level][point]{x y z - | de0 de1 - -}: 32-byte scatter payload (second grid)
-    w.da = take(64 * P);
-    w.g = take(64 * P);
-    w.h = take(64 * P);
-    w.sq = take(64 * P);
+    // per-sample upstream vectors shade_bwd hands to the weight-gradient kernels (SoA)
     w.v = take(35 * P);
-    w.pu = take(3 * P);
     w.p3 = take(3 * P);
     w.gf = take(17 * P);
     w.dz = take(3 * P);
-    w.da2 = take(dual ? 64 * P : 0);
-    w.h2 = take(dual ? 64 * P : 0);
     w.gf2 = take(dual ? 17 * P : 0);
     w.dzr = take(3 * w.r_pad);
     w.renc = take(27 * w.r_pad);
-    w.nblk = (int)((w.p + kWgradKB - 1) / kWgradKB);
-    if (w.nblk < 1) w.nblk = 1;
-    w.part = take((int64_t)kWgradJobs * w.nblk * kWgradTile);
+    w.mpart = take(ls2fm_wgrad_mlp_part_floats(dual));
     w.wg = take(WgLayout::total);
     w.dbeta = take(64);
     // bin meta (counts first) directly after wg / dbeta: one memset zeroes all three (render_bwd.hip)
@@ -295,6 +286,10 @@ struct Upstream {                  // dL/d(outputs of render_fwd); any pointer m
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
                            const Upstream& up, hipStream_t s);
+
+// wgrad_mlp.hip
+int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s);
 
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,

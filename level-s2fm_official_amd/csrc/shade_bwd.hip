@@ -10,7 +10,8 @@
 //        DA = S1 . T + S2 . w1_0 . Q,  GJ = S1 . w1_0         (elementwise on accumulator registers)
 //        DE = W0'^T DA,  RR = W0'^T GJ            (encoding rows only: the payload of the table-gradient scatter)
 //        second field: A2, T2 = W1g^T GF2, DA2 = S1 . T2, DE2 = W0g'^T DA2
-//      and the per-sample operands of the weight-gradient GEMMs (wgrad kernel) are stored from the accumulator layout.
+//      Only the small per-sample upstream vectors (v, gf, gf2, dz, p) are stored for the weight-gradient kernels
+//      (wgrad_mlp.hip re-derives the hidden-layer operands instead of reading them back from HBM).
 // MFMA-ordered weights are staged into LDS once per workgroup.  fp32 MFMA: exact fp32 products / sums.
 #include "render_common.h"
 
@@ -45,12 +46,6 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     const float* __restrict__ f_e2 = fws + w.e2;
     float* __restrict__ o_v = out + w.v;
     float* __restrict__ o_gf = out + w.gf;
-    float* __restrict__ o_da = out + w.da;
-    float* __restrict__ o_g = out + w.g;
-    float* __restrict__ o_h = out + w.h;
-    float* __restrict__ o_sq = out + w.sq;
-    float* __restrict__ o_da2 = out + w.da2;
-    float* __restrict__ o_h2 = out + w.h2;
     float* __restrict__ o_gf2 = out + w.gf2;
     const RayGeom gm = load_ray(fc, center, ray, r);
     {   // stage the SDF field's operand-ordered weights (consumed after the barriers of part 1)
@@ -254,7 +249,6 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     if (4 * t + g < kOut) o_gf[(uint32_t)(4 * t + g) * P32 + is[cc]] = gfb[t][cc];
                 if (g < 3) {
                     const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
-                    (out + w.pu)[(uint32_t)g * P32 + is[cc]] = pg / fc.rescale;
                     (out + w.p3)[(uint32_t)g * P32 + is[cc]] = pg;
                     (out + w.dz)[(uint32_t)g * P32 + is[cc]] = g == 0 ? dz[cc][0] : (g == 1 ? dz[cc][1] : dz[cc][2]);
                 }
@@ -290,19 +284,12 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float w10 = s_w10[(m * 4 + q) * 64 + lane];
-                const uint32_t row = (uint32_t)(16 * m + 4 * g + q) * P32;
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     float h, s1, s2;
                     softplus100(aa[cc][q], h, s1, s2);
                     da[cc][q] = fmaf(s1, tt[cc][q], s2 * w10 * qq[cc][q]);
                     gj[cc][q] = s1 * w10;
-                    if (live_c[cc]) {
-                        o_da[row + is[cc]] = da[cc][q];
-                        o_g[row + is[cc]] = gj[cc][q];
-                        o_h[row + is[cc]] = h;
-                        o_sq[row + is[cc]] = s1 * qq[cc][q];
-                    }
                 }
             }
 #pragma unroll
@@ -392,16 +379,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 float da[NC][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t row = (uint32_t)(16 * m + 4 * g + q) * P32;
-#pragma unroll
+    #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) {
                         float h, s1, s2;
                         softplus100(aa[cc][q], h, s1, s2);
                         da[cc][q] = s1 * tt[cc][q];
-                        if (live_c[cc]) {
-                            o_da2[row + is[cc]] = da[cc][q];
-                            o_h2[row + is[cc]] = h;
-                        }
                     }
                 }
 #pragma unroll

@@ -1,7 +1,8 @@
 // Internal fork/join helper: a cached non-blocking side stream + events per device, so that latency-bound
 // single-workgroup kernels (prep_weights, wgrad_reduce, finalize) and the MFMA weight-gradient GEMM overlap with the
 // wide kernels of the same call.  Everything forked is joined back into the caller's stream before the C-ABI call
-// returns, so the caller-visible contract ("asynchronous on `stream`") is unchanged.  LS2FM_SERIAL=1 disables it.
+// returns, so the caller-visible contract ("asynchronous on `stream`") is unchanged.  LS2FM_SERIAL=1 disables it, and so does the opt-in per-kernel
+// profiler (overlapped kernels would time each other).
 #include <cstdlib>
 #include <mutex>
 
@@ -15,7 +16,8 @@ DeviceCtx g_ctx[64];
 
 bool ls2fm_side_stream(SideCtx* out) {
     static const bool serial = [] { const char* e = getenv("LS2FM_SERIAL"); return e && e[0] == '1'; }();
-    if (serial) return false;
+    if (serial || ls2fm_prof_enabled()) return false;      // per-kernel profiling: serial launches, so that the
+                                                           // event-bracketed durations are those of the kernel alone
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lock(g_mu);

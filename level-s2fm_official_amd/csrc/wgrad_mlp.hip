@@ -1,0 +1,371 @@
+// Weight gradients of the two Geometry MLPs (SDF field incl. the double-backward terms, second field) on the matrix
+// cores, WITHOUT materialising the per-sample GEMM operands in HBM.
+//
+// shade_bwd leaves only the small per-sample upstream vectors (gf: 17 rows, v: 35 rows, gf2: 16 rows).  This kernel
+// re-derives the hidden-layer quantities of a 16-sample tile with the same transposed MFMA chain as shade_bwd
+//      A = W0' U,  Q = W0' V,  T = W1^T GF   ->   DA = S1.T + S2.w1_0.Q,  GJ = S1.w1_0,  H
+// (~40 % of the kernel's MFMAs, against 173 MB of fp32 operand stores + 278 MB of loads for the old SoA hand-over) and
+// contracts them over the samples:
+//      dW0'  += DA U^T + GJ V^T     (64 x 36)      dW1[1..16] += GF H^T   (16 x 64)
+//      dW1[0] += sum_s gf0 H + S1.Q (row sums, VALU)               db1 += sum_s GF
+// The contraction index of these products is the SAMPLE, which sits on the wrong side of the accumulator layout, so each
+// operand tile takes one trip through a wave-private LDS tile: written [feature][sample] from the accumulator / B
+// layout, read back as one ds_read_b128 per lane (4 consecutive samples = the 4 k-slots of 4 MFMAs).
+// Persistent waves keep all 85 accumulator registers for the whole kernel; workgroups reduce through LDS and write one
+// partial each, summed by wgrad_mlp_reduce in a fixed order (deterministic).
+#include "render_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int kWmThreads = 256;
+constexpr int kWmWaves = kWmThreads / 64;
+constexpr int kLd = 20;                          // floats per LDS tile row: 16 samples + 4 pad (16-B aligned rows)
+constexpr int kRowsU = 36, kRowsGf = 20;
+constexpr int kXRows = 2 * kRowsU + kRowsGf + 3 * 16;            // u, v, gf, da, gj, h
+constexpr int kRegsSdf = 48 + 16 + 16 + 5;       // dW0 tiles, dW1 tiles, dW1 row 0, db1
+constexpr int kRegsGeo = 48 + 16 + 4;
+
+template <bool GEO>
+__global__ void __launch_bounds__(kWmThreads, 2)
+wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, const float* __restrict__ center,
+                 const float* __restrict__ ray, const float* __restrict__ ws, float* __restrict__ part, int n_tiles) {
+    constexpr int NT = GEO ? 4 : 5;
+    constexpr int R = GEO ? kRegsGeo : kRegsSdf;
+    __shared__ float s_w[4 * 9 * 64 + 4 * 5 * 64 + 4 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float s_x[kWmWaves][kXRows * kLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jl = lane & 15, g = lane >> 4;
+    const int N = fc.n_samples;
+    const uint32_t P32 = (uint32_t)w.p_pad;
+    const float* __restrict__ f_e = ws + (GEO ? w.e2 : w.e1);
+    const float* __restrict__ f_v = ws + w.v;
+    const float* __restrict__ f_gf = ws + (GEO ? w.gf2 : w.gf);
+    {
+        const float* src = GEO ? &pk->bg.w0a[0][0][0] : &pk->bs.w0a[0][0][0];      // w0a then w1ta are contiguous
+        constexpr int n01 = 4 * 9 * 64 + 4 * NT * 64;
+        for (int q = tid; q < n01 / 4; q += kWmThreads) reinterpret_cast<float4*>(s_w)[q] = reinterpret_cast<const float4*>(src)[q];
+        if (!GEO)
+            for (int q = tid; q < 4 * 4 * 64 / 4; q += kWmThreads)
+                reinterpret_cast<float4*>(s_w + 4 * 9 * 64 + 4 * 5 * 64)[q] = reinterpret_cast<const float4*>(&pk->bs.w10[0][0][0])[q];
+    }
+    __syncthreads();
+    const float* __restrict__ s_w0a = s_w;
+    const float* __restrict__ s_w1ta = s_w + 4 * 9 * 64;
+    const float* __restrict__ s_w10 = s_w + 4 * 9 * 64 + 4 * 5 * 64;
+    float* __restrict__ xu = s_x[wave];
+    float* __restrict__ xv = xu + kRowsU * kLd;
+    float* __restrict__ xgf = xv + kRowsU * kLd;
+    float* __restrict__ xda = xgf + kRowsGf * kLd;
+    float* __restrict__ xgj = xda + 16 * kLd;
+    float* __restrict__ xh = xgj + 16 * kLd;
+
+    f32x4 acc0[4][3], acc1[4];
+    float w1r0[4][4], gsum[5];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        acc1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mk = 0; mk < 3; ++mk) acc0[m][mk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w1r0[m][q] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) gsum[t] = 0.f;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles; tile += gridDim.x * kWmWaves) {
+        const uint32_t i = (uint32_t)tile * 16u + (uint32_t)jl;
+        const bool live = (int64_t)i < w.p;
+        // ---- B-layout operands of this lane's sample: rows k' = 4t + g / o = 4t + g
+        float ub[9], vb[9], gfb[5];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int c = 4 * t + g;
+            const bool on = live && c < ch;
+            ub[t] = on ? f_e[(uint32_t)c * P32 + i] : 0.f;
+            vb[t] = (!GEO && on) ? f_v[(uint32_t)(3 + c) * P32 + i] : 0.f;
+        }
+        {
+            float pg = 0.f;
+            if (live && g < 3) {
+                const int64_t r = i / (uint32_t)N;
+                const int n = (int)(i - (uint32_t)r * (uint32_t)N);
+                const RayGeom gm = load_ray(fc, center, ray, r);
+                float p[3], x[3];
+                sample_position(fc, gm, sample_depth(gm, n, N), p, x);
+                pg = g == 0 ? p[0] : (g == 1 ? p[1] : p[2]);
+            }
+            ub[8] = live ? (g < 3 ? pg / fc.rescale : 1.0f) : 0.f;
+            vb[8] = (!GEO && live && g < 3) ? f_v[(uint32_t)g * P32 + i] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int o = GEO ? 1 + 4 * t + g : 4 * t + g;
+            gfb[t] = (live && t < NT && o < kOut) ? f_gf[(uint32_t)o * P32 + i] : 0.f;
+            gsum[t] += gfb[t];
+        }
+        const float gf0 = (!GEO && live) ? f_gf[i] : 0.f;
+        // transposed copies: [feature row][sample jl]
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            xu[(4 * t + g) * kLd + jl] = ub[t];
+            if (!GEO) xv[(4 * t + g) * kLd + jl] = vb[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) xgf[(4 * t + g) * kLd + jl] = gfb[t];
+
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, qq = aa, tt = aa;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float a = s_w0a[(m * 9 + t) * 64 + lane];
+                aa = mfma4(a, ub[t], aa);
+                if (!GEO) qq = mfma4(a, vb[t], qq);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) tt = mfma4(s_w1ta[(m * NT + t) * 64 + lane], gfb[t], tt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float h, s1, s2;
+                softplus100(aa[q], h, s1, s2);
+                float da;
+                if (GEO) {
+                    da = s1 * tt[q];
+                } else {
+                    const float w10 = s_w10[(m * 4 + q) * 64 + lane];
+                    da = fmaf(s1, tt[q], s2 * w10 * qq[q]);
+                    xgj[(4 * g + q) * kLd + jl] = s1 * w10;
+                    w1r0[m][q] += fmaf(gf0, h, s1 * qq[q]);
+                }
+                xda[(4 * g + q) * kLd + jl] = da;
+                xh[(4 * g + q) * kLd + jl] = h;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // contraction over the 16 samples: lane supplies row jl, samples 4g..4g+3 of every operand
+            const float4 a_da = *reinterpret_cast<const float4*>(xda + jl * kLd + 4 * g);
+            const float4 a_gj = GEO ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(xgj + jl * kLd + 4 * g);
+            const float4 b_h = *reinterpret_cast<const float4*>(xh + jl * kLd + 4 * g);
+            const float4 a_gf = *reinterpret_cast<const float4*>(xgf + ((GEO ? 0 : 1) + jl) * kLd + 4 * g);
+#pragma unroll
+            for (int mk = 0; mk < 3; ++mk) {
+                const bool row_on = 16 * mk + jl < kRowsU;
+                float4 b_u = make_float4(0.f, 0.f, 0.f, 0.f), b_v = b_u;
+                if (row_on) {
+                    b_u = *reinterpret_cast<const float4*>(xu + (16 * mk + jl) * kLd + 4 * g);
+                    if (!GEO) b_v = *reinterpret_cast<const float4*>(xv + (16 * mk + jl) * kLd + 4 * g);
+                }
+                f32x4 c = acc0[m][mk];
+                c = mfma4(a_da.x, b_u.x, c); c = mfma4(a_da.y, b_u.y, c); c = mfma4(a_da.z, b_u.z, c); c = mfma4(a_da.w, b_u.w, c);
+                if (!GEO) {
+                    c = mfma4(a_gj.x, b_v.x, c); c = mfma4(a_gj.y, b_v.y, c); c = mfma4(a_gj.z, b_v.z, c); c = mfma4(a_gj.w, b_v.w, c);
+                }
+                acc0[m][mk] = c;
+            }
+            {
+                f32x4 c = acc1[m];
+                c = mfma4(a_gf.x, b_h.x, c); c = mfma4(a_gf.y, b_h.y, c); c = mfma4(a_gf.z, b_h.z, c); c = mfma4(a_gf.w, b_h.w, c);
+                acc1[m] = c;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- row sums over the 16 sample lanes, then workgroup reduction through LDS and one partial per workgroup
+    float regs[R];
+    {
+        int k = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int mk = 0; mk < 3; ++mk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) regs[k++] = acc0[m][mk][q];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) regs[k++] = acc1[m][q];
+        if (!GEO) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = w1r0[m][q];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    regs[k++] = v;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v = gsum[t];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            regs[k++] = v;
+        }
+    }
+    __syncthreads();                              // every wave is done with its LDS tiles
+    float* red = &s_x[0][0];                      // [R][64]
+    static_assert(kRegsSdf * 64 <= kWmWaves * kXRows * kLd, "reduction buffer fits in the tile storage");
+    for (int wv = 0; wv < kWmWaves; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (wv == 0) red[k * 64 + lane] = regs[k];
+                else red[k * 64 + lane] += regs[k];
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * (R * 64);
+    for (int q = tid; q < R * 64; q += kWmThreads) dst[q] = red[q];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Radiance-decoder columns: dWc (3 x 39) = sum over samples of dz [p, n, f, f2, 1]^T and dWv (3 x 27) = sum over rays of
+// (per-ray sums of dz) renc^T.  Every operand already lies in HBM as [row][sample]: the MFMA operands (row jl, 4
+// consecutive samples) are plain 16-byte loads, no LDS.
+constexpr int kRegsDec = 20;                     // 5 output tiles
+
+__device__ __forceinline__ float4 load4_masked(const float* __restrict__ row, int64_t s, int64_t n, bool on) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on && s < n) {
+        v = *reinterpret_cast<const float4*>(row + s);
+        if (s + 1 >= n) v.y = 0.f;
+        if (s + 2 >= n) v.z = 0.f;
+        if (s + 3 >= n) v.w = 0.f;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(kWmThreads)
+wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__ ws, float* __restrict__ part) {
+    __shared__ float red[kRegsDec * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jl = lane & 15, g = lane >> 4;
+    const int64_t P = w.p_pad;
+    f32x4 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n_tiles_p = (int)((w.p + 15) / 16), n_tiles_r = (int)((n_rays + 15) / 16);
+#pragma unroll 1
+    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_p; tile += gridDim.x * kWmWaves) {
+        const int64_t s = (int64_t)tile * 16 + 4 * g;
+        const float4 a = load4_masked(ws + w.dz + jl * P, s, w.p, jl < 3);
+        const float4 b0 = load4_masked(ws + w.fe + jl * P, s, w.p, true);
+        const float4 b1 = load4_masked(ws + w.fe2 + jl * P, s, w.p, dual != 0);
+        float4 b2 = load4_masked(jl < 3 ? ws + w.p3 + jl * P : ws + w.nrm + (jl - 3) * P, s, w.p, jl < 6);
+        if (jl == 6) b2 = make_float4(1.f, 1.f, 1.f, 1.f);           // bias column (a is zero beyond the last sample)
+        acc[0] = mfma4(a.x, b0.x, acc[0]); acc[0] = mfma4(a.y, b0.y, acc[0]); acc[0] = mfma4(a.z, b0.z, acc[0]); acc[0] = mfma4(a.w, b0.w, acc[0]);
+        acc[1] = mfma4(a.x, b1.x, acc[1]); acc[1] = mfma4(a.y, b1.y, acc[1]); acc[1] = mfma4(a.z, b1.z, acc[1]); acc[1] = mfma4(a.w, b1.w, acc[1]);
+        acc[2] = mfma4(a.x, b2.x, acc[2]); acc[2] = mfma4(a.y, b2.y, acc[2]); acc[2] = mfma4(a.z, b2.z, acc[2]); acc[2] = mfma4(a.w, b2.w, acc[2]);
+    }
+#pragma unroll 1
+    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_r; tile += gridDim.x * kWmWaves) {
+        const int64_t s = (int64_t)tile * 16 + 4 * g;
+        const float4 a = load4_masked(ws + w.dzr + jl * w.r_pad, s, n_rays, jl < 3);
+        const float4 b0 = load4_masked(ws + w.renc + jl * w.r_pad, s, n_rays, true);
+        const float4 b1 = load4_masked(ws + w.renc + (16 + jl) * w.r_pad, s, n_rays, 16 + jl < kView);
+        acc[3] = mfma4(a.x, b0.x, acc[3]); acc[3] = mfma4(a.y, b0.y, acc[3]); acc[3] = mfma4(a.z, b0.z, acc[3]); acc[3] = mfma4(a.w, b0.w, acc[3]);
+        acc[4] = mfma4(a.x, b1.x, acc[4]); acc[4] = mfma4(a.y, b1.y, acc[4]); acc[4] = mfma4(a.z, b1.z, acc[4]); acc[4] = mfma4(a.w, b1.w, acc[4]);
+    }
+    for (int wv = 0; wv < kWmWaves; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (wv == 0) red[(t * 4 + q) * 64 + lane] = acc[t][q];
+                    else red[(t * 4 + q) * 64 + lane] += acc[t][q];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * (kRegsDec * 64);
+    for (int q = tid; q < kRegsDec * 64; q += kWmThreads) dst[q] = red[q];
+}
+
+// sum of the per-workgroup partials (fixed order -> deterministic), scattered into the reduced-gradient buffer
+// (WgLayout).  One launch for all three producers: block ranges [0,85) SDF MLP, [85,153) second MLP, then 20 decoder.
+__global__ void __launch_bounds__(kWmThreads)
+wgrad_reduce_all_kernel(const float* __restrict__ part_sdf, const float* __restrict__ part_geo, const float* __restrict__ part_dec,
+                        int nb_mlp, int nb_dec, int dual, float* __restrict__ wg) {
+    __shared__ float s_sum[kWmWaves][64];
+    int k = blockIdx.x, kind = 0;
+    if (k >= kRegsSdf) { k -= kRegsSdf; kind = 1; if (!dual || k >= kRegsGeo) { k -= dual ? kRegsGeo : 0; kind = 2; } }
+    const float* part = kind == 0 ? part_sdf : (kind == 1 ? part_geo : part_dec);
+    const int R = kind == 0 ? kRegsSdf : (kind == 1 ? kRegsGeo : kRegsDec);
+    const int nb = kind == 2 ? nb_dec : nb_mlp;
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, jl = lane & 15, g = lane >> 4;
+    float s0 = 0.f, s1 = 0.f;
+    int b = grp;
+    for (; b + kWmWaves < nb; b += 2 * kWmWaves) {
+        s0 += part[((int64_t)b * R + k) * 64 + lane];
+        s1 += part[((int64_t)(b + kWmWaves) * R + k) * 64 + lane];
+    }
+    if (b < nb) s0 += part[((int64_t)b * R + k) * 64 + lane];
+    s_sum[grp][lane] = s0 + s1;
+    __syncthreads();
+    if (grp != 0) return;
+    const float v = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+    if (kind == 2) {                              // decoder: rows = dz component 4g + q (g = 0, q < 3)
+        const int t = k / 4, c3 = 4 * g + (k & 3);
+        if (c3 >= 3) return;
+        float* dWc = wg + WgLayout::dWc + c3 * 39;
+        float* dWv = wg + WgLayout::dWv + c3 * 27;
+        if (t == 0) dWc[6 + jl] = v;
+        else if (t == 1) dWc[22 + jl] = v;
+        else if (t == 2) { if (jl < 6) dWc[jl] = v; else if (jl == 6) dWc[38] = v; }
+        else if (t == 3) dWv[jl] = v;
+        else if (16 + jl < kView) dWv[16 + jl] = v;
+        return;
+    }
+    const bool GEO = kind == 1;
+    float* dW0 = wg + (GEO ? WgLayout::dG0 : WgLayout::dW0);
+    float* dW1 = wg + (GEO ? WgLayout::dG1 : WgLayout::dW1);
+    if (k < 48) {                                 // dW0'[16m + 4g + q][k' = 16mk + jl] -> the reference's column order
+        const int m = k / 12, mk = (k / 4) % 3, q = k & 3;
+        const int kp = 16 * mk + jl;
+        if (kp < 36) dW0[(16 * m + 4 * g + q) * 36 + (kp < 32 ? 3 + kp : (kp < 35 ? kp - 32 : 35))] = v;
+    } else if (k < 64) {                          // dW1[1 + 4g + q][16m + jl]
+        const int m = (k - 48) / 4, q = k & 3;
+        dW1[(1 + 4 * g + q) * 65 + 16 * m + jl] = v;
+    } else if (!GEO && k < 80) {                  // dW1[0][16m + 4g + q] (both row-0 terms; already summed over jl)
+        const int m = (k - 64) / 4, q = k & 3;
+        if (jl == 0) dW1[16 * m + 4 * g + q] = v;
+    } else {                                      // db1
+        const int t = k - (GEO ? 64 : 80);
+        const int o = GEO ? 1 + 4 * t + g : 4 * t + g;
+        if (jl == 0 && o < kOut) dW1[o * 65 + 64] = v;
+    }
+}
+
+}  // namespace
+
+int64_t ls2fm_wgrad_mlp_part_floats(int dual) {
+    return (int64_t)kWgradMlpBlocks * 64 * (kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec);
+}
+
+// enqueue every weight-gradient kernel of the backward (+ the reduction of their partials) on `s`
+int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s) {
+    const int n_tiles = (int)((w.p + 15) / 16);
+    int blocks = (n_tiles + kWmWaves - 1) / kWmWaves;
+    if (blocks > kWgradMlpBlocks) blocks = kWgradMlpBlocks;
+    const int dec_blocks = blocks;
+    float* part1 = ws + w.mpart;
+    float* part2 = part1 + (int64_t)kWgradMlpBlocks * 64 * kRegsSdf;
+    float* part3 = part2 + (int64_t)kWgradMlpBlocks * 64 * (dual ? kRegsGeo : 0);
+    wgrad_mlp_kernel<false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles);
+    if (dual) wgrad_mlp_kernel<true><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles);
+    wgrad_dec_kernel<<<dec_blocks, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3);
+    wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(part1, part2, part3, blocks,
+                                                                                             dec_blocks, dual, ws + w.wg);
+    return LS2FM_OK;
+}
