@@ -13,7 +13,7 @@
 //       4-byte item in the list of the slab it falls into: LDS histogram + one global reservation per (workgroup, slab).
 //   slab_accumulate  (per grid)
 //       workgroup = (level, slab[, part]) OWNS 8192 entries x 2 features of the table gradient in LDS as 64-bit
-//       FIXED-POINT integers and walks only its own item list; an item = one 64-byte record gather + 4 unmasked
+//       FIXED-POINT integers and walks only its own item list; an item = a 16-byte per-level record + the point's L2-resident 32-byte record, then 4 unmasked
 //       ds_add_u64 (2 x-corners x 2 features; first-order trilinear weight and, for the SDF grid, the double-backward
 //       derivative weight in the same add).  The quantum is a per-level power of two from a bound on one contribution
 //       (per-ray maxima from shade_bwd) with head-room for the worst-case hit count, so float->fixed and the integer
@@ -208,18 +208,24 @@ __device__ __forceinline__ void add_pair(const LevelC& L, u64* acc, const Payloa
     }
 }
 
-// rec: SDF grid [level][point][16] = {x y z - | de0 de1 rr0 rr1 | gn0 gn1 gn2 - | pad}; second grid [level][point][8] = {x y z - | de0 de1 - -}
+// payload of one (level, point): per-point record rpt[point] = {x y z gn0 | gn1 gn2 - -} and the per-level record
+// rec[level][point] = {de0 de1 rr0 rr1} (SDF grid) / {de0 de1} (second grid)
 template <bool SECOND_ORDER>
-__device__ __forceinline__ Payload load_payload(const float* __restrict__ rec_l, int64_t i, float scale) {
+__device__ __forceinline__ Payload load_payload(const float* __restrict__ rec_l, const float* __restrict__ rpt, int64_t i,
+                                                float scale) {
     Payload pl;
-    const float4* r = reinterpret_cast<const float4*>(rec_l + i * (SECOND_ORDER ? 16 : 8));
-    const float4 a = r[0], b = r[1];
+    const float4 a = reinterpret_cast<const float4*>(rpt)[2 * i];
     pl.x[0] = a.x; pl.x[1] = a.y; pl.x[2] = a.z;
-    pl.d0 = b.x; pl.d1 = b.y; pl.r0 = b.z; pl.r1 = b.w;
     pl.qd[0] = pl.qd[1] = pl.qd[2] = 0.f;
+    pl.r0 = pl.r1 = 0.f;
     if (SECOND_ORDER) {
-        const float4 c = r[2];
-        pl.qd[0] = scale * c.x; pl.qd[1] = scale * c.y; pl.qd[2] = scale * c.z;
+        const float4 c = reinterpret_cast<const float4*>(rpt)[2 * i + 1];
+        const float4 b = reinterpret_cast<const float4*>(rec_l)[i];
+        pl.d0 = b.x; pl.d1 = b.y; pl.r0 = b.z; pl.r1 = b.w;
+        pl.qd[0] = scale * a.w; pl.qd[1] = scale * c.x; pl.qd[2] = scale * c.y;
+    } else {
+        const float2 b = reinterpret_cast<const float2*>(rec_l)[i];
+        pl.d0 = b.x; pl.d1 = b.y;
     }
     return pl;
 }
@@ -241,8 +247,8 @@ __device__ __forceinline__ void process_item(const LevelC& L, u64* acc, const Pa
 template <bool SECOND_ORDER>
 __global__ void __launch_bounds__(kAccThreads)
 slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int64_t p_pad, const float* __restrict__ rec,
-                       const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad, float* __restrict__ dtable) {
-    constexpr int REC = SECOND_ORDER ? 16 : 8;
+                       const float* __restrict__ rpt, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad, float* __restrict__ dtable) {
+    constexpr int REC = SECOND_ORDER ? 4 : 2;
     __shared__ u64 acc[2 * kSlabEntries];
     __shared__ float s_bound[kAccThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -294,9 +300,9 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int64_t p_pad, co
             const int j2 = j + kAccThreads;
             const uint32_t it0 = bm.items[st + j];
             const uint32_t it1 = j2 < hi ? bm.items[st + j2] : 0u;
-            const Payload p0 = load_payload<SECOND_ORDER>(rec_l, it0 >> 3, L.scale);
+            const Payload p0 = load_payload<SECOND_ORDER>(rec_l, rpt, it0 >> 3, L.scale);
             Payload p1 = p0;
-            if (j2 < hi) p1 = load_payload<SECOND_ORDER>(rec_l, it1 >> 3, L.scale);
+            if (j2 < hi) p1 = load_payload<SECOND_ORDER>(rec_l, rpt, it1 >> 3, L.scale);
             process_item<SECOND_ORDER>(L, acc, p0, which == 0 ? (it0 & 7u) : 4u);
             if (j2 < hi) process_item<SECOND_ORDER>(L, acc, p1, which == 0 ? (it1 & 7u) : 4u);
         }
@@ -347,7 +353,7 @@ int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, in
 // dtable is OVERWRITTEN over the whole grid.  rec: per-(level, point) payload records (see load_payload);
 // ray_bound: [level][r_pad] per-ray bounds of a single contribution.
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, int64_t p_pad, const float* rec,
-                                 bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
+                                 const float* rpt, bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
                                  hipStream_t stream) {
     const BinMeta bm = make_bin_meta(bins_ws);
     SlabPlan plan{};
@@ -383,8 +389,8 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     }
     const LevelSet lv = make_level_set(grid);
     if (second_order)
-        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, p_pad, rec, ray_bound, n_rays, r_pad, dtable);
+        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, p_pad, rec, rpt, ray_bound, n_rays, r_pad, dtable);
     else
-        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, p_pad, rec, ray_bound, n_rays, r_pad, dtable);
+        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, p_pad, rec, rpt, ray_bound, n_rays, r_pad, dtable);
     return ls2fm_launch_status();
 }

@@ -146,7 +146,7 @@ int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, in
                            hipStream_t stream);
 size_t ls2fm_bin_counts_bytes();
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, int64_t p_pad, const float* rec,
-                                 bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
+                                 const float* rpt, bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
                                  hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
@@ -214,13 +214,13 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (forked && hipStreamWaitEvent(s, sc.mid, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;         // item lists ready
     {
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
-        int st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, P, ws + w.rec1, true, ws + w.smax, n_rays,
+        int st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, P, ws + w.rec1, ws + w.rpt, true, ws + w.smax, n_rays,
                                               grads->sdf_table, s);
         ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
         if (st != LS2FM_OK) return st;
         if (dual) {
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
-            st = ls2fm_launch_slab_accumulate(rad_grid, ws + w.bins, w.p, P, ws + w.rec2, false, ws + w.smax + 16 * w.r_pad,
+            st = ls2fm_launch_slab_accumulate(rad_grid, ws + w.bins, w.p, P, ws + w.rec2, ws + w.rpt, false, ws + w.smax + 16 * w.r_pad,
                                               n_rays, grads->rad_table, s);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
             if (st != LS2FM_OK) return st;

@@ -211,7 +211,7 @@ struct WsLayout {
     // forward -> backward
     int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4, keys;
     // backward scratch
-    int64_t rec1, rec2, bins, v, p3, gf, dz, gf2, dzr, renc, mpart, wg, dbeta, smax;
+    int64_t rec1, rec2, rpt, bins, v, p3, gf, dz, gf2, dzr, renc, mpart, wg, dbeta, smax;
     int64_t total;
 };
 
@@ -252,8 +252,11 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.ones = take(P);
     w.keys = take((int64_t)l1 * P); // uint32 per (level, point): slab-test key for the table-gradient scatter
     w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
-    w.rec1 = take(16 * (int64_t)l1 * P);         // [level][point]{x y z - | de0 de1 rr0 rr1 | gn0 gn1 gn2 - | pad}: 64-byte scatter payload (SDF grid)
-    w.rec2 = take(dual ? 8 * (int64_t)l2 * P : 0); // [level][point]{x y z - | de0 de1 - -}: 32-byte scatter payload (second grid)
+    // scatter payload: per point {x y z | gn0 gn1 gn2 | - -} (32 B, 4 MB per 131072 points: L2-resident across all the
+    // levels' slab workgroups) + per (level, point) {de0 de1 rr0 rr1} (SDF grid, 16 B) / {de0 de1} (second grid, 8 B)
+    w.rpt = take(8 * P);
+    w.rec1 = take(4 * (int64_t)l1 * P);
+    w.rec2 = take(dual ? 2 * (int64_t)l2 * P : 0);
     // per-sample upstream vectors shade_bwd hands to the weight-gradient kernels (SoA)
     w.v = take(35 * P);
     w.p3 = take(3 * P);

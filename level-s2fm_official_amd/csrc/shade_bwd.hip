@@ -254,6 +254,15 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 }
             }
 
+        // per-point part of the scatter payload (position + the normal's upstream), shared by every level and both grids
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+            if (live_c[cc] && g == 0) {
+                float4* dst = reinterpret_cast<float4*>(out + w.rpt + (int64_t)is[cc] * 8);
+                dst[0] = make_float4(xg[cc][0], xg[cc][1], xg[cc][2], gns[cc][0]);
+                dst[1] = make_float4(gns[cc][1], gns[cc][2], 0.f, 0.f);
+            }
+
         // ---- SDF field
         f32x4 de[2][NC], rr[2][NC];
 #pragma unroll
@@ -304,7 +313,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     }
                 }
         }
-        // scatter payload of the SDF grid: one 64-byte record per (level, point); this lane owns rows 16 mk + 4 g + {0..3}
+        // scatter payload of the SDF grid: 16 bytes per (level, point); this lane owns rows 16 mk + 4 g + {0..3}
         // = levels 8 mk + 2 g and 8 mk + 2 g + 1.  Per-level bound of a single contribution |w de + D rr| <=
         // |de| + scale |g_n|_1 |rr| fixes the fixed-point quantum of the slab accumulators.
 #pragma unroll
@@ -317,10 +326,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     if (2 * l < ch1 && live_c[cc]) {
                         const float d0 = de[mk][cc][2 * hv], d1 = de[mk][cc][2 * hv + 1];
                         const float r0 = rr[mk][cc][2 * hv], r1 = rr[mk][cc][2 * hv + 1];
-                        float4* dst = reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + is[cc]) * 16);
-                        dst[0] = make_float4(xg[cc][0], xg[cc][1], xg[cc][2], 0.f);
-                        dst[1] = make_float4(d0, d1, r0, r1);
-                        dst[2] = make_float4(gns[cc][0], gns[cc][1], gns[cc][2], 0.f);
+                        *reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + is[cc]) * 4) = make_float4(d0, d1, r0, r1);
                         const float b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[l] * g1[cc] * fmaxf(fabsf(r0), fabsf(r1));
                         atomicMax(&s_bound[l], __float_as_int(b));
                     }
@@ -404,9 +410,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         const int l = 8 * mk + 2 * g + hv;
                         if (2 * l < ch2 && live_c[cc]) {
                             const float d0 = de2[mk][cc][2 * hv], d1 = de2[mk][cc][2 * hv + 1];
-                            float4* dst = reinterpret_cast<float4*>(out + w.rec2 + ((int64_t)l * P + is[cc]) * 8);
-                            dst[0] = make_float4(xg[cc][0], xg[cc][1], xg[cc][2], 0.f);
-                            dst[1] = make_float4(d0, d1, 0.f, 0.f);
+                            *reinterpret_cast<float2*>(out + w.rec2 + ((int64_t)l * P + is[cc]) * 2) = make_float2(d0, d1);
                             atomicMax(&s_bound[16 + l], __float_as_int(fmaxf(fabsf(d0), fabsf(d1))));
                         }
                     }
