@@ -55,16 +55,22 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
     __shared__ float s_row[64][68];       // effective-weight gradients of the layer being processed
     const int tid = threadIdx.x;
 
-    // ---- geometry MLPs
-    for (int which = 0; which < (dual ? 2 : 1); ++which) {
+    // one workgroup per layer (7 independent tasks; a single workgroup doing all of them was a 58 us latency chain):
+    // 0/1 SDF MLP layers, 2/3 second field's layers, 4..6 radiance layers (each re-derives the small shared terms)
+    const int task = blockIdx.x;
+    if (task < 4) {
+        const int which = task >> 1;
+        if (which && !dual) return;
         const float* dW0 = wg + (which ? WgLayout::dG0 : WgLayout::dW0);
         const float* dW1 = wg + (which ? WgLayout::dG1 : WgLayout::dW1);
         const ls2fm_linear* lin = which ? P.geo_mlp : P.sdf_mlp;
         const ls2fm_linear_grad* gl = which ? G.geo_mlp : G.sdf_mlp;
         const int ind = which ? in_dim2 : in_dim;
-        weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, dW0, 36, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid);
-        if (tid < kHidden) gl[0].bias[tid] = dW0[tid * 36 + 35];
-        __syncthreads();
+        if ((task & 1) == 0) {
+            weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, dW0, 36, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid);
+            if (tid < kHidden) gl[0].bias[tid] = dW0[tid * 36 + 35];
+            return;
+        }
         for (int idx = tid; idx < kOut * kHidden; idx += 256) {
             const int o = idx / kHidden, j = idx % kHidden;
             s_row[o][j] = dW1[o * 65 + j] + ((which == 0 && o == 0) ? wg[WgLayout::dW1r0 + j] : 0.f);
@@ -73,7 +79,7 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
         weight_norm_bwd_rows(lin[1].weight_v, lin[1].weight_g, &s_row[0][0], 68, kOut, kHidden, gl[1].weight_v,
                              gl[1].weight_g, tid);
         if (tid < kOut) gl[1].bias[tid] = dW1[tid * 65 + 64];
-        __syncthreads();
+        return;
     }
 
     // ---- radiance decoder: expand dWc (3 x rad_in) and back through Wc = R2 R1 R0, bc = T1 b0 + R2 b1 + b2
@@ -95,36 +101,43 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
         for (int k = 0; k < rad_in; ++k) acc = fmaf(s_dwc[c][k], pk->r0[j][k], acc);
         s_dt1[c][j] = acc;
     }
-    for (int idx = tid; idx < 64 * 68; idx += 256) {      // dR0 = T1^T dWc
-        const int j = idx / 68, k = idx % 68;
-        float acc = 0.f;
-        for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][j], s_dwc[c][k], acc);
-        s_row[j][k] = acc;
+    if (task == 4) {
+        for (int idx = tid; idx < 64 * 68; idx += 256) {      // dR0 = T1^T dWc
+            const int j = idx / 68, k = idx % 68;
+            float acc = 0.f;
+            for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][j], s_dwc[c][k], acc);
+            s_row[j][k] = acc;
+        }
+        __syncthreads();
+        weight_norm_bwd_rows(P.rad_mlp[0].weight_v, P.rad_mlp[0].weight_g, &s_row[0][0], 68, 64, rad_in,
+                             G.rad_mlp[0].weight_v, G.rad_mlp[0].weight_g, tid);
+        if (tid < 64) {
+            float acc = 0.f;
+            for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][tid], s_dbc[c], acc);
+            G.rad_mlp[0].bias[tid] = acc;
+        }
+        // beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed
+        if (tid == 0) G.beta[0] = (float)(*reinterpret_cast<const double*>(dbeta) * (double)pk->beta * (double)P.beta_speed);
+        return;
     }
-    __syncthreads();
-    weight_norm_bwd_rows(P.rad_mlp[0].weight_v, P.rad_mlp[0].weight_g, &s_row[0][0], 68, 64, rad_in,
-                         G.rad_mlp[0].weight_v, G.rad_mlp[0].weight_g, tid);
-    if (tid < 64) {
-        float acc = 0.f;
-        for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][tid], s_dbc[c], acc);
-        G.rad_mlp[0].bias[tid] = acc;
+    __syncthreads();          // s_dt1 complete
+    if (task == 5) {
+        for (int idx = tid; idx < 64 * 64; idx += 256) {      // dR1 = R2^T dT1
+            const int m = idx / 64, j = idx % 64;
+            float acc = 0.f;
+            for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][m], s_dt1[c][j], acc);
+            s_row[m][j] = acc;
+        }
+        __syncthreads();
+        weight_norm_bwd_rows(P.rad_mlp[1].weight_v, P.rad_mlp[1].weight_g, &s_row[0][0], 68, 64, 64,
+                             G.rad_mlp[1].weight_v, G.rad_mlp[1].weight_g, tid);
+        if (tid < 64) {
+            float acc = 0.f;
+            for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][tid], s_dbc[c], acc);
+            G.rad_mlp[1].bias[tid] = acc;
+        }
+        return;
     }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * 64; idx += 256) {      // dR1 = R2^T dT1
-        const int m = idx / 64, j = idx % 64;
-        float acc = 0.f;
-        for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][m], s_dt1[c][j], acc);
-        s_row[m][j] = acc;
-    }
-    __syncthreads();
-    weight_norm_bwd_rows(P.rad_mlp[1].weight_v, P.rad_mlp[1].weight_g, &s_row[0][0], 68, 64, 64,
-                         G.rad_mlp[1].weight_v, G.rad_mlp[1].weight_g, tid);
-    if (tid < 64) {
-        float acc = 0.f;
-        for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][tid], s_dbc[c], acc);
-        G.rad_mlp[1].bias[tid] = acc;
-    }
-    __syncthreads();
     for (int idx = tid; idx < 3 * 64; idx += 256) {       // dR2 = dT1 R1^T + dbc b1^T
         const int c = idx / 64, m = idx % 64;
         float acc = s_dbc[c] * P.rad_mlp[1].bias[m];
@@ -135,8 +148,6 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
     weight_norm_bwd_rows(P.rad_mlp[2].weight_v, P.rad_mlp[2].weight_g, &s_row[0][0], 68, 3, 64,
                          G.rad_mlp[2].weight_v, G.rad_mlp[2].weight_g, tid);
     if (tid < 3) G.rad_mlp[2].bias[tid] = s_dbc[tid];
-    // ---- beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed
-    if (tid == 0) G.beta[0] = (float)(*reinterpret_cast<const double*>(dbeta) * (double)pk->beta * (double)P.beta_speed);
 }
 
 }  // namespace
@@ -205,7 +216,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
     ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, gs);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
-    finalize_kernel<<<1, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
+    finalize_kernel<<<7, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
                                        ws + w.dbeta);
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;

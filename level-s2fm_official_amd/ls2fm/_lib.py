@@ -18,7 +18,7 @@ FEAT = 16
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libls2fm_hip.so")
+LIB_PATH = os.environ.get("LS2FM_LIB") or os.path.join(_HERE, "libls2fm_hip.so")
 
 
 class GridDesc(Structure):

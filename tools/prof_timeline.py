@@ -12,7 +12,8 @@ cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
 q = f"select d.start, d.end, d.queue_id, d.stream_id, s.kernel_name from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"
 rows = list(cur.execute(q))
 marks = [i for i, r in enumerate(rows) if 'prep_weights' in r[4]]
-a, b = marks[-3], marks[-2]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 3
+a, b = marks[k], marks[k + 1]
 t0 = rows[a][0]
 for st, en, qid, sid, name in rows[a:b]:
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
