@@ -60,11 +60,24 @@ def loss_head(ret):
     return 1e3 * rgb + 1e2 * eik + dep
 
 
+def host_threads(cap=32):
+    """cores this process may actually run on (affinity mask and cgroup quota, not the machine's core count: sizing the
+    OpenMP pool by os.cpu_count() inside a CPU-limited container oversubscribes spinning threads)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(dataset, dual, n_samples, budget_s=20.0):
     """The CPU oracle (a torch restatement of the reference's op sequence, pinned against the reference's golden
     vectors) timed on the host cores of this box on a bounded sample of the same workload."""
     from oracle import fields as OF
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     torch.set_num_threads(threads)
     cfg = OF.dataset_config(dataset, dual_field=dual, sample_intvs=n_samples)
     gen = torch.Generator().manual_seed(0)
@@ -105,12 +118,16 @@ def main():
     ap.add_argument("--dataset", default="ETH3D")
     ap.add_argument("--single-field", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
     ap.add_argument("--graph", action="store_true",
                     help="time hipGraph replays of the whole step (ls2fm.graph.CapturedStep) instead of eager launches; "
                          "measured slower than eager on ROCm 7.2 for this step (graph branches serialise), so off by default")
     ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.dataset, not args.single_field, args.samples)))
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,7 +178,7 @@ def main():
         loss.backward()
         return loss
 
-    captured = CapturedStep(render_step) if args.graph else None
+    captured = CapturedStep(render_step, params) if args.graph else None
 
     def step(eager=False):
         if captured is None or eager:
@@ -208,6 +225,15 @@ def main():
         from ls2fm.profile import dominant_kernel_roofline
         roofline = dominant_kernel_roofline(lib, n_points=args.rays * args.samples, dual=dual,
                                             hbm_peak_gbs=HBM_PEAK_GBS, f32_peak_tflops=F32_PEAK_TFLOPS)
+        # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter
+        # summary of this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is quoted
+        # when the workload is the default one
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
+            rec = json.load(open(pmc)).get(roofline["kernel"])
+            if rec:
+                roofline["traffic"] = rec["fetch"] + rec["write"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; raw)"
     out = {
         "metric": "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -222,10 +248,19 @@ def main():
         "roofline": roofline,
     }
     if rank == 0:
+        out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.dataset, dual, args.samples)
-        else:
-            out["cpu_baseline"] = None
+            # the CPU leg runs in a fresh process (clean OpenMP state, no GPU context) under a hard wall-clock bound, so a
+            # misbehaving host can never hang the benchmark
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--dataset", args.dataset,
+                   "--samples", str(args.samples)] + (["--single-field"] if args.single_field else [])
+            try:
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+                out["cpu_baseline"] = json.loads(res.stdout.strip().splitlines()[-1])
+            except Exception as e:                                   # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": host_threads(), "kind": "port",
+                                       "sample": f"CPU leg did not finish within 150 s ({type(e).__name__})"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

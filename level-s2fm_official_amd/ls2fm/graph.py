@@ -6,7 +6,7 @@ Python / launch overhead between the ~15 kernels of the fused path is of the sam
 step once into a hipGraph (the library's internal fork/join onto its side stream is captured as graph branches) and
 replays it with one launch.
 
-    step = CapturedStep(lambda: loss_fn(renderer.forward(opt, center, ray, sdf, rad)).backward() ...)
+    step = CapturedStep(lambda: loss_fn(renderer.forward(opt, center, ray, sdf, rad)).backward() ..., params=all_parameters)
     for it in range(n): new rays -> center.copy_(...), ray.copy_(...); step.replay(); optimizer.step()
 
 Contract (the usual one for graphs): the closure reads its inputs from tensors that keep their address (update them in
@@ -19,7 +19,7 @@ import torch
 
 
 class CapturedStep:
-    def __init__(self, fn, warmup: int = 3):
+    def __init__(self, fn, params=None, warmup: int = 3):
         if not torch.cuda.is_available():
             raise RuntimeError("ls2fm.graph.CapturedStep needs the GPU (no CPU path)")
         self.fn = fn
@@ -33,7 +33,12 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()
+        # the gradients the capture produced live in the graph's memory pool; `params` lets replay() re-bind them after
+        # eager code replaced p.grad in between
+        self._grads = [(p, p.grad) for p in params] if params is not None else []
 
     def replay(self):
         self.graph.replay()
+        for p, g in self._grads:
+            p.grad = g
         return self.outputs
