@@ -171,7 +171,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;
     if (field->dual_field && !same_grid_geometry(sdf_grid, rad_grid)) return LS2FM_ERR_UNSUPPORTED;
     if (field->n_samples < 1 || field->n_samples > 512) return LS2FM_ERR_UNSUPPORTED;
-    if (d_center || d_ray) return LS2FM_ERR_UNSUPPORTED;   // pose gradients: general (composed) form
+    LS2FM_CHECK_ARG((d_center == nullptr) == (d_ray == nullptr));     // pose gradients: both or neither
+    const int want_pose = d_center != nullptr;
     if (n_rays == 0) return LS2FM_OK;
     LS2FM_CHECK_ARG(center && ray && grads->sdf_table && grads->beta && (!field->dual_field || grads->rad_table));
     if (!workspace) return LS2FM_ERR_WORKSPACE;
@@ -206,8 +207,13 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
 
     const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, s);
+    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
+    if (want_pose) {
+        ls2fm_prof_begin(LS2FM_PROF_POSE, s);
+        ls2fm_launch_pose_grad(fc, sdf_grid, rad_grid, dual, w, pk, params, center, ray, n_rays, ws, d_center, d_ray, s);
+        ls2fm_prof_end(LS2FM_PROF_POSE, s);
+    }
 
     // fork 2: weight-gradient GEMM -> reduce -> finalize run on the side stream, concurrently with the table scatters
     if (forked && (hipEventRecord(sc.fork, s) != hipSuccess || hipStreamWaitEvent(sc.side, sc.fork, 0) != hipSuccess))

@@ -14,7 +14,7 @@ enum ls2fm_prof_id {
     LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
     LS2FM_PROF_WGRAD, LS2FM_PROF_WGRAD_REDUCE, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
     LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_BIN, LS2FM_PROF_LOSS_FWD,
-    LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_COUNT
+    LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_POSE, LS2FM_PROF_COUNT
 };
 bool ls2fm_prof_enabled();
 void ls2fm_prof_begin(int id, hipStream_t stream);      // bracket one kernel launch on the stream it is enqueued on
@@ -50,6 +50,7 @@ struct MfmaW {                 // sdf .. w10 is one contiguous block (staged int
     MfmaField geo;
     float b1a[2][4][64];       // b1[1 + 4g + r]                                                       [field][r][lane]
     float b10[4];              // b1[0] per field
+    float w0tx_geo[4][4][64];  // second field's W0'[16m + 4g + r][k' = 32 + jl] (p / rescale rows; pose gradients) [m][r][lane]
 };
 // backward: per-field contiguous blocks (staged into LDS by shade_bwd)
 struct MfmaBwdSdf {
@@ -211,7 +212,7 @@ struct WsLayout {
     // forward -> backward
     int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4, keys;
     // backward scratch
-    int64_t rec1, rec2, rpt, bins, v, p3, gf, dz, gf2, dzr, renc, mpart, wg, dbeta, smax;
+    int64_t rec1, rec2, rpt, bins, v, p3, gf, dz, gf2, dzr, renc, dexyz, dlen, mpart, wg, dbeta, smax;
     int64_t total;
 };
 
@@ -263,6 +264,8 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.gf = take(17 * P);
     w.dz = take(3 * P);
     w.gf2 = take(dual ? 17 * P : 0);
+    w.dexyz = take(6 * P);       // pose gradients: d L / d (p / rescale) of the SDF field (3) and of the second field (3)
+    w.dlen = take(w.r_pad);      // pose gradients: d L / d |ray| through the interval lengths of the composite
     w.dzr = take(3 * w.r_pad);
     w.renc = take(27 * w.r_pad);
     w.mpart = take(ls2fm_wgrad_mlp_part_floats(dual));
@@ -288,7 +291,12 @@ struct Upstream {                  // dL/d(outputs of render_fwd); any pointer m
 // shade_bwd.hip
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
-                           const Upstream& up, hipStream_t s);
+                           const Upstream& up, int want_pose, hipStream_t s);
+
+// pose_grad.hip
+int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, const ls2fm_grid_desc* rad_grid, int dual,
+                           const WsLayout& w, const Packed* pk, const ls2fm_params* params, const float* center,
+                           const float* ray, int64_t n_rays, const float* ws, float* d_center, float* d_ray, hipStream_t s);
 
 // wgrad_mlp.hip
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,

@@ -93,6 +93,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             const int m = idx / 256, r = (idx / 64) & 3, ln = idx & 63;
             const int hid = 16 * m + 4 * (ln >> 4) + r;
             (which ? mw.geo : mw.sdf).w1a[m][r][ln] = L1.v[(1 + (ln & 15)) * kHidden + hid] * s1[1 + (ln & 15)];
+            if (which == 1) mw.w0tx_geo[m][r][ln] = (ln & 15) < 3 ? w0p(hid, 32 + (ln & 15)) : 0.f;
             if (which == 0) {
                 mw.w10[m][r][ln] = L1.v[hid] * s1[0];
                 for (int mk = 0; mk < 3; ++mk) {

@@ -29,7 +29,7 @@ template <bool DUAL, int MAXT>
 __global__ void __launch_bounds__(MAXT, 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
-                 Upstream up, float* __restrict__ out) {
+                 Upstream up, float* __restrict__ out, int want_pose) {
     __shared__ float s_part[MAXT / 64][8];
     __shared__ double s_db[MAXT / 64];
     __shared__ int s_bound[32];                  // per-level max of a single scatter contribution (bits of a float >= 0)
@@ -119,6 +119,10 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         const float d_tau = interval ? (v_term - b_term) * trans * ex - suffix : 0.f;
         const float g_sigma = d_tau * delta;
         const float rest = 1.0f - opacity;
+        {   // d L / d |ray| : delta = (t_next - t) |ray| (Renderer.py:36-38); only consumed by the pose gradients
+            const float s = wave_sum(d_tau * sigma * (t_next - t));
+            if (lane == 0) s_part[wave][3] = s;
+        }
         // per-sample upstream of colour, normal, sdf
         float gc[3], gn[3];
 #pragma unroll
@@ -173,6 +177,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             atomicAdd(reinterpret_cast<double*>(out + w.dbeta), s);
         }
         if (n < kView) out[w.renc + n * w.r_pad + r] = view_component(gm.d, n);
+        if (n == 4 && want_pose) {
+            float s = 0.f;
+            for (int q = 0; q < n_waves; ++q) s += s_part[q][3];
+            out[w.dlen + r] = s;
+        }
     }
 
     // =========================================================================== 2. MFMA lanes
@@ -264,7 +273,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             }
 
         // ---- SDF field
-        f32x4 de[2][NC], rr[2][NC];
+        f32x4 de[2][NC], rr[2][NC], dex[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) dex[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
@@ -311,6 +322,22 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         de[mk][cc] = mfma4(at, da[cc][q], de[mk][cc]);
                         rr[mk][cc] = mfma4(at, gj[cc][q], rr[mk][cc]);
                     }
+                }
+            if (want_pose) {          // rows 32..34 of W0'^T DA: d L / d (p / rescale) through the MLP's position inputs
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float at = pk->mw.w0ta[2][m][q][lane];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) dex[cc] = mfma4(at, da[cc][q], dex[cc]);
+                }
+            }
+        }
+        if (want_pose && g == 0) {
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+                if (live_c[cc]) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) (out + w.dexyz)[(uint32_t)a * P32 + is[cc]] = dex[cc][a];
                 }
         }
         // scatter payload of the SDF grid: 16 bytes per (level, point); this lane owns rows 16 mk + 4 g + {0..3}
@@ -362,6 +389,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             __syncthreads();      // second field's weights staged
             f32x4 de2[2][NC];
 #pragma unroll
+            for (int cc = 0; cc < NC; ++cc) dex[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
             for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) de2[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -400,6 +429,22 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 #pragma unroll
                         for (int cc = 0; cc < NC; ++cc) de2[mk][cc] = mfma4(at, da[cc][q], de2[mk][cc]);
                     }
+                if (want_pose) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float at = pk->mw.w0tx_geo[m][q][lane];
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) dex[cc] = mfma4(at, da[cc][q], dex[cc]);
+                    }
+                }
+            }
+            if (want_pose && g == 0) {
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc)
+                    if (live_c[cc]) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) (out + w.dexyz)[(uint32_t)(3 + a) * P32 + is[cc]] = dex[cc][a];
+                    }
             }
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc)
@@ -432,10 +477,10 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
-                           const Upstream& up, hipStream_t s) {
+                           const Upstream& up, int want_pose, hipStream_t s) {
     const int threads = (fc.n_samples + 63) / 64 * 64;
 #define LS2FM_SHADE_BWD(DUAL, MAXT) \
-    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws)
+    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, want_pose)
     if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD

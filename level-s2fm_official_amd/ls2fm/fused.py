@@ -4,8 +4,8 @@ modules directly (weight_v / weight_g / bias, the flat hash tables, beta) and re
 very parametrisation, so nothing but this one node sits between the optimizer and the HIP code.
 
 Gating: the fused kernels implement the reference's network sizes (hidden 64, 16 features, 2 features per
-level, <= 16 levels, affine radiance decoder) with uniform sampling and no background-sphere `min`.  Anything
-else -- and any call that needs gradients w.r.t. the camera rays -- is served by the general autograd
+level, <= 16 levels, affine radiance decoder) with uniform sampling and no background-sphere `min`, including the
+gradients w.r.t. the camera rays.  Anything else is served by the general autograd
 composition (HIP hash-grid op + torch dense layers), never by a CPU path.
 """
 from __future__ import annotations
@@ -109,9 +109,7 @@ def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
 def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
     if not (center.is_cuda and ray.is_cuda) or not _plan(renderer, opt, sdf_field, rad_field).ok:
         return False
-    if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad):
-        return False            # pose gradients: general form
-    return True
+    return True                 # pose gradients (center / ray requiring grad) are part of the fused backward
 
 
 _HAS_SDF_EVAL = True
@@ -234,6 +232,7 @@ class _Render(torch.autograd.Function):
         ctx.ws = ws
         ctx.n_rays = n_rays
         ctx.pstruct = pstruct
+        ctx.pose_shape = tuple(center.shape)
         ctx.save_for_backward(c, d, *ps)
         return rgb, sdfs, normals, depth, nmlp
 
@@ -261,11 +260,16 @@ class _Render(torch.autograd.Function):
                 at += p.numel()
         pstruct = ctx.pstruct
         gstruct = _params_struct(grads, dual, beta_speed, cls=_lib.ParamGrads)
+        want_pose = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d_center = torch.empty_like(c) if want_pose else None
+        d_ray = torch.empty_like(d) if want_pose else None
         check(lib.ls2fm_render_bwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), ctx.n_rays, ptr(d_rgb), ptr(d_sdfs),
-                                   ptr(d_normals), ptr(d_depth), ptr(d_nmlp), ctypes.byref(gstruct), None, None,
+                                   ptr(d_normals), ptr(d_depth), ptr(d_nmlp), ctypes.byref(gstruct), ptr(d_center), ptr(d_ray),
                                    ptr(ctx.ws), stream_ptr()), "ls2fm_render_bwd")
-        return (None, None, None, *grads)       # ctx.ws is kept: backward may run again (retain_graph)
+        if want_pose:
+            d_center, d_ray = d_center.view(ctx.pose_shape), d_ray.view(ctx.pose_shape)
+        return (d_center, d_ray, None, *grads)  # ctx.ws is kept: backward may run again (retain_graph)
 
 
 def render(renderer, opt, center, ray, sdf_field, rad_field):

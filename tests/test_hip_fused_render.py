@@ -27,8 +27,8 @@ BETA_TOL = 5e-4      # d/d beta is ONE scalar: a sum over every sample of terms 
 def test_fused_render_vs_reference_golden(case, manifest):
     g = load_golden(case)
     opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
-    center = torch.from_numpy(g["center"]).to(DEV)
-    ray = torch.from_numpy(g["ray"]).to(DEV)
+    center = torch.from_numpy(g["center"]).to(DEV).requires_grad_(True)       # pose gradients on: BA.py:153-154
+    ray = torch.from_numpy(g["ray"]).to(DEV).requires_grad_(True)
     took_fused = fused.can_render(ren, opt, center, ray, sdf, rad)
     assert took_fused == (case != "dtu_bgsdf")        # the background-sphere min() is served by the composed form
     ret = ren.forward(opt=opt, center=center, ray=ray, SDF_Field=sdf, Rad_Field=rad)
@@ -41,6 +41,30 @@ def test_fused_render_vs_reference_golden(case, manifest):
     for name, mod in (("sdf", sdf), ("rad", rad)):
         for k, v in named_grads(mod).items():
             assert rel_err(v, g[f"render_grad/{name}/{k}"]) < (BETA_TOL if k == "beta" else GTOL), (name, k)
+    # gradients w.r.t. the camera rays (the reference's own values)
+    assert rel_err(center.grad.cpu(), g["d_center"]) < GTOL
+    assert rel_err(ray.grad.cpu(), g["d_ray"]) < GTOL
+
+
+def test_fused_pose_gradients_equal_composed_at_full_grid():
+    """d L / d center, d L / d ray of the fused backward vs the general autograd composition (HIP hash-grid op with its
+    double backward + torch layers) on the full L16/T19 grids, dual field; parameter gradients unchanged by asking."""
+    opt = make_options("ETH3D", device=DEV, dual_field=True, sample_intvs=48)
+    sdf, rad, ren = _randomized(opt, 21)
+    center, ray = _rays(64, 5.0, 22)
+    tgt, nm = torch.rand(1, 64, 3, device=DEV), torch.tensor([0.2, -0.4, 0.3], device=DEV)
+    out = {}
+    for form in ("fused", "composed", "fused_nopose"):
+        c = center.clone().requires_grad_(form != "fused_nopose")
+        r = ray.clone().requires_grad_(form != "fused_nopose")
+        sdf.zero_grad(); rad.zero_grad()
+        fn = ren.forward_composed if form == "composed" else ren.forward
+        losses.render_loss(fn(opt, c, r, sdf, rad), tgt, nm).backward()
+        out[form] = (c.grad, r.grad, {**named_grads(sdf), **{"r." + k: v for k, v in named_grads(rad).items()}})
+    assert rel_err(out["fused"][0].cpu(), out["composed"][0].cpu()) < GTOL
+    assert rel_err(out["fused"][1].cpu(), out["composed"][1].cpu()) < GTOL
+    for k, v in out["fused"][2].items():
+        assert rel_err(v, out["fused_nopose"][2][k]) < 1e-6, k           # asking for pose gradients changes nothing else
 
 
 def _randomized(opt, seed):
