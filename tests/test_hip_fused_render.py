@@ -174,3 +174,31 @@ def test_fused_properties_at_baseline_size():
     for k in g1:
         assert rel_err(g2[k], 2.0 * g1[k]) < 1e-4, k           # atomics reorder the fp32 sums, nothing else
     assert g1["embed_fn.embedder_obj.params"].abs().max() > 0
+
+
+def test_fused_sharding_invariance_large_batch():
+    """4096 rays x 128 samples (512 k sample points, full-size dual grids): the gradients of a sum-type loss over the
+    whole batch equal the sum of the gradients over four 1024-ray shards -- the property the data-parallel path relies
+    on, at a size the composed form / the CPU oracle cannot reach in test time."""
+    opt = make_options("ETH3D", device=DEV, dual_field=True, sample_intvs=128)
+    sdf, rad, ren = _randomized(opt, 31)
+    center, ray = _rays(4096, 5.0, 32)
+    tgt = torch.rand(1, 4096, 3, device=DEV)
+
+    def loss_of(ret, sl):
+        return ((ret["rgb"] - tgt[:, sl]).abs().sum() + 0.1 * ((ret["normals"].norm(dim=-1) - 1.0) ** 2).sum()
+                + 0.01 * ret["depth_mlp"].sum() + 0.05 * (ret["sdfs_volume"] ** 2).sum())
+
+    sdf.zero_grad(); rad.zero_grad()
+    loss_of(ren.forward(opt, center, ray, sdf, rad), slice(None)).backward()
+    full = {**named_grads(sdf), **{"r." + k: v for k, v in named_grads(rad).items()}}
+    acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in full.items()}
+    for q in range(4):
+        sl = slice(1024 * q, 1024 * (q + 1))
+        sdf.zero_grad(); rad.zero_grad()
+        loss_of(ren.forward(opt, center[:, sl].contiguous(), ray[:, sl].contiguous(), sdf, rad), sl).backward()
+        for k, v in {**named_grads(sdf), **{"r." + k: v for k, v in named_grads(rad).items()}}.items():
+            acc[k] += v.double()
+    for k in full:
+        assert torch.isfinite(full[k]).all(), k
+        assert rel_err(full[k], acc[k]) < (1e-4 if k == "beta" else 2e-5), k
