@@ -45,6 +45,18 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
     }
 
 
+def _fractions(times, work, hbm_peak_gbs, f32_peak_tflops):
+    """algorithmic bytes (or FLOPs) / measured duration / peak, for every kernel with an algorithmic figure"""
+    out = {}
+    for name, (avg_us, _, _) in times.items():
+        if name not in work:
+            continue
+        bound, amount = work[name]
+        rate = amount / (avg_us * 1e-6)
+        out[name] = {"bound": bound, "frac": round(rate / 1e9 / hbm_peak_gbs if bound == "hbm" else rate / 1e12 / f32_peak_tflops, 4)}
+    return out
+
+
 def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float, f32_peak_tflops: float):
     """roofline object of bench.py's JSON line for the kernel with the largest share of device time"""
     times = kernel_times(lib)
@@ -64,4 +76,5 @@ def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float
         "traffic": None, "avg_launch_us": avg_us, "launches": launches, "share_of_device_time": total_ms / grand,
         "algorithmic_per_launch": amount,
         "all_kernels_avg_us": {k: round(v[0], 2) for k, v in sorted(times.items(), key=lambda kv: -kv[1][2])},
+        "all_kernels_frac_of_peak": _fractions(times, work, hbm_peak_gbs, f32_peak_tflops),
     }
