@@ -239,6 +239,18 @@ int ls2fm_loss_head_bwd(const float* rgb, const float* rgb_gt, const float* norm
                         float* d_rgb, float* d_normals, float* d_depth, float* d_depth_ref, const double* sums, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused Adam step over a list of fp32 tensors, one launch, one pass over memory.
+ * Replaces: torch.optim.Adam.step() of the stage loops (Initialization.py:149-179, BA.py:117-182; amsgrad = False,
+ * maximize = False), operation by operation:  g' = g + wd p;  m = lerp(m, g', 1 - beta1);
+ * v = v beta2 + (1 - beta2) g' g';  p -= (lr / (1 - beta1^step)) m / (sqrt(v) / sqrt(1 - beta2^step) + eps).
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers; numel: HOST array; step >= 1 is the
+ * count AFTER this update (torch increments before use).  Updates params, exp_avg, exp_avg_sq in place.
+ */
+int ls2fm_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the
  * call's own stream; ls2fm_profile_get() synchronises those events and returns, per internal kernel, the

@@ -1,0 +1,56 @@
+"""Fused Adam for the path's parameters.
+
+The reference's stage loops (Initialization.py:149-179, BA.py:117-182, rendering_refine.py:78-96) drive
+``torch.optim.Adam`` + ``ExponentialLR`` over two 12 M-entry hash tables and 26 small tensors.  ``FusedAdam`` is a
+``torch.optim.Optimizer`` with Adam's state layout (``step, exp_avg, exp_avg_sq``) and hyper-parameters, so LR schedulers
+and ``state_dict`` round trips work unchanged; ``step()`` is ONE kernel launch and one pass over memory per parameter
+group (csrc/adam.hip) instead of torch's multi-kernel foreach sequence.  fp32 GPU tensors only; no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_device(p, p.grad)
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
+                    raise RuntimeError("ls2fm.optim.FusedAdam: contiguous fp32 dense parameters and gradients only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+                by_step.setdefault(st["step"], []).append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st))
+            for step, items in by_step.items():
+                n = len(items)
+                ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+                numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
+                _lib.check(lib.ls2fm_adam_step(n, ptrs([p for p, _, _ in items]), ptrs([g for _, g, _ in items]),
+                                               ptrs([s["exp_avg"] for _, _, s in items]),
+                                               ptrs([s["exp_avg_sq"] for _, _, s in items]), numel, float(group["lr"]),
+                                               float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                                               float(group["weight_decay"]), int(step), _lib.stream_ptr()),
+                           "ls2fm_adam_step")
+        return loss
