@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--single-field", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group, gradient all-reduce, barriers) even with one process")
     ap.add_argument("--graph", action="store_true",
                     help="time hipGraph replays of the whole step (ls2fm.graph.CapturedStep) instead of eager launches; "
                          "measured slower than eager on ROCm 7.2 for this step (graph branches serialise), so off by default")
@@ -136,9 +138,13 @@ def main():
                          "`cpu_baseline` leg of the GPU run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from ls2fm import _lib, fused
@@ -158,7 +164,7 @@ def main():
     center, ray = synthetic_rays(args.rays, s, dev, seed=rank)      # each rank: its own view's rays
     assert fused.can_render(ren, opt, center, ray, sdf, rad), "fused HIP path not taken"
     params = list(sdf.parameters()) + list(rad.parameters())
-    reducer = GradAllReducer(params) if world > 1 else None
+    reducer = GradAllReducer(params) if multi else None
 
     from ls2fm.losses import RenderLossHead
     from ls2fm.graph import CapturedStep
@@ -189,7 +195,7 @@ def main():
             reducer.all_reduce()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -213,7 +219,7 @@ def main():
     dt_eager = time.perf_counter() - t1
     lib.ls2fm_profile_enable(0)
     has_prof = True
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -242,7 +248,7 @@ def main():
         "eager_profiled_ms_per_step": dt_eager / args.steps * 1e3,
         "config": {"workload": f"{args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
                                f"{'dual' if dual else 'single'} field, L16/F2/T19 hash grid, fwd+loss+bwd"
-                               + (", RCCL grad all-reduce" if world > 1 else ""),
+                               + (", RCCL grad all-reduce" if multi else ""),
                    "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "dual_field": dual,
                    "parallelism": f"dp{world} (rays sharded by view)"},
         "roofline": roofline,
@@ -261,9 +267,13 @@ def main():
             except Exception as e:                                   # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": host_threads(), "kind": "port",
                                        "sample": f"CPU leg did not finish within 150 s ({type(e).__name__})"}
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if multi:
+        dist.destroy_process_group()      # RCCL writes its version banner to stdout on the way: keep the JSON line last
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL's banner sits in the C stdio buffer until exit otherwise
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
