@@ -61,9 +61,9 @@ def global_max_int(value: int, device) -> int:
 
 
 class GradAllReducer:
-    """Sum-all-reduce of `.grad` of a parameter list: big tensors individually, small ones through one flat buffer.
-    When the small gradients already are views of one flat buffer (the fused backward allocates them that way,
-    ls2fm.fused.small_grad_buffer) that buffer is reduced in place with no packing at all."""
+    """Sum-all-reduce of `.grad` of a parameter list.  When every gradient already is a view of one flat buffer (the
+    fused backward allocates them that way, ls2fm.fused.small_grad_buffer) that buffer is reduced in place as ONE
+    message; otherwise big tensors go individually and the small ones through a packed flat buffer."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], big_numel: int = 1 << 20, average: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -83,10 +83,29 @@ class GradAllReducer:
                 return None
         return flat
 
+    def _all_in_flat(self) -> Optional[torch.Tensor]:
+        from . import fused
+        flat = fused.small_grad_buffer()
+        if flat is None:
+            return None
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        covered = 0
+        for p in self.params:
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                return None
+            covered += p.grad.numel()
+        return flat if covered + 4 * len(self.params) >= flat.numel() else None    # nothing else lives in the buffer
+
     def all_reduce(self) -> None:
         if not is_distributed():
             return
         world = dist.get_world_size()
+        whole = self._all_in_flat()
+        if whole is not None:                              # one message: both tables and every small tensor
+            dist.all_reduce(whole)
+            if self.average:
+                whole.div_(world)
+            return
         handles = [dist.all_reduce(p.grad, async_op=True) for p in self.big if p.grad is not None]
         flat = self._shared_flat()
         packed = flat is None

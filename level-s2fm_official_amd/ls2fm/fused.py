@@ -179,7 +179,7 @@ def _params_struct(ts, dual, beta_speed, with_rad=True, cls=_lib.Params):
 
 
 # ------------------------------------------------------------------------------------------------ render
-_SMALL_GRADS = None      # flat buffer holding every small gradient of the latest fused backward
+_SMALL_GRADS = None      # flat buffer holding every gradient of the latest fused backward
 
 
 def small_grad_buffer():
@@ -245,19 +245,16 @@ class _Render(torch.autograd.Function):
         def prep(t):
             return None if t is None else t.float().contiguous()
         d_rgb, d_sdfs, d_normals, d_depth, d_nmlp = map(prep, (d_rgb, d_sdfs, d_normals, d_depth, d_nmlp))
-        # table gradients: zeroed accumulators (atomics).  All small gradients (MLPs, beta) are views of ONE flat
-        # buffer so that a multi-GPU run can all-reduce them as a single message without packing kernels.
+        # every gradient -- both tables (overwritten in full by the slab scatter) and the small tensors -- is a view of ONE
+        # flat buffer: a multi-GPU run all-reduces it as a single message without packing kernels (ls2fm.dist)
         global _SMALL_GRADS
-        small_total = sum(p.numel() for p in ps if not _is_table(p))
-        flat = torch.empty(small_total, device=c.device, dtype=torch.float32)
-        _SMALL_GRADS = flat
-        grads, at = [], 0
+        offs, total = [], 0
         for p in ps:
-            if _is_table(p):
-                grads.append(torch.empty_like(p))      # overwritten in full by the LDS-slab scatter
-            else:
-                grads.append(flat[at:at + p.numel()].view(p.shape))
-                at += p.numel()
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4                   # 16-byte aligned views
+        flat = torch.empty(total, device=c.device, dtype=torch.float32)
+        _SMALL_GRADS = flat
+        grads = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, ps)]
         pstruct = ctx.pstruct
         gstruct = _params_struct(grads, dual, beta_speed, cls=_lib.ParamGrads)
         want_pose = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
