@@ -10,7 +10,7 @@
 namespace {
 
 const char* const kNames[LS2FM_PROF_COUNT] = {
-    "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "wgrad", "wgrad_reduce",
+    "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "-", "-",
     "slab_scatter_sdf", "slab_scatter_rad", "finalize", "sdf_eval", "sphere_trace", "bin_build", "loss_head_fwd",
     "loss_head_bwd", "wgrad_mlp", "pose_grad"};
 

@@ -12,7 +12,7 @@
 // opt-in per-kernel timing (profile.hip): a mark before every launch, a mark with id -1 at the end of a call
 enum ls2fm_prof_id {
     LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
-    LS2FM_PROF_WGRAD, LS2FM_PROF_WGRAD_REDUCE, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
+    LS2FM_PROF_RESERVED0, LS2FM_PROF_RESERVED1, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
     LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_BIN, LS2FM_PROF_LOSS_FWD,
     LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_POSE, LS2FM_PROF_COUNT
 };
@@ -210,7 +210,7 @@ struct WsLayout {
     int64_t p, p_pad, r_pad;
     int l1, l2, dual;
     // forward -> backward
-    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, ones, x4, keys;
+    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, keys;
     // backward scratch
     int64_t rec1, rec2, rpt, bins, v, p3, gf, dz, gf2, dzr, renc, dexyz, dlen, mpart, wg, dbeta, smax;
     int64_t total;
@@ -250,9 +250,7 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.rgbs = take(3 * P);
     w.fe = take(16 * P);
     w.fe2 = take(dual ? 16 * P : 0);
-    w.ones = take(P);
     w.keys = take((int64_t)l1 * P); // uint32 per (level, point): slab-test key for the table-gradient scatter
-    w.x4 = take(4 * P);          // float4 (x, y, z, -): grid-normalised sample positions for the slab scatter
     // scatter payload: per point {x y z | gn0 gn1 gn2 | - -} (32 B, 4 MB per 131072 points: L2-resident across all the
     // levels' slab workgroups) + per (level, point) {de0 de1 rr0 rr1} (SDF grid, 16 B) / {de0 de1} (second grid, 8 B)
     w.rpt = take(8 * P);

@@ -189,8 +189,7 @@ template <bool WITH_JAC>
 __global__ void __launch_bounds__(256)
 ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
                   const float* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks,
-                  float* __restrict__ enc, float* __restrict__ jac, float* __restrict__ ones,
-                  float* __restrict__ xs, uint32_t* __restrict__ keys) {
+                  float* __restrict__ enc, float* __restrict__ jac, uint32_t* __restrict__ keys) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int l = xcd + 8 * (j / n_chunks);
     if (l >= lv.n_levels) return;
@@ -256,10 +255,6 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
         }
         keys[(int64_t)l * p_pad + i] = key;
     }
-    if (ones && l == 0) {
-        ones[i] = 1.0f;
-        reinterpret_cast<float4*>(xs)[i] = make_float4(x[0], x[1], x[2], 0.f);
-    }
 }
 
 
@@ -321,13 +316,13 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
     ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
     ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
-                                              n_chunks, ws + w.e1, ws + w.j1, ws + w.ones, ws + w.x4,
+                                              n_chunks, ws + w.e1, ws + w.j1,
                                               reinterpret_cast<uint32_t*>(ws + w.keys));
     ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
     if (dual) {
         ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
         ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,
-                                                   n_chunks, ws + w.e2, nullptr, nullptr, nullptr, nullptr);
+                                                   n_chunks, ws + w.e2, nullptr, nullptr);
         ls2fm_prof_end(LS2FM_PROF_ENCODE_RAD, s);
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
