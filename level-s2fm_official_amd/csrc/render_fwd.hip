@@ -45,13 +45,19 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
                     Packed* __restrict__ out) {
     __shared__ float row_scale[296];
     const int tid = threadIdx.x;
+    // one workgroup per independent task (a single workgroup doing everything was a 72 us latency chain that gated
+    // shade_fwd in single-field runs): 0 = SDF MLP, 1 = second field's MLP, 2 = radiance chain (+ beta)
+    const int task = blockIdx.x;
+    if (task == 1 && !dual) return;
+    const int row_lo = task == 0 ? row_base(0) : (task == 1 ? row_base(2) : row_base(4));
+    const int row_hi = task == 0 ? row_base(2) : (task == 1 ? row_base(4) : row_base(7));
     // 1. weight-norm row scales  s = g / ||v||   (torch._weight_norm(v, g, 0) = v * (g / norm))
     //    (16 lanes per row: coalesced reads + a 16-wide shuffle reduction instead of a serial latency chain)
-    for (int row0 = 0; row0 < 293; row0 += 16) {
+    for (int row0 = row_lo; row0 < row_hi; row0 += 16) {
         const int row = row0 + (tid >> 4), sub = tid & 15;
         int li = 0;
         while (li < 6 && row >= row_base(li + 1)) ++li;
-        const bool on = row < 293 && (dual || (li != 2 && li != 3)) && (with_rad || li < 4);
+        const bool on = row < row_hi && (dual || (li != 2 && li != 3)) && (with_rad || li < 4);
         const LayerRef L = layer_ref(P, li, li == 2 ? in_dim2 : in_dim, rad_in);
         const int o = row - row_base(li);
         float ss = 0.f;
@@ -59,11 +65,12 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             for (int k = sub; k < L.in; k += 16) { const float x = L.v[o * L.in + k]; ss = fmaf(x, x, ss); }
 #pragma unroll
         for (int m = 8; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 16);
-        if (sub == 0 && row < 293) row_scale[row] = on ? L.g[o] / sqrtf(ss) : 0.f;
+        if (sub == 0 && row < row_hi) row_scale[row] = on ? L.g[o] / sqrtf(ss) : 0.f;
     }
     __syncthreads();
     // 2. packed geometry MLPs
     for (int which = 0; which < (dual ? 2 : 1); ++which) {
+        if (which != task) continue;
         float* dst = which ? out->geo : out->sdf;
         const int ind = which ? in_dim2 : in_dim;
         const LayerRef L0 = layer_ref(P, which ? 2 : 0, ind, rad_in), L1 = layer_ref(P, which ? 3 : 1, ind, rad_in);
@@ -134,12 +141,12 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
         }
         if (tid == 0) mw.b10[which] = L1.b[0];
     }
-    if (tid == 3) {
+    if (task == 0 && tid == 3) {
         const float beta = expf(P.beta[0] * P.beta_speed);
         out->beta = beta;
         out->alpha = 1.0f / beta;
     }
-    if (!with_rad) return;          // SDF-only users (sdf_eval, sphere_trace); uniform exit
+    if (task != 2 || !with_rad) return;          // SDF-only users (sdf_eval, sphere_trace) launch task 0 alone
     // 3. effective radiance layers
     {
         const LayerRef R0 = layer_ref(P, 4, in_dim, rad_in), R1 = layer_ref(P, 5, in_dim, rad_in),
@@ -263,7 +270,7 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
 int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream) {
     ls2fm_prof_begin(LS2FM_PROF_PREP, stream);
-    prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out);
+    prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out);      // task 0 only
     ls2fm_prof_end(LS2FM_PROF_PREP, stream);
     return ls2fm_launch_status();
 }
@@ -309,7 +316,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
                         hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t ps = forked ? sc.side : s;
     ls2fm_prof_begin(LS2FM_PROF_PREP, ps);
-    prep_weights_kernel<<<1, 256, 0, ps>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
+    prep_weights_kernel<<<3, 256, 0, ps>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
     ls2fm_prof_end(LS2FM_PROF_PREP, ps);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
     const int n_chunks = (int)((w.p + 255) / 256);
