@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path over one batch of synthetic rays, forward + backward:
+One "step" = one pass of the hot path over one batch of synthetic rays, forward + backward (launched eagerly or as a
+hipGraph replay, see --launch):
 Renderer.forward (fused HIP kernels) -> loss head -> loss.backward() (fused HIP backward), and for N > 1 the
 RCCL all-reduce of the gradients.  Workload (BASELINE.json configs[1]): ETH3D bounds (+-5, scale_mlp 5,
 inside = false), 1024 rays x 128 samples per GPU, full L16/F2/T19 hash grids, dual field (SDF + radiance grid),
@@ -121,9 +122,11 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, gradient all-reduce, barriers) even with one process")
-    ap.add_argument("--graph", action="store_true",
-                    help="time hipGraph replays of the whole step (ls2fm.graph.CapturedStep) instead of eager launches; "
-                         "measured slower than eager on ROCm 7.2 for this step (graph branches serialise), so off by default")
+    ap.add_argument("--launch", choices=("auto", "eager", "graph"), default="auto",
+                    help="how the timed steps are launched: eager kernel launches, hipGraph replays of the whole step "
+                         "(ls2fm.graph.CapturedStep), or whichever a short untimed probe finds faster on this host (eager "
+                         "wins by ~5 %% when the host keeps up, the graph wins when the host CPU is slow or busy)")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
     args = ap.parse_args()
 
@@ -184,15 +187,47 @@ def main():
         loss.backward()
         return loss
 
-    captured = CapturedStep(render_step, params) if args.graph else None
+    mode = "graph" if args.graph else args.launch
+    # every step -- eager or captured -- runs on ONE non-default stream: autograd's gradient accumulators stay tied to
+    # the stream of their first backward, and mixing streams costs synchronisations (and breaks captures)
+    s_main = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(s_main)
+    captured = None
+    use_graph = False
 
     def step(eager=False):
-        if captured is None or eager:
-            render_step()
-        else:
+        if use_graph and not eager:
             captured.replay()
+        else:
+            render_step()
         if reducer is not None:
             reducer.all_reduce()
+
+    if mode == "graph":
+        captured = CapturedStep(render_step, params, stream=s_main)
+        use_graph = True
+    if mode == "auto":                      # untimed probe (part of the warm-up): pick the faster launch mode on this host
+        def probe(graph, n=40):
+            nonlocal use_graph
+            use_graph = graph
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        t_eager = probe(False)
+        captured = CapturedStep(render_step, params, stream=s_main)
+        t_graph = probe(True)
+        use_graph = t_graph < 0.98 * t_eager
+        if rank == 0:
+            print(f"[bench] launch probe: eager {t_eager * 1e3:.3f} ms/step, hipGraph {t_graph * 1e3:.3f} ms/step", file=sys.stderr)
+        if world > 1:                       # every rank must take the same path
+            flag = torch.tensor([1.0 if use_graph else 0.0], device=dev)
+            dist.all_reduce(flag)
+            use_graph = bool(flag.item() * 2 > world)
 
     def barrier():
         if multi:
@@ -244,7 +279,7 @@ def main():
         "metric": "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "launch": "hipGraph replay of the whole step" if args.graph else "eager",
+        "launch": ("hipGraph replay of the whole step" if use_graph else "eager") + (" (auto)" if mode == "auto" else ""),
         "eager_profiled_ms_per_step": dt_eager / args.steps * 1e3,
         "config": {"workload": f"{args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
                                f"{'dual' if dual else 'single'} field, L16/F2/T19 hash grid, fwd+loss+bwd"
