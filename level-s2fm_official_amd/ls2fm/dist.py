@@ -94,7 +94,7 @@ class GradAllReducer:
             if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
                 return None
             covered += p.grad.numel()
-        return flat if covered + 4 * len(self.params) >= flat.numel() else None    # nothing else lives in the buffer
+        return flat if covered == flat.numel() else None     # nothing else lives in the buffer
 
     def all_reduce(self) -> None:
         if not is_distributed():

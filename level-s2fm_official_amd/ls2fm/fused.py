@@ -248,13 +248,10 @@ class _Render(torch.autograd.Function):
         # every gradient -- both tables (overwritten in full by the slab scatter) and the small tensors -- is a view of ONE
         # flat buffer: a multi-GPU run all-reduces it as a single message without packing kernels (ls2fm.dist)
         global _SMALL_GRADS
-        offs, total = [], 0
-        for p in ps:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4                   # 16-byte aligned views
-        flat = torch.empty(total, device=c.device, dtype=torch.float32)
+        sizes = [p.numel() for p in ps]
+        flat = torch.empty(sum(sizes), device=c.device, dtype=torch.float32)
         _SMALL_GRADS = flat
-        grads = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, ps)]
+        grads = [g if p.dim() == 1 else g.view(p.shape) for g, p in zip(flat.split_with_sizes(sizes), ps)]
         pstruct = ctx.pstruct
         gstruct = _params_struct(grads, dual, beta_speed, cls=_lib.ParamGrads)
         want_pose = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
