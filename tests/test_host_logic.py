@@ -128,3 +128,20 @@ def test_options_attribute_dict():
     assert o.a.b.c == 4
     with pytest.raises(AttributeError):
         _ = o.missing
+
+
+def test_loss_head_and_fused_adam_have_no_cpu_path():
+    """the round's later additions keep the rule: CPU tensors are refused, nothing falls back"""
+    import pytest
+    import torch
+    from ls2fm.losses import RenderLossHead
+    from ls2fm.optim import FusedAdam
+    ret = {"rgb": torch.zeros(1, 4, 3), "normals": torch.zeros(1, 4, 2, 3), "depth_mlp": torch.zeros(1, 4, 1)}
+    head = RenderLossHead.__new__(RenderLossHead)
+    head.weights = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        head.terms(ret, torch.zeros(1, 4, 3))
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError):
+        FusedAdam([p]).step()
