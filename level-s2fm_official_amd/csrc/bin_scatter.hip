@@ -1,154 +1,73 @@
-// Hash-table gradient scatter for gfx950: binning pre-pass + LDS-owned slabs with exact fixed-point accumulation.
-// No table-wide global atomics, no floating-point atomics.
+// Hash-table gradient scatter for gfx950: a counting sort of per-corner-pair payloads by table slab, then LDS-owned slabs
+// that STREAM their payload lists and accumulate in exact 64-bit fixed point.
+// No table-wide global atomics, no floating-point atomics, no gathers in the accumulate phase.
 //
-// Measurements on MI355X that shaped this design (profiles/r01_*, tools/atomic_bench.hip):
+// Measurements on MI355X that shaped this design (profiles/r01_*, tools/atomic_bench.hip, tools/stamps.py):
 //   * global fp32 atomics: 17-21 G/s at every scope (memory side; the 8 XCD L2s are not coherent): a tcnn-style scatter
 //     was 80 % of the step
 //   * LDS ds_add_f32 ~0.26 lane/clk/CU, but LDS ds_add_u64 ~3160 G/s chip-wide (30x): accumulate in 64-bit fixed point
-//   * letting every slab workgroup scan all sample points cost ~143 M wave instructions per launch (PMC): bin first
+//   * a slab workgroup that walks a list of (point, pair) ids and GATHERS each point's records is bound by the request
+//     rate of the L2 -> L1 path (one cache line per lane, ~205 G requests/s: ~3 requests per item, 131 + 114 us for the
+//     two grids) -- so the records are turned into per-item payloads where they are still coalesced (by sample point)
+//     and delivered to the slabs sorted
 //
-//   bin_count / bin_scan / bin_fill   (once per backward, shared by both grids -- they have the same geometry)
-//       thread per 8 (point, level) keys; the 4-byte key (written by ray_encode) holds the slab ids of the point's four
-//       (y,z) corner pairs on a hashed level, or its first corner index on a dense level.  Every (point, pair) becomes a
-//       4-byte item in the list of the slab it falls into: LDS histogram + one global reservation per (workgroup, slab).
-//   slab_accumulate  (per grid)
-//       workgroup = (level, slab[, part]) OWNS 8192 entries x 2 features of the table gradient in LDS as 64-bit
-//       FIXED-POINT integers and walks only its own item list; an item = a 16-byte per-level record + the point's L2-resident 32-byte record, then 4 unmasked
-//       ds_add_u64 (2 x-corners x 2 features; first-order trilinear weight and, for the SDF grid, the double-backward
-//       derivative weight in the same add).  The quantum is a per-level power of two from a bound on one contribution
-//       (per-ray maxima from shade_bwd) with head-room for the worst-case hit count, so float->fixed and the integer
-//       sums are exact: the table gradient is the exactly rounded sum of its fp32 contributions, order-independent and
-//       bit-reproducible.  Every entry belongs to one slab: the table is written once with plain coalesced stores (no
-//       zero fill); only point-split coarse levels are flushed with a few float atomics.
+//   scatter_count  thread = (point, level): which slab does each of the four (y,z) corner pairs fall into (the two
+//                  x-corners of a pair share a slab except when cx+1 carries across the slab bit or a dense row ends --
+//                  then the pair is split into two half items).  Needs the rays only: runs on the side stream under
+//                  shade_bwd.
+//   scatter_scan   per-(tile, slab) counts -> absolute offsets (two small kernels; no global atomics in any pass: 1 M of
+//                  them per pass cost ~50 us, and the item order is now deterministic)
+//   scatter_fill   same classification, now with shade_bwd's records (read once, coalesced): builds the 32-byte payload
+//                  {local idx0 | idx1, wx, A0 A1 B0 B1 (SDF grid), C0 C1 (second grid)} of every item, sorts the workgroup's
+//                  items by slab in LDS and writes each (workgroup, slab) run with full cache lines
+//   slab_accumulate  workgroup = (level, slab[, part]) OWNS the slab of the table gradient(s) in LDS as 64-bit
+//                  FIXED-POINT integers -- 8192 entries x 2 features of one grid, or (dual field: same geometry, same
+//                  items) 4096 entries x (2 + 2) features of both -- and streams its payload list: value(bx) =
+//                  px(bx) A + sgn(bx) B  (first-order trilinear weight and the double-backward derivative weight, A.4),
+//                  second grid px(bx) C.  The quantum is a per-level power of two from a bound on one contribution
+//                  (per-ray maxima from shade_bwd) with head-room for the worst-case hit count, so float->fixed and the
+//                  integer sums are exact: the table gradient is the exactly rounded sum of its fp32 contributions,
+//                  order-independent.  Every entry belongs to one slab: the table is written once with plain coalesced
+//                  stores (no zero fill); only point-split coarse levels are flushed with a few float atomics.
 #include <cstdlib>
 
 #include "render_common.h"
 
 namespace {
 
-constexpr int kSlabEntries = 1 << kSlabShift;    // 8192 entries = 128 KiB of int64 pairs
-constexpr int kBins = 72;                        // per level: 64 slab bins, bin 64 = "check against every slab", padding
-constexpr int kGenericBin = 64;
-constexpr int kBinThreads = 256;
-constexpr int kBinPerThread = 8;
-constexpr int kBinTile = kBinThreads * kBinPerThread;     // 2048 points per workgroup
+constexpr int kAccSlots = 2 << kSlabShift;       // 16384 u64 accumulators = 128 KiB of LDS per workgroup
+constexpr int kSlabBins = 128;                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
+constexpr int kBins = kSlabBins;
+constexpr int kCountThreads = 256;
+constexpr int kFillThreads = 256;                // one sample point per thread
+constexpr int kFillCap = kFillThreads * 5;       // items staged in LDS per workgroup (4 per point + split pairs)
 constexpr int kAccThreads = 1024;
 constexpr int kMaxParts = 16;
 
 typedef unsigned long long u64;
 
-// items: (point << 3) | code ; code 0..3 = (y,z) corner pair whose two x-corners lie in the slab, 4 = check all corners
-struct BinMeta {           // device arrays inside the workspace
-    int* count;            // [L][kBins]
-    int* start;            // [L][kBins]  absolute offsets into items
-    int* cursor;           // [L][kBins]
-    uint32_t* items;
+struct __attribute__((aligned(16))) Item {      // 32 bytes
+    uint32_t ij;           // local entry index of x-corner 0 (low 16 bits) and 1 (high 16 bits); 0xFFFF = not in this slab
+    float wx;              // x weight: px(0) = 1 - wx, px(1) = wx
+    float a0, a1, b0, b1;  // SDF grid, per feature: A = pyz de + qyz rr ; B = qd_x pyz rr
+    float c0, c1;          // second grid: C = pyz de2
 };
 
-struct LevelGeom { uint32_t size, res, hashed; };
+struct BinMeta {           // device arrays inside the workspace
+    int* count;            // [L][kBins]  items per (level, slab)
+    int* start;            // [L][kBins]  absolute offsets into items
+    int* tile;             // [L][n_tiles][kBins]  per fill-workgroup counts, turned into absolute offsets by the scan: no
+                           //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
+                           //                      order is deterministic
+    Item* items;
+    int n_tiles;
+};
 
-__device__ __forceinline__ bool fast_level(uint32_t size, uint32_t hashed) {
-    const uint32_t slabs = size >> kSlabShift;
-    return hashed && (size & (size - 1u)) == 0u && slabs >= 1u && slabs <= 64u;
-}
-
-// classification of one key: up to 4 (bin, code) targets
-template <typename F>
-__device__ __forceinline__ void for_each_target(uint32_t k, uint32_t size, uint32_t res, uint32_t hashed, F&& f) {
-    if (size <= (uint32_t)kSlabEntries) { f(0, 4u); return; }                  // single slab: every point, all corners
-    if (k == 0xFFFFFFFFu || (hashed && !fast_level(size, hashed))) { f(kGenericBin, 4u); return; }
-    if (hashed) {
-#pragma unroll
-        for (unsigned c = 0; c < 4; ++c) f((int)((k >> (6 * c)) & 63u), c);
-        return;
-    }
-    const uint32_t span = 1u + res + res * res;                                  // dense: slabs its 8 corners can touch
-    const uint32_t s0 = k >> kSlabShift, s1 = (k + span) >> kSlabShift;
-    for (uint32_t s = s0; s <= s1 && s < 64u; ++s) f((int)s, 4u);
-}
-
-template <bool FILL>
-__global__ void __launch_bounds__(kBinThreads)
-bin_pass_kernel(LevelSet lv, const uint32_t* __restrict__ keys, int64_t n_points, int64_t p_pad, BinMeta bm) {
-    __shared__ int hist[kBins];
-    __shared__ int base[kBins];
-    const int tid = threadIdx.x, l = blockIdx.y;
-    const uint32_t size = lv.size[l], res = lv.res[l], hashed = lv.hashed[l];
-    if (tid < kBins) hist[tid] = 0;
-    __syncthreads();
-    uint32_t key[kBinPerThread];
-    const int64_t tile = (int64_t)blockIdx.x * kBinTile;
-#pragma unroll
-    for (int q = 0; q < kBinPerThread; ++q) {
-        const int64_t i = tile + q * kBinThreads + tid;
-        key[q] = i < n_points ? keys[(int64_t)l * p_pad + i] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < kBinPerThread; ++q) {
-        const int64_t i = tile + q * kBinThreads + tid;
-        if (i < n_points) for_each_target(key[q], size, res, hashed, [&](int bin, unsigned) { atomicAdd(&hist[bin], 1); });
-    }
-    __syncthreads();
-    if (!FILL) {
-        if (tid < kBins && hist[tid]) atomicAdd(&bm.count[l * kBins + tid], hist[tid]);
-        return;
-    }
-    if (tid < kBins) {
-        const int n = hist[tid];
-        base[tid] = n ? bm.start[l * kBins + tid] + atomicAdd(&bm.cursor[l * kBins + tid], n) : 0;
-        hist[tid] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kBinPerThread; ++q) {
-        const int64_t i = tile + q * kBinThreads + tid;
-        if (i < n_points)
-            for_each_target(key[q], size, res, hashed, [&](int bin, unsigned code) {
-                const int rank = atomicAdd(&hist[bin], 1);
-                bm.items[base[bin] + rank] = ((uint32_t)i << 3) | code;
-            });
-    }
-}
-
-// exclusive prefix of the per-(level, bin) counts into absolute item offsets; zeroes the fill cursors.
-// one wave per level (72 bins = lanes + 8 spill lanes), level totals combined through LDS
-__device__ __forceinline__ int wave_scan_incl_int(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
-__global__ void __launch_bounds__(64 * LS2FM_MAX_LEVELS)
-bin_scan_kernel(int n_levels, BinMeta bm) {
-    __shared__ int level_total[LS2FM_MAX_LEVELS];
-    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const bool on = l < n_levels;
-    const int c0 = on ? bm.count[l * kBins + lane] : 0;
-    const int c1 = (on && lane < kBins - 64) ? bm.count[l * kBins + 64 + lane] : 0;
-    const int i0 = wave_scan_incl_int(c0, lane);
-    const int t0 = __shfl(i0, 63, 64);
-    const int i1 = wave_scan_incl_int(c1, lane);
-    const int t1 = __shfl(i1, 63, 64);
-    if (lane == 0) level_total[l] = t0 + t1;
-    __syncthreads();
-    if (!on) return;
-    int before = 0;
-    for (int q = 0; q < l; ++q) before += level_total[q];
-    bm.start[l * kBins + lane] = before + i0 - c0;
-    bm.cursor[l * kBins + lane] = 0;
-    if (lane < kBins - 64) {
-        bm.start[l * kBins + 64 + lane] = before + t0 + i1 - c1;
-        bm.cursor[l * kBins + 64 + lane] = 0;
-    }
-}
-
-struct SlabPlan {
-    int first[LS2FM_MAX_LEVELS + 1];     // first work item of every level
-    int parts[LS2FM_MAX_LEVELS];         // item-range parts per slab of the level
-    int headroom_bits;                   // log2 of the worst-case number of contributions to one entry
+struct LevelC {            // level constants
+    uint32_t size, res, hashed, mask;
+    bool pow2;
+    float scale;
+    int sshift;            // log2 of the slab size in entries on this level
 };
 
 __device__ __forceinline__ uint32_t wrap_index(uint32_t idx, uint32_t size) {
@@ -159,13 +78,6 @@ __device__ __forceinline__ uint32_t wrap_index(uint32_t idx, uint32_t size) {
     return idx;
 }
 
-struct LevelC {                          // block-uniform level constants
-    uint32_t size, res, hashed, mask, lo, hi;
-    bool pow2;
-    float scale;
-    float to_fixed;                      // 1 / quantum (a power of two)
-};
-
 __device__ __forceinline__ uint32_t level_index(const LevelC& L, uint32_t cx, uint32_t cy, uint32_t cz) {
     if (L.hashed) {
         const uint32_t h = cx ^ (cy * LS2FM_PRIME_Y) ^ (cz * LS2FM_PRIME_Z);
@@ -174,203 +86,418 @@ __device__ __forceinline__ uint32_t level_index(const LevelC& L, uint32_t cx, ui
     return wrap_index(cx + cy * L.res + cz * L.res * L.res, L.size);
 }
 
-struct Payload { float x[3], d0, d1, r0, r1, qd[3]; };
+// slabs of a level at the base slab size (8192 entries single grid / 4096 dual); a level with more than kSlabBins of them
+// (log2_hashmap_size > 19 single / > 19 dual) is refused by the launcher
+__host__ __device__ __forceinline__ int level_slabs(uint32_t size, int sshift) { return (int)((size + (1u << sshift) - 1u) >> sshift); }
+
+__device__ __forceinline__ LevelC make_level_c(const LevelSet& lv, int l, int sshift) {
+    LevelC L;
+    L.size = lv.size[l]; L.res = lv.res[l]; L.hashed = lv.hashed[l]; L.scale = lv.scale[l];
+    L.mask = L.size - 1u;
+    L.pow2 = (L.size & L.mask) == 0u;
+    L.sshift = sshift;
+    return L;
+}
+
+// The items of one (point, level): for each (y,z) corner pair c = by + 2 bz the two x-corner entries idx0, idx1; one item
+// when both lie in the same slab, else two half items.  f(slab, c, local idx0 or 0xFFFF, local idx1 or 0xFFFF).
+// Used identically by the count and the fill pass.
+template <typename F>
+__device__ __forceinline__ void for_each_item(const LevelC& L, const uint32_t g[3], F&& f) {
+    const uint32_t lmask = (1u << L.sshift) - 1u;
+#pragma unroll
+    for (unsigned c = 0; c < 4; ++c) {
+        const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
+        const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
+        const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
+        if (s0 == s1) {
+            f((int)s0, c, i0 & lmask, i1 & lmask);
+        } else {
+            f((int)s0, c, i0 & lmask, 0xFFFFu);
+            f((int)s1, c, 0xFFFFu, i1 & lmask);
+        }
+    }
+}
+
+// sample i -> grid-normalised position, exactly as every other kernel of the path computes it
+__device__ __forceinline__ void point_position(const FieldC& fc, const float* __restrict__ center, const float* __restrict__ ray,
+                                               int64_t i, float x[3]) {
+    const int64_t r = i / fc.n_samples;
+    const int n = (int)(i - r * fc.n_samples);
+    const RayGeom gm = load_ray(fc, center, ray, r);
+    float p[3];
+    sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
+}
+
+// ------------------------------------------------------------------------------------------------ count
+__global__ void __launch_bounds__(kCountThreads)
+scatter_count_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
+                     int sshift, BinMeta bm) {
+    __shared__ int hist[kBins];
+    const int tid = threadIdx.x, l = blockIdx.y;
+    for (int b = tid; b < kBins; b += kCountThreads) hist[b] = 0;
+    __syncthreads();
+    const LevelC L = make_level_c(lv, l, sshift);
+    const int64_t i = (int64_t)blockIdx.x * kCountThreads + tid;
+    if (i < n_points) {
+        float x[3];
+        point_position(fc, center, ray, i, x);
+        uint32_t g[3];
+        float w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pos_fract(x[a], L.scale, g[a], w);
+        for_each_item(L, g, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
+    }
+    __syncthreads();
+    int* row = bm.tile + ((int64_t)l * bm.n_tiles + blockIdx.x) * kBins;
+    for (int b = tid; b < kBins; b += kCountThreads) row[b] = hist[b];
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+__device__ __forceinline__ int wave_scan_incl_int(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Offsets.  Pass 1 (workgroup = level, thread = (slab, chunk of tiles)): per-slab totals and, inside a slab, the
+// exclusive prefix of the tile counts.  Pass 2 (one workgroup): exclusive prefix of the (level, slab) totals into absolute
+// starts.  The fill adds the two.
+constexpr int kScanChunks = 8;
+__global__ void __launch_bounds__(kBins * kScanChunks)
+scatter_scan_tiles_kernel(BinMeta bm) {
+    __shared__ int chunk_sum[kScanChunks][kBins];
+    const int b = threadIdx.x % kBins, ch = threadIdx.x / kBins, l = blockIdx.x;
+    const int per = (bm.n_tiles + kScanChunks - 1) / kScanChunks;
+    const int t0 = ch * per, t1 = t0 + per < bm.n_tiles ? t0 + per : bm.n_tiles;
+    int* col = bm.tile + (int64_t)l * bm.n_tiles * kBins + b;
+    int sum = 0;
+    for (int t = t0; t < t1; ++t) sum += col[(int64_t)t * kBins];
+    chunk_sum[ch][b] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int q = 0; q < ch; ++q) run += chunk_sum[q][b];
+    for (int t = t0; t < t1; ++t) {
+        const int c = col[(int64_t)t * kBins];
+        col[(int64_t)t * kBins] = run;
+        run += c;
+    }
+    if (ch == kScanChunks - 1) bm.count[l * kBins + b] = run;
+}
+
+__global__ void __launch_bounds__(64 * LS2FM_MAX_LEVELS)
+scatter_scan_kernel(int n_levels, BinMeta bm) {
+    __shared__ int level_total[LS2FM_MAX_LEVELS];
+    constexpr int kChunks = (kBins + 63) / 64;
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const bool on = l < n_levels;
+    int excl[kChunks], run = 0;
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        const int b = 64 * c + lane;
+        const int cnt = (on && b < kBins) ? bm.count[l * kBins + b] : 0;
+        const int incl = wave_scan_incl_int(cnt, lane);
+        excl[c] = run + incl - cnt;
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) level_total[l] = run;
+    __syncthreads();
+    if (!on) return;
+    int before = 0;
+    for (int q = 0; q < l; ++q) before += level_total[q];
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        const int b = 64 * c + lane;
+        if (b < kBins) bm.start[l * kBins + b] = before + excl[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fill
+// rpt[point] = {x y z gn0 | gn1 gn2 - -}; rec1[level][point] = {de0 de1 rr0 rr1}; rec2[level][point] = {de0 de1}
+template <bool DUAL>
+__global__ void __launch_bounds__(kFillThreads)
+scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
+                    int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
+                    const float* __restrict__ rec2, BinMeta bm) {
+    __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
+    __shared__ int lds_off[kBins];       // first LDS slot of the slab's run
+    __shared__ int base[kBins];          // first global item index of the slab's run
+    __shared__ int run_len[kBins];       // items of this workgroup in the slab's run
+    __shared__ Item s_items[kFillCap];
+    __shared__ uint32_t s_gidx[kFillCap];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, l = blockIdx.y;
+    for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
+    __syncthreads();
+    const LevelC L = make_level_c(lv, l, sshift);
+    const int64_t i = (int64_t)blockIdx.x * kFillThreads + tid;
+    const bool live = i < n_points;
+    uint32_t g[3] = {0u, 0u, 0u};
+    float w[3] = {0.f, 0.f, 0.f}, d0 = 0.f, d1 = 0.f, r0 = 0.f, r1 = 0.f, e0 = 0.f, e1 = 0.f, qd[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        const float4 a = reinterpret_cast<const float4*>(rpt)[2 * i];
+        const float4 c = reinterpret_cast<const float4*>(rpt)[2 * i + 1];
+        const float4 b = reinterpret_cast<const float4*>(rec1)[(int64_t)l * p_pad + i];
+        float x[3];
+        point_position(fc, center, ray, i, x);              // the very code path of the count pass: same cells, same slabs
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pos_fract(x[q], L.scale, g[q], w[q]);
+        d0 = b.x; d1 = b.y; r0 = b.z; r1 = b.w;
+        qd[0] = L.scale * a.w; qd[1] = L.scale * c.x; qd[2] = L.scale * c.y;
+        if (DUAL) {
+            const float2 e = reinterpret_cast<const float2*>(rec2)[(int64_t)l * p_pad + i];
+            e0 = e.x; e1 = e.y;
+        }
+        for_each_item(L, g, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
+    }
+    __syncthreads();
+    // runs: LDS offsets (exclusive prefix over the slabs, wave 0) and one global reservation per slab
+    if (tid < 64) {
+        int run = 0;
+#pragma unroll
+        for (int c = 0; c < (kBins + 63) / 64; ++c) {
+            const int b = 64 * c + lane;
+            const int cnt = b < kBins ? hist[b] : 0;
+            const int incl = wave_scan_incl_int(cnt, lane);
+            if (b < kBins) lds_off[b] = run + incl - cnt;
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) s_total = run;
+    }
+    __syncthreads();
+    for (int b = tid; b < kBins; b += kFillThreads) {
+        const int n = hist[b];
+        base[b] = bm.start[l * kBins + b] + bm.tile[((int64_t)l * bm.n_tiles + blockIdx.x) * kBins + b];
+        run_len[b] = n;
+    }
+    __syncthreads();
+    for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
+    __syncthreads();
+    if (live) {
+        for_each_item(L, g, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
+            const int by = (int)(c & 1u), bz = (int)(c >> 1);
+            const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
+            const float pyz = py * pz;
+            const float qyz = (by ? qd[1] : -qd[1]) * pz + py * (bz ? qd[2] : -qd[2]);
+            Item it;
+            it.ij = i0 | (i1 << 16);
+            it.wx = w[0];
+            it.a0 = fmaf(qyz, r0, pyz * d0);
+            it.a1 = fmaf(qyz, r1, pyz * d1);
+            it.b0 = qd[0] * pyz * r0;
+            it.b1 = qd[0] * pyz * r1;
+            it.c0 = pyz * e0;
+            it.c1 = pyz * e1;
+            int rank = atomicAdd(&hist[slab], 1);
+            // long runs (coarse levels: consecutive samples of a ray fall into the same cell) are stored permuted, so that
+            // the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same entry (same-address
+            // LDS atomics serialise): position = rank * K mod n with K prime > n
+            const int n_run = run_len[slab];
+            if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
+            const int slot = lds_off[slab] + rank;
+            const uint32_t gi = (uint32_t)(base[slab] + rank);
+            if (slot < kFillCap) { s_items[slot] = it; s_gidx[slot] = gi; }
+            else bm.items[gi] = it;                         // more split pairs than the staging area holds: direct write
+        });
+    }
+    __syncthreads();
+    // runs of one slab are contiguous in LDS and in memory: consecutive threads write consecutive 32-byte items
+    const int staged = s_total < kFillCap ? s_total : kFillCap;
+    for (int q = tid; q < staged; q += kFillThreads) bm.items[s_gidx[q]] = s_items[q];
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+struct SlabPlan {
+    int first[LS2FM_MAX_LEVELS + 1];     // first workgroup of every level
+    int parts[LS2FM_MAX_LEVELS];         // item-range parts per slab of the level
+    int headroom_bits;                   // log2 of the worst-case number of contributions to one entry
+};
 
 __device__ __forceinline__ void add_fixed(u64* slot, float v, float to_fixed) {
     // v * to_fixed is exact (power-of-two scale); |.| < 2^62 / worst-case hits by construction of the quantum
     atomicAdd(slot, (u64)__float2ll_rn(v * to_fixed));        // two's complement: integer sums are exact
 }
 
-// trilinear weight  W = px py pz ; directional derivative weight  D = qx py pz + px qy pz + px py qz
-// with p_a(b) = b ? w_a : 1 - w_a and q_a(b) = (b ? +1 : -1) * scale * gn_a
-template <bool SECOND_ORDER, bool CHECK>
-__device__ __forceinline__ void add_pair(const LevelC& L, u64* acc, const Payload& pl, const uint32_t g[3], const float w[3],
-                                         int by, int bz) {
-    const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
-    const float pyz = py * pz;
-    float qyz = 0.f;
-    if (SECOND_ORDER) qyz = (by ? pl.qd[1] : -pl.qd[1]) * pz + py * (bz ? pl.qd[2] : -pl.qd[2]);
-#pragma unroll
-    for (int bx = 0; bx < 2; ++bx) {
-        const uint32_t idx = level_index(L, g[0] + bx, g[1] + by, g[2] + bz);
-        if (!CHECK || (idx >= L.lo && idx < L.hi)) {
-            const float px = bx ? w[0] : 1.0f - w[0];
-            const float wt = px * pyz;
-            float v0 = wt * pl.d0, v1 = wt * pl.d1;
-            if (SECOND_ORDER) {
-                const float dirw = fmaf(bx ? pl.qd[0] : -pl.qd[0], pyz, px * qyz);
-                v0 = fmaf(dirw, pl.r0, v0);
-                v1 = fmaf(dirw, pl.r1, v1);
-            }
-            add_fixed(&acc[2 * (idx - L.lo) + 0], v0, L.to_fixed);
-            add_fixed(&acc[2 * (idx - L.lo) + 1], v1, L.to_fixed);
-        }
-    }
+__device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float& to_fixed, double& to_float) {
+    // contributions are bounded by 2^e (e from the level's bound), sums by 2^(e + headroom): value * 2^shift fits in 62 bits
+    int e_bound = 0;
+    if (bound > 0.f) (void)frexpf(bound, &e_bound);             // bound < 2^e_bound
+    int shift = 62 - headroom_bits - e_bound;
+    shift = shift > 126 ? 126 : (shift < -126 ? -126 : shift);
+    to_fixed = ldexpf(1.0f, shift);
+    to_float = ldexp(1.0, -shift);
 }
 
-// payload of one (level, point): per-point record rpt[point] = {x y z gn0 | gn1 gn2 - -} and the per-level record
-// rec[level][point] = {de0 de1 rr0 rr1} (SDF grid) / {de0 de1} (second grid)
-template <bool SECOND_ORDER>
-__device__ __forceinline__ Payload load_payload(const float* __restrict__ rec_l, const float* __restrict__ rpt, int64_t i,
-                                                float scale) {
-    Payload pl;
-    const float4 a = reinterpret_cast<const float4*>(rpt)[2 * i];
-    pl.x[0] = a.x; pl.x[1] = a.y; pl.x[2] = a.z;
-    pl.qd[0] = pl.qd[1] = pl.qd[2] = 0.f;
-    pl.r0 = pl.r1 = 0.f;
-    if (SECOND_ORDER) {
-        const float4 c = reinterpret_cast<const float4*>(rpt)[2 * i + 1];
-        const float4 b = reinterpret_cast<const float4*>(rec_l)[i];
-        pl.d0 = b.x; pl.d1 = b.y; pl.r0 = b.z; pl.r1 = b.w;
-        pl.qd[0] = scale * a.w; pl.qd[1] = scale * c.x; pl.qd[2] = scale * c.y;
-    } else {
-        const float2 b = reinterpret_cast<const float2*>(rec_l)[i];
-        pl.d0 = b.x; pl.d1 = b.y;
-    }
-    return pl;
-}
-
-template <bool SECOND_ORDER>
-__device__ __forceinline__ void process_item(const LevelC& L, u64* acc, const Payload& pl, unsigned code) {
-    uint32_t g[3];
-    float w[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) pos_fract(pl.x[a], L.scale, g[a], w[a]);
-    if (code < 4u) {
-        add_pair<SECOND_ORDER, false>(L, acc, pl, g, w, (int)(code & 1u), (int)(code >> 1));
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) add_pair<SECOND_ORDER, true>(L, acc, pl, g, w, c & 1, c >> 1);
-    }
-}
-
-template <bool SECOND_ORDER>
+template <bool DUAL>
 __global__ void __launch_bounds__(kAccThreads)
-slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int64_t p_pad, const float* __restrict__ rec,
-                       const float* __restrict__ rpt, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad, float* __restrict__ dtable) {
-    constexpr int REC = SECOND_ORDER ? 4 : 2;
-    __shared__ u64 acc[2 * kSlabEntries];
-    __shared__ float s_bound[kAccThreads / 64];
+slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, const float* __restrict__ ray_bound,
+                       int64_t n_rays, int64_t r_pad, float* __restrict__ dtable1, float* __restrict__ dtable2) {
+    constexpr int F = DUAL ? 4 : 2;
+    __shared__ u64 acc[kAccSlots];
+    __shared__ float s_bound[2][kAccThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int l = 0;
     while ((int)blockIdx.x >= plan.first[l + 1]) ++l;
     const int parts = plan.parts[l];
-    const uint32_t item = blockIdx.x - plan.first[l];
-    const uint32_t slab = item / parts;
-    const int part = (int)(item % parts);
+    const uint32_t wg = blockIdx.x - plan.first[l];
+    const uint32_t slab = wg / parts;
+    const int part = (int)(wg % parts);
+    const uint32_t size = lv.size[l];
+    const uint32_t lo = slab << sshift;
+    const uint32_t hi = lo + (1u << sshift) < size ? lo + (1u << sshift) : size;
 
-    // bound of a single contribution on this level = max over rays (written per ray by shade_bwd)
+    // bound of a single contribution on this level = max over rays (written per ray by shade_bwd); second grid: rows 16..31
     {
-        float b = 0.f;
-        for (int64_t r = tid; r < n_rays; r += kAccThreads) b = fmaxf(b, ray_bound[(int64_t)l * r_pad + r]);
+        float b1 = 0.f, b2 = 0.f;
+        for (int64_t r = tid; r < n_rays; r += kAccThreads) {
+            b1 = fmaxf(b1, ray_bound[(int64_t)l * r_pad + r]);
+            if (DUAL) b2 = fmaxf(b2, ray_bound[(int64_t)(16 + l) * r_pad + r]);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
-        if (lane == 0) s_bound[wave] = b;
+        for (int o = 32; o > 0; o >>= 1) { b1 = fmaxf(b1, __shfl_xor(b1, o, 64)); b2 = fmaxf(b2, __shfl_xor(b2, o, 64)); }
+        if (lane == 0) { s_bound[0][wave] = b1; s_bound[1][wave] = b2; }
     }
-    for (int e = tid; e < 2 * kSlabEntries; e += kAccThreads) acc[e] = 0ull;
+    const int n_slots = F * (int)(hi - lo);
+    for (int e = tid; e < n_slots; e += kAccThreads) acc[e] = 0ull;
     __syncthreads();
-    float bound = 0.f;
+    float bound1 = 0.f, bound2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < kAccThreads / 64; ++q) bound = fmaxf(bound, s_bound[q]);
+    for (int q = 0; q < kAccThreads / 64; ++q) { bound1 = fmaxf(bound1, s_bound[0][q]); bound2 = fmaxf(bound2, s_bound[1][q]); }
+    float to_fixed1, to_fixed2;
+    double to_float1, to_float2;
+    quantum_of(bound1, plan.headroom_bits, to_fixed1, to_float1);
+    quantum_of(bound2, plan.headroom_bits, to_fixed2, to_float2);
 
-    LevelC L;
-    L.size = lv.size[l]; L.res = lv.res[l]; L.hashed = lv.hashed[l]; L.scale = lv.scale[l];
-    L.mask = L.size - 1u;
-    L.pow2 = (L.size & L.mask) == 0u;
-    L.lo = slab << kSlabShift;
-    L.hi = L.lo + kSlabEntries < L.size ? L.lo + kSlabEntries : L.size;
-    // fixed-point quantum: contributions are bounded by 2^e (e from the level's bound), sums by 2^(e + headroom)
-    int e_bound = 0;
-    if (bound > 0.f) (void)frexpf(bound, &e_bound);             // bound < 2^e_bound
-    int shift = 62 - plan.headroom_bits - e_bound;              // value * 2^shift fits in 62 bits after all hits
-    shift = shift > 126 ? 126 : (shift < -126 ? -126 : shift);
-    L.to_fixed = ldexpf(1.0f, shift);
-    const double to_float = ldexp(1.0, -shift);
-    const float* __restrict__ rec_l = rec + (int64_t)l * p_pad * REC;
-
-    // this workgroup's share of its slab's item list, then of the level's "check every slab" list
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
-        const int bin = which == 0 ? (int)slab : kGenericBin;
-        const int n = bm.count[l * kBins + bin];
-        const int64_t st = bm.start[l * kBins + bin];
-        const int lo = (int)((int64_t)n * part / parts), hi = (int)((int64_t)n * (part + 1) / parts);
-        // two items per thread per trip: the second record's gather is in flight while the first is accumulated
-        for (int j = lo + tid; j < hi; j += 2 * kAccThreads) {
-            const int j2 = j + kAccThreads;
-            const uint32_t it0 = bm.items[st + j];
-            const uint32_t it1 = j2 < hi ? bm.items[st + j2] : 0u;
-            const Payload p0 = load_payload<SECOND_ORDER>(rec_l, rpt, it0 >> 3, L.scale);
-            Payload p1 = p0;
-            if (j2 < hi) p1 = load_payload<SECOND_ORDER>(rec_l, rpt, it1 >> 3, L.scale);
-            process_item<SECOND_ORDER>(L, acc, p0, which == 0 ? (it0 & 7u) : 4u);
-            if (j2 < hi) process_item<SECOND_ORDER>(L, acc, p1, which == 0 ? (it1 & 7u) : 4u);
+    // this workgroup's share of the slab's payload list: streamed, 32 bytes per lane, fully coalesced
+    {
+        const int n = bm.count[l * kBins + slab];
+        const Item* __restrict__ list = bm.items + bm.start[l * kBins + slab];
+        const int j_lo = (int)((int64_t)n * part / parts), j_hi = (int)((int64_t)n * (part + 1) / parts);
+        for (int j = j_lo + tid; j < j_hi; j += kAccThreads) {
+            const uint4 q0 = reinterpret_cast<const uint4*>(list + j)[0];
+            const uint4 q1 = reinterpret_cast<const uint4*>(list + j)[1];
+            const uint32_t i0 = q0.x & 0xFFFFu, i1 = q0.x >> 16;
+            const float wx = __uint_as_float(q0.y);
+            const float a0 = __uint_as_float(q0.z), a1 = __uint_as_float(q0.w);
+            const float b0 = __uint_as_float(q1.x), b1 = __uint_as_float(q1.y);
+            const float c0 = __uint_as_float(q1.z), c1 = __uint_as_float(q1.w);
+            const float px0 = 1.0f - wx;
+            if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
+                u64* slot = acc + F * i0;
+                add_fixed(slot + 0, fmaf(px0, a0, -b0), to_fixed1);
+                add_fixed(slot + 1, fmaf(px0, a1, -b1), to_fixed1);
+                if (DUAL) { add_fixed(slot + 2, px0 * c0, to_fixed2); add_fixed(slot + 3, px0 * c1, to_fixed2); }
+            }
+            if (i1 != 0xFFFFu) {                             // x-corner 1: px = wx, derivative sign +
+                u64* slot = acc + F * i1;
+                add_fixed(slot + 0, fmaf(wx, a0, b0), to_fixed1);
+                add_fixed(slot + 1, fmaf(wx, a1, b1), to_fixed1);
+                if (DUAL) { add_fixed(slot + 2, wx * c0, to_fixed2); add_fixed(slot + 3, wx * c1, to_fixed2); }
+            }
         }
     }
     __syncthreads();
-    // ---- flush: fixed point -> fp32 (one rounding of the exact sum)
-    float* dst = dtable + 2ull * (lv.offset[l] + L.lo);
-    const int n_out = 2 * (int)(L.hi - L.lo);
-    if (parts == 1) {
-        for (int e = tid; e < n_out; e += kAccThreads) dst[e] = (float)((double)(long long)acc[e] * to_float);   // sole owner
-    } else {
-        for (int e = tid; e < n_out; e += kAccThreads)                        // small coarse level, zeroed by the host
-            if (acc[e] != 0ull) atomicAdd(dst + e, (float)((double)(long long)acc[e] * to_float));
+    // ---- flush: fixed point -> fp32 (one rounding of the exact sum); slot e = F * entry + feature
+    float* dst1 = dtable1 + 2ull * (lv.offset[l] + lo);
+    float* dst2 = DUAL ? dtable2 + 2ull * (lv.offset[l] + lo) : nullptr;
+    for (int e = tid; e < n_slots; e += kAccThreads) {
+        const int entry = e / F, f = e % F;
+        const bool second = DUAL && f >= 2;
+        float* dst = (second ? dst2 : dst1) + 2 * entry + (f & 1);
+        const float v = (float)((double)(long long)acc[e] * (second ? to_float2 : to_float1));
+        if (parts == 1) *dst = v;                                 // sole owner of the entry
+        else if (acc[e] != 0ull) atomicAdd(dst, v);               // point-split coarse level, zeroed by the host
     }
 }
 
-BinMeta make_bin_meta(float* bins_ws) {
+constexpr int kFillTile = kFillThreads;          // sample points per count / fill workgroup (must agree)
+static_assert(kCountThreads == kFillThreads, "count and fill classify the same tiles");
+
+int64_t meta_ints(int64_t n_points) {
+    const int64_t n_tiles = (n_points + kFillTile - 1) / kFillTile;
+    return (2 * LS2FM_MAX_LEVELS * kBins + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
+}
+
+BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     BinMeta bm;
     int* meta = reinterpret_cast<int*>(bins_ws);
+    bm.n_tiles = (int)((n_points + kFillTile - 1) / kFillTile);
     bm.count = meta;
     bm.start = meta + LS2FM_MAX_LEVELS * kBins;
-    bm.cursor = meta + 2 * LS2FM_MAX_LEVELS * kBins;
-    bm.items = reinterpret_cast<uint32_t*>(meta + 3 * LS2FM_MAX_LEVELS * kBins + 64);
+    bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins;
+    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points));      // 256-byte aligned
     return bm;
+}
+
+bool levels_fit(const ls2fm_grid_desc* grid, int sshift) {
+    for (int l = 0; l < grid->n_levels; ++l)
+        if (level_slabs(grid->size[l], sshift) > kSlabBins) return false;
+    return true;
 }
 
 }  // namespace
 
-// floats of workspace the bins need: meta + worst case 4 items per (point, level) (+1 for the generic list)
+// floats of workspace the scatter needs: meta + worst case 8 items (4 pairs, each split) of 32 bytes per (point, level)
 int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points) {
-    return 3 * LS2FM_MAX_LEVELS * kBins + 64 + 5 * (int64_t)n_levels * n_points + 64;
+    static_assert(sizeof(Item) == 32, "item layout");
+    return meta_ints(n_points) + 8 * 8 * (int64_t)n_levels * n_points + 64;
 }
 
-size_t ls2fm_bin_counts_bytes() { return sizeof(int) * LS2FM_MAX_LEVELS * kBins; }
+size_t ls2fm_bin_counts_bytes() { return 0; }      // nothing to zero: every count is written, not accumulated
 
-// count -> scan -> fill of the per-slab item lists (geometry only: shared by both grids)
-int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, int64_t n_points, int64_t p_pad, float* bins_ws,
-                           hipStream_t stream) {
-    const BinMeta bm = make_bin_meta(bins_ws);              // counts: zeroed by the caller (ls2fm_bin_counts_bytes)
+// count -> scan of the per-slab item lists: positions only (the rays), shared by both grids; counts zeroed by the caller
+int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, int64_t n_points,
+                           float* bins_ws, int dual, hipStream_t stream) {
+    const int sshift = ls2fm_slab_shift(dual);
+    if (!levels_fit(grid, sshift)) return LS2FM_ERR_UNSUPPORTED;
+    const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
-    const dim3 g((unsigned)((n_points + kBinTile - 1) / kBinTile), (unsigned)grid->n_levels);
-    bin_pass_kernel<false><<<g, kBinThreads, 0, stream>>>(lv, keys, n_points, p_pad, bm);
-    bin_scan_kernel<<<1, 64 * LS2FM_MAX_LEVELS, 0, stream>>>(grid->n_levels, bm);
-    bin_pass_kernel<true><<<g, kBinThreads, 0, stream>>>(lv, keys, n_points, p_pad, bm);
+    const dim3 g((unsigned)bm.n_tiles, (unsigned)grid->n_levels);
+    scatter_count_kernel<<<g, kCountThreads, 0, stream>>>(lv, fc, center, ray, n_points, sshift, bm);
+    scatter_scan_tiles_kernel<<<grid->n_levels, kBins * kScanChunks, 0, stream>>>(bm);
+    scatter_scan_kernel<<<1, 64 * LS2FM_MAX_LEVELS, 0, stream>>>(grid->n_levels, bm);
     return ls2fm_launch_status();
 }
 
-// dtable is OVERWRITTEN over the whole grid.  rec: per-(level, point) payload records (see load_payload);
-// ray_bound: [level][r_pad] per-ray bounds of a single contribution.
-int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, int64_t p_pad, const float* rec,
-                                 const float* rpt, bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
-                                 hipStream_t stream) {
-    const BinMeta bm = make_bin_meta(bins_ws);
+// payloads from shade_bwd's records, sorted by slab
+int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
+                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt, int dual,
+                              hipStream_t stream) {
+    const int sshift = ls2fm_slab_shift(dual);
+    const BinMeta bm = make_bin_meta(bins_ws, n_points);
+    const LevelSet lv = make_level_set(grid);
+    const dim3 g((unsigned)bm.n_tiles, (unsigned)grid->n_levels);
+    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, bm);
+    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, bm);
+    return ls2fm_launch_status();
+}
+
+// dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid.
+// ray_bound: [32][r_pad] per-ray bounds of a single contribution (rows 0..15 SDF grid, 16..31 second grid).
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, const float* ray_bound,
+                                 int64_t n_rays, float* dtable1, float* dtable2, hipStream_t stream) {
+    const bool dual = dtable2 != nullptr;
+    const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
+    const BinMeta bm = make_bin_meta(bins_ws, n_points);
+    const LevelSet lv = make_level_set(grid);
     SlabPlan plan{};
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) plan.parts[l] = 1;
     plan.headroom_bits = 4;                  // 8 corners per point (+1)
     while ((1ll << (plan.headroom_bits - 4)) < n_points) ++plan.headroom_bits;
     const int64_t r_pad = (n_rays + 63) / 64 * 64;
     int total = 0, zero_lo = -1, zero_hi = -1;
-    const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/64)
+    const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
     for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
         plan.first[l] = total;
         if (l >= grid->n_levels) continue;
-        const int slabs = (int)((grid->size[l] + kSlabEntries - 1) / kSlabEntries);
+        const int slabs = level_slabs(grid->size[l], sshift);
         int parts = 1;
         if (!grid->hashed[l] || slabs < 16) {
-            // dense / tiny level: each slab's list holds ~ P / slabs points, each touching up to 8 corners
-            const int64_t per_block = 2 * n_points / slabs;
+            // dense / tiny level: 4 pair items per point spread over few slabs -> split the slabs' lists
+            const int64_t per_block = 4 * n_points / slabs;
             parts = (int)((per_block + target - 1) / target);
             if (parts > kMaxParts) parts = kMaxParts;
             if (parts < 1) parts = 1;
@@ -384,13 +511,14 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     }
     if (zero_lo >= 0) {       // levels in between that have a sole owner are overwritten afterwards anyway
         const size_t first = grid->offset[zero_lo], last = (size_t)grid->offset[zero_hi] + grid->size[zero_hi];
-        if (hipMemsetAsync(dtable + 2ull * first, 0, sizeof(float) * 2ull * (last - first), stream) != hipSuccess)
+        if (hipMemsetAsync(dtable1 + 2ull * first, 0, sizeof(float) * 2ull * (last - first), stream) != hipSuccess)
+            return LS2FM_ERR_LAUNCH;
+        if (dual && hipMemsetAsync(dtable2 + 2ull * first, 0, sizeof(float) * 2ull * (last - first), stream) != hipSuccess)
             return LS2FM_ERR_LAUNCH;
     }
-    const LevelSet lv = make_level_set(grid);
-    if (second_order)
-        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, p_pad, rec, rpt, ray_bound, n_rays, r_pad, dtable);
+    if (dual)
+        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, ray_bound, n_rays, r_pad, dtable1, dtable2);
     else
-        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, p_pad, rec, rpt, ray_bound, n_rays, r_pad, dtable);
+        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, ray_bound, n_rays, r_pad, dtable1, nullptr);
     return ls2fm_launch_status();
 }

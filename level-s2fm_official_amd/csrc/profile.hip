@@ -11,7 +11,7 @@ namespace {
 
 const char* const kNames[LS2FM_PROF_COUNT] = {
     "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "-", "-",
-    "slab_scatter_sdf", "slab_scatter_rad", "finalize", "sdf_eval", "sphere_trace", "bin_build", "loss_head_fwd",
+    "slab_accumulate", "scatter_fill", "finalize", "sdf_eval", "sphere_trace", "bin_build", "loss_head_fwd",
     "loss_head_bwd", "wgrad_mlp", "pose_grad"};
 
 struct Span { int id; hipEvent_t a, b; };

@@ -153,12 +153,14 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- C ABI
-int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const uint32_t* keys, int64_t n_points, int64_t p_pad, float* bins_ws,
-                           hipStream_t stream);
+int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, int64_t n_points,
+                           float* bins_ws, int dual, hipStream_t stream);
 size_t ls2fm_bin_counts_bytes();
-int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, int64_t p_pad, const float* rec,
-                                 const float* rpt, bool second_order, const float* ray_bound, int64_t n_rays, float* dtable,
-                                 hipStream_t stream);
+int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
+                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt, int dual,
+                              hipStream_t stream);
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, const float* ray_bound,
+                                 int64_t n_rays, float* dtable1, float* dtable2, hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -192,14 +194,14 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
-    // fork 1: the per-slab item lists depend on the forward's keys only -> built on the side stream under shade_bwd
+    // fork 1: the per-slab item counts / offsets depend on the sample positions only -> side stream, under shade_bwd
     SideCtx sc;
     const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
                         hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
     ls2fm_prof_begin(LS2FM_PROF_BIN, gs);
     {
-        const int st = ls2fm_launch_bin_build(sdf_grid, reinterpret_cast<const uint32_t*>(ws + w.keys), w.p, P, ws + w.bins, gs);
+        const int st = ls2fm_launch_bin_build(sdf_grid, fc, center, ray, w.p, ws + w.bins, dual, gs);
         if (st != LS2FM_OK) return st;
     }
     ls2fm_prof_end(LS2FM_PROF_BIN, gs);
@@ -230,18 +232,17 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // hash-table gradients: LDS-owned slabs walking their binned item lists (bin_scatter.hip); tables overwritten in full
     if (forked && hipStreamWaitEvent(s, sc.mid, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;         // item lists ready
     {
+        // payloads sorted by slab, then one streaming pass per slab; dual field: both grids share geometry, hence items
+        ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
+        int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
+                                           ws + w.rpt, dual, s);
+        ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
+        if (st != LS2FM_OK) return st;
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
-        int st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, P, ws + w.rec1, ws + w.rpt, true, ws + w.smax, n_rays,
-                                              grads->sdf_table, s);
+        st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, ws + w.smax, n_rays, grads->sdf_table,
+                                          dual ? grads->rad_table : nullptr, s);
         ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
         if (st != LS2FM_OK) return st;
-        if (dual) {
-            ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
-            st = ls2fm_launch_slab_accumulate(rad_grid, ws + w.bins, w.p, P, ws + w.rec2, ws + w.rpt, false, ws + w.smax + 16 * w.r_pad,
-                                              n_rays, grads->rad_table, s);
-            ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
-            if (st != LS2FM_OK) return st;
-        }
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();

@@ -210,13 +210,14 @@ struct WsLayout {
     int64_t p, p_pad, r_pad;
     int l1, l2, dual;
     // forward -> backward
-    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, keys;
+    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2;
     // backward scratch
     int64_t rec1, rec2, rpt, bins, v, p3, gf, dz, gf2, dzr, renc, dexyz, dlen, mpart, wg, dbeta, smax;
     int64_t total;
 };
 
-constexpr int kSlabShift = 13;          // table-gradient scatter: 8192-entry slabs (slab_scatter.hip)
+constexpr int kSlabShift = 13;          // table-gradient scatter: 8192-entry slabs of one grid, or 4096-entry slabs of both
+static inline int ls2fm_slab_shift(int dual) { return dual ? kSlabShift - 1 : kSlabShift; }
 constexpr int kWgradMlpBlocks = 512;   // persistent workgroups of wgrad_mlp (2 per CU)
 int64_t ls2fm_wgrad_mlp_part_floats(int dual);
 
@@ -250,7 +251,6 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.rgbs = take(3 * P);
     w.fe = take(16 * P);
     w.fe2 = take(dual ? 16 * P : 0);
-    w.keys = take((int64_t)l1 * P); // uint32 per (level, point): slab-test key for the table-gradient scatter
     // scatter payload: per point {x y z | gn0 gn1 gn2 | - -} (32 B, 4 MB per 131072 points: L2-resident across all the
     // levels' slab workgroups) + per (level, point) {de0 de1 rr0 rr1} (SDF grid, 16 B) / {de0 de1} (second grid, 8 B)
     w.rpt = take(8 * P);

@@ -196,7 +196,7 @@ template <bool WITH_JAC>
 __global__ void __launch_bounds__(256)
 ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
                   const float* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks,
-                  float* __restrict__ enc, float* __restrict__ jac, uint32_t* __restrict__ keys) {
+                  float* __restrict__ enc, float* __restrict__ jac) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int l = xcd + 8 * (j / n_chunks);
     if (l >= lv.n_levels) return;
@@ -235,32 +235,6 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
             __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
             __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
         }
-    }
-    if (keys) {
-        // slab-test key of the gradient scatter (slab_scatter.hip): hashed power-of-two level -> the slab ids
-        // (entry index >> kSlabShift, 6 bits each) of the four (y,z) corner pairs; both x-corners of a pair lie in the
-        // same slab unless cx+1 crosses a slab-sized boundary.  Dense level -> first corner index.
-        // ~0u = "decide exactly in the process phase".
-        uint32_t cell[3];
-        float wd;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) pos_fract(x[a], lv.scale[l], cell[a], wd);
-        uint32_t key = 0xFFFFFFFFu;
-        const uint32_t res = lv.res[l], size = lv.size[l];
-        if (lv.hashed[l]) {
-            const uint32_t mask = size - 1u;
-            if ((size & mask) == 0u && (size >> kSlabShift) >= 1u && (size >> kSlabShift) <= 64u &&
-                ((cell[0] ^ (cell[0] + 1u)) >> kSlabShift) == 0u) {
-                const uint32_t y0 = cell[1] * LS2FM_PRIME_Y, y1 = (cell[1] + 1u) * LS2FM_PRIME_Y;
-                const uint32_t z0 = cell[2] * LS2FM_PRIME_Z, z1 = (cell[2] + 1u) * LS2FM_PRIME_Z;
-                key = (((cell[0] ^ y0 ^ z0) & mask) >> kSlabShift) | ((((cell[0] ^ y1 ^ z0) & mask) >> kSlabShift) << 6) |
-                      ((((cell[0] ^ y0 ^ z1) & mask) >> kSlabShift) << 12) | ((((cell[0] ^ y1 ^ z1) & mask) >> kSlabShift) << 18);
-            }
-        } else if (cell[0] < res && cell[1] < res && cell[2] < res) {
-            const uint32_t first = cell[0] + cell[1] * res + cell[2] * res * res;
-            if (first + 1u + res + res * res < size) key = first;
-        }
-        keys[(int64_t)l * p_pad + i] = key;
     }
 }
 
@@ -323,13 +297,12 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
     ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
     ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
-                                              n_chunks, ws + w.e1, ws + w.j1,
-                                              reinterpret_cast<uint32_t*>(ws + w.keys));
+                                              n_chunks, ws + w.e1, ws + w.j1);
     ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
     if (dual) {
         ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
         ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,
-                                                   n_chunks, ws + w.e2, nullptr, nullptr);
+                                                   n_chunks, ws + w.e2, nullptr);
         ls2fm_prof_end(LS2FM_PROF_ENCODE_RAD, s);
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join

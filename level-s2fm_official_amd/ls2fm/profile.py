@@ -39,7 +39,9 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
     wgrad_mn = 64 * 36 + 64 * 35 + 17 * 65 + 64 + 3 * 39 + (64 * 36 + 17 * 65 if dual else 0)
     return {
         "ray_encode_sdf": ("hbm", table_bytes), "ray_encode_rad": ("hbm", table_bytes),
-        "slab_scatter_sdf": ("hbm", table_bytes), "slab_scatter_rad": ("hbm", table_bytes),
+        # table-gradient scatter = scatter_fill (payload sort) + slab_accumulate; dual field: both grids in one pass
+        "slab_accumulate": ("hbm", table_bytes * (2 if dual else 1)),
+        "scatter_fill": ("hbm", table_bytes * (2 if dual else 1)),
         "shade_fwd": ("mfma", 2 * fwd_macs * n_points), "shade_bwd": ("mfma", 2 * bwd_macs * n_points),
         "wgrad_mlp": ("mfma", 2 * wgrad_mn * n_points),
     }
