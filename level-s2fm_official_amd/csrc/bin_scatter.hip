@@ -60,6 +60,7 @@ struct BinMeta {           // device arrays inside the workspace
                            //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
                            //                      order is deterministic
     Item* items;
+    float* level_bound;    // [32] max over rays of the per-ray contribution bounds (rows 0..15 SDF grid, 16..31 second grid)
     int n_tiles;
 };
 
@@ -221,7 +222,8 @@ template <bool DUAL>
 __global__ void __launch_bounds__(kFillThreads)
 scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
                     int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
-                    const float* __restrict__ rec2, BinMeta bm) {
+                    const float* __restrict__ rec2, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad,
+                    BinMeta bm) {
     __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
     __shared__ int lds_off[kBins];       // first LDS slot of the slab's run
     __shared__ int base[kBins];          // first global item index of the slab's run
@@ -307,6 +309,26 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     // runs of one slab are contiguous in LDS and in memory: consecutive threads write consecutive 32-byte items
     const int staged = s_total < kFillCap ? s_total : kFillCap;
     for (int q = tid; q < staged; q += kFillThreads) bm.items[s_gidx[q]] = s_items[q];
+    // the level's first workgroup also reduces the per-ray bounds of a single contribution (written by shade_bwd) to the
+    // level's bound: the accumulate workgroups read two floats instead of n_rays each
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(hist);
+        for (int which = 0; which < (DUAL ? 2 : 1); ++which) {
+            float b = 0.f;
+            for (int64_t r = tid; r < n_rays; r += kFillThreads) b = fmaxf(b, ray_bound[(int64_t)(16 * which + l) * r_pad + r]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+            if (lane == 0) red[tid >> 6] = b;
+            __syncthreads();
+            if (tid == 0) {
+                float m = 0.f;
+                for (int q = 0; q < kFillThreads / 64; ++q) m = fmaxf(m, red[q]);
+                bm.level_bound[16 * which + l] = m;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -333,12 +355,11 @@ __device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float
 
 template <bool DUAL>
 __global__ void __launch_bounds__(kAccThreads)
-slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, const float* __restrict__ ray_bound,
-                       int64_t n_rays, int64_t r_pad, float* __restrict__ dtable1, float* __restrict__ dtable2) {
+slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
+                       float* __restrict__ dtable2) {
     constexpr int F = DUAL ? 4 : 2;
     __shared__ u64 acc[kAccSlots];
-    __shared__ float s_bound[2][kAccThreads / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     int l = 0;
     while ((int)blockIdx.x >= plan.first[l + 1]) ++l;
     const int parts = plan.parts[l];
@@ -349,54 +370,47 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, const
     const uint32_t lo = slab << sshift;
     const uint32_t hi = lo + (1u << sshift) < size ? lo + (1u << sshift) : size;
 
-    // bound of a single contribution on this level = max over rays (written per ray by shade_bwd); second grid: rows 16..31
-    {
-        float b1 = 0.f, b2 = 0.f;
-        for (int64_t r = tid; r < n_rays; r += kAccThreads) {
-            b1 = fmaxf(b1, ray_bound[(int64_t)l * r_pad + r]);
-            if (DUAL) b2 = fmaxf(b2, ray_bound[(int64_t)(16 + l) * r_pad + r]);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { b1 = fmaxf(b1, __shfl_xor(b1, o, 64)); b2 = fmaxf(b2, __shfl_xor(b2, o, 64)); }
-        if (lane == 0) { s_bound[0][wave] = b1; s_bound[1][wave] = b2; }
+    // this workgroup's share of the slab's payload list; the first trip's loads are issued before the LDS is zeroed
+    const int n_items = bm.count[l * kBins + slab];
+    const Item* __restrict__ list = bm.items + bm.start[l * kBins + slab];
+    const int j_lo = (int)((int64_t)n_items * part / parts), j_hi = (int)((int64_t)n_items * (part + 1) / parts);
+    uint4 q0 = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u), q1 = make_uint4(0u, 0u, 0u, 0u);
+    if (j_lo + tid < j_hi) {
+        q0 = reinterpret_cast<const uint4*>(list + j_lo + tid)[0];
+        q1 = reinterpret_cast<const uint4*>(list + j_lo + tid)[1];
     }
     const int n_slots = F * (int)(hi - lo);
     for (int e = tid; e < n_slots; e += kAccThreads) acc[e] = 0ull;
-    __syncthreads();
-    float bound1 = 0.f, bound2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < kAccThreads / 64; ++q) { bound1 = fmaxf(bound1, s_bound[0][q]); bound2 = fmaxf(bound2, s_bound[1][q]); }
+    // bound of a single contribution on this level (reduced over the rays by scatter_fill); second grid: rows 16..31
     float to_fixed1, to_fixed2;
     double to_float1, to_float2;
-    quantum_of(bound1, plan.headroom_bits, to_fixed1, to_float1);
-    quantum_of(bound2, plan.headroom_bits, to_fixed2, to_float2);
+    quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
+    quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
+    __syncthreads();
 
-    // this workgroup's share of the slab's payload list: streamed, 32 bytes per lane, fully coalesced
-    {
-        const int n = bm.count[l * kBins + slab];
-        const Item* __restrict__ list = bm.items + bm.start[l * kBins + slab];
-        const int j_lo = (int)((int64_t)n * part / parts), j_hi = (int)((int64_t)n * (part + 1) / parts);
-        for (int j = j_lo + tid; j < j_hi; j += kAccThreads) {
-            const uint4 q0 = reinterpret_cast<const uint4*>(list + j)[0];
-            const uint4 q1 = reinterpret_cast<const uint4*>(list + j)[1];
-            const uint32_t i0 = q0.x & 0xFFFFu, i1 = q0.x >> 16;
-            const float wx = __uint_as_float(q0.y);
-            const float a0 = __uint_as_float(q0.z), a1 = __uint_as_float(q0.w);
-            const float b0 = __uint_as_float(q1.x), b1 = __uint_as_float(q1.y);
-            const float c0 = __uint_as_float(q1.z), c1 = __uint_as_float(q1.w);
-            const float px0 = 1.0f - wx;
-            if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
-                u64* slot = acc + F * i0;
-                add_fixed(slot + 0, fmaf(px0, a0, -b0), to_fixed1);
-                add_fixed(slot + 1, fmaf(px0, a1, -b1), to_fixed1);
-                if (DUAL) { add_fixed(slot + 2, px0 * c0, to_fixed2); add_fixed(slot + 3, px0 * c1, to_fixed2); }
-            }
-            if (i1 != 0xFFFFu) {                             // x-corner 1: px = wx, derivative sign +
-                u64* slot = acc + F * i1;
-                add_fixed(slot + 0, fmaf(wx, a0, b0), to_fixed1);
-                add_fixed(slot + 1, fmaf(wx, a1, b1), to_fixed1);
-                if (DUAL) { add_fixed(slot + 2, wx * c0, to_fixed2); add_fixed(slot + 3, wx * c1, to_fixed2); }
-            }
+    // streamed, 32 bytes per lane, fully coalesced
+    for (int j = j_lo + tid; j < j_hi; j += kAccThreads) {
+        if (j != j_lo + tid) {
+            q0 = reinterpret_cast<const uint4*>(list + j)[0];
+            q1 = reinterpret_cast<const uint4*>(list + j)[1];
+        }
+        const uint32_t i0 = q0.x & 0xFFFFu, i1 = q0.x >> 16;
+        const float wx = __uint_as_float(q0.y);
+        const float a0 = __uint_as_float(q0.z), a1 = __uint_as_float(q0.w);
+        const float b0 = __uint_as_float(q1.x), b1 = __uint_as_float(q1.y);
+        const float c0 = __uint_as_float(q1.z), c1 = __uint_as_float(q1.w);
+        const float px0 = 1.0f - wx;
+        if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
+            u64* slot = acc + F * i0;
+            add_fixed(slot + 0, fmaf(px0, a0, -b0), to_fixed1);
+            add_fixed(slot + 1, fmaf(px0, a1, -b1), to_fixed1);
+            if (DUAL) { add_fixed(slot + 2, px0 * c0, to_fixed2); add_fixed(slot + 3, px0 * c1, to_fixed2); }
+        }
+        if (i1 != 0xFFFFu) {                             // x-corner 1: px = wx, derivative sign +
+            u64* slot = acc + F * i1;
+            add_fixed(slot + 0, fmaf(wx, a0, b0), to_fixed1);
+            add_fixed(slot + 1, fmaf(wx, a1, b1), to_fixed1);
+            if (DUAL) { add_fixed(slot + 2, wx * c0, to_fixed2); add_fixed(slot + 3, wx * c1, to_fixed2); }
         }
     }
     __syncthreads();
@@ -418,7 +432,7 @@ static_assert(kCountThreads == kFillThreads, "count and fill classify the same t
 
 int64_t meta_ints(int64_t n_points) {
     const int64_t n_tiles = (n_points + kFillTile - 1) / kFillTile;
-    return (2 * LS2FM_MAX_LEVELS * kBins + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
+    return (2 * LS2FM_MAX_LEVELS * kBins + 64 + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
 }
 
 BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
@@ -427,7 +441,8 @@ BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     bm.n_tiles = (int)((n_points + kFillTile - 1) / kFillTile);
     bm.count = meta;
     bm.start = meta + LS2FM_MAX_LEVELS * kBins;
-    bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins;
+    bm.level_bound = reinterpret_cast<float*>(meta + 2 * LS2FM_MAX_LEVELS * kBins);
+    bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
     bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points));      // 256-byte aligned
     return bm;
 }
@@ -464,21 +479,22 @@ int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const FieldC& fc, const 
 
 // payloads from shade_bwd's records, sorted by slab
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
-                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt, int dual,
-                              hipStream_t stream) {
+                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream) {
+    const int64_t r_pad = (n_rays + 63) / 64 * 64;
     const int sshift = ls2fm_slab_shift(dual);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
     const dim3 g((unsigned)bm.n_tiles, (unsigned)grid->n_levels);
-    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, bm);
-    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, bm);
+    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm);
+    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm);
     return ls2fm_launch_status();
 }
 
 // dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid.
 // ray_bound: [32][r_pad] per-ray bounds of a single contribution (rows 0..15 SDF grid, 16..31 second grid).
-int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, const float* ray_bound,
-                                 int64_t n_rays, float* dtable1, float* dtable2, hipStream_t stream) {
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
+                                 hipStream_t stream) {
     const bool dual = dtable2 != nullptr;
     const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
@@ -487,7 +503,6 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) plan.parts[l] = 1;
     plan.headroom_bits = 4;                  // 8 corners per point (+1)
     while ((1ll << (plan.headroom_bits - 4)) < n_points) ++plan.headroom_bits;
-    const int64_t r_pad = (n_rays + 63) / 64 * 64;
     int total = 0, zero_lo = -1, zero_hi = -1;
     const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
     for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
@@ -517,8 +532,8 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
             return LS2FM_ERR_LAUNCH;
     }
     if (dual)
-        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, ray_bound, n_rays, r_pad, dtable1, dtable2);
+        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, dtable1, dtable2);
     else
-        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, ray_bound, n_rays, r_pad, dtable1, nullptr);
+        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, dtable1, nullptr);
     return ls2fm_launch_status();
 }

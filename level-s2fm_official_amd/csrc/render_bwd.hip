@@ -157,10 +157,10 @@ int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const FieldC& fc, const 
                            float* bins_ws, int dual, hipStream_t stream);
 size_t ls2fm_bin_counts_bytes();
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
-                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt, int dual,
-                              hipStream_t stream);
-int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, const float* ray_bound,
-                                 int64_t n_rays, float* dtable1, float* dtable2, hipStream_t stream);
+                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream);
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
+                                 hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -235,12 +235,11 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         // payloads sorted by slab, then one streaming pass per slab; dual field: both grids share geometry, hence items
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
         int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
-                                           ws + w.rpt, dual, s);
+                                           ws + w.rpt, ws + w.smax, n_rays, dual, s);
         ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
         if (st != LS2FM_OK) return st;
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
-        st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, ws + w.smax, n_rays, grads->sdf_table,
-                                          dual ? grads->rad_table : nullptr, s);
+        st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s);
         ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
         if (st != LS2FM_OK) return st;
     }
