@@ -491,22 +491,25 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
     return ls2fm_launch_status();
 }
 
-// dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid.
-// ray_bound: [32][r_pad] per-ray bounds of a single contribution (rows 0..15 SDF grid, 16..31 second grid).
-int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream) {
-    const bool dual = dtable2 != nullptr;
-    const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
-    const BinMeta bm = make_bin_meta(bins_ws, n_points);
-    const LevelSet lv = make_level_set(grid);
-    SlabPlan plan{};
-    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) plan.parts[l] = 1;
-    plan.headroom_bits = 4;                  // 8 corners per point (+1)
-    while ((1ll << (plan.headroom_bits - 4)) < n_points) ++plan.headroom_bits;
-    int total = 0, zero_lo = -1, zero_hi = -1;
+namespace {
+// one launch for both tables (a hipMemsetAsync per table and range is several launches on the critical path)
+__global__ void __launch_bounds__(256)
+zero_ranges_kernel(float4* __restrict__ a, float4* __restrict__ b, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) (blockIdx.y ? b : a)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+struct HostPlan { SlabPlan plan; int total, zero_lo, zero_hi; };
+
+HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift) {
+    HostPlan h{};
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) h.plan.parts[l] = 1;
+    h.plan.headroom_bits = 4;                // 8 corners per point (+1)
+    while ((1ll << (h.plan.headroom_bits - 4)) < n_points) ++h.plan.headroom_bits;
+    h.zero_lo = h.zero_hi = -1;
     const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
     for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
-        plan.first[l] = total;
+        h.plan.first[l] = h.total;
         if (l >= grid->n_levels) continue;
         const int slabs = level_slabs(grid->size[l], sshift);
         int parts = 1;
@@ -517,23 +520,42 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
             if (parts > kMaxParts) parts = kMaxParts;
             if (parts < 1) parts = 1;
         }
-        plan.parts[l] = parts;
-        if (parts > 1) {      // atomically flushed level: zeroed first (one memset over the range of such levels)
-            if (zero_lo < 0) zero_lo = l;
-            zero_hi = l;
+        h.plan.parts[l] = parts;
+        if (parts > 1) {      // atomically flushed level: zeroed first (one range covering all such levels)
+            if (h.zero_lo < 0) h.zero_lo = l;
+            h.zero_hi = l;
         }
-        total += slabs * parts;
+        h.total += slabs * parts;
     }
-    if (zero_lo >= 0) {       // levels in between that have a sole owner are overwritten afterwards anyway
-        const size_t first = grid->offset[zero_lo], last = (size_t)grid->offset[zero_hi] + grid->size[zero_hi];
-        if (hipMemsetAsync(dtable1 + 2ull * first, 0, sizeof(float) * 2ull * (last - first), stream) != hipSuccess)
-            return LS2FM_ERR_LAUNCH;
-        if (dual && hipMemsetAsync(dtable2 + 2ull * first, 0, sizeof(float) * 2ull * (last - first), stream) != hipSuccess)
-            return LS2FM_ERR_LAUNCH;
-    }
+    return h;
+}
+}  // namespace
+
+// the point-split coarse levels are flushed with float atomics: their range of the gradient table(s) is zeroed first --
+// one small kernel, enqueued at the start of the backward
+int ls2fm_launch_scatter_zero(const ls2fm_grid_desc* grid, int64_t n_points, float* dtable1, float* dtable2, hipStream_t stream) {
+    const bool dual = dtable2 != nullptr;
+    const HostPlan h = make_plan(grid, n_points, ls2fm_slab_shift(dual ? 1 : 0));
+    if (h.zero_lo < 0) return LS2FM_OK;      // levels in between that have a sole owner are overwritten afterwards anyway
+    const size_t first = grid->offset[h.zero_lo], last = (size_t)grid->offset[h.zero_hi] + grid->size[h.zero_hi];
+    const int64_t n4 = (int64_t)(last - first) / 2;          // float4s per table (level offsets are multiples of 8 entries)
+    zero_ranges_kernel<<<dim3((unsigned)((n4 + 255) / 256), dual ? 2 : 1), 256, 0, stream>>>(
+        reinterpret_cast<float4*>(dtable1 + 2ull * first), dual ? reinterpret_cast<float4*>(dtable2 + 2ull * first) : nullptr, n4);
+    return ls2fm_launch_status();
+}
+
+// dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid; ls2fm_launch_scatter_zero must
+// have run on them before.
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
+                                 hipStream_t stream) {
+    const bool dual = dtable2 != nullptr;
+    const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
+    const BinMeta bm = make_bin_meta(bins_ws, n_points);
+    const LevelSet lv = make_level_set(grid);
+    const HostPlan h = make_plan(grid, n_points, sshift);
     if (dual)
-        slab_accumulate_kernel<true><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, dtable1, dtable2);
+        slab_accumulate_kernel<true><<<h.total, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, dtable2);
     else
-        slab_accumulate_kernel<false><<<total, kAccThreads, 0, stream>>>(lv, plan, bm, sshift, dtable1, nullptr);
+        slab_accumulate_kernel<false><<<h.total, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, nullptr);
     return ls2fm_launch_status();
 }

@@ -161,6 +161,7 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
                                  hipStream_t stream);
+int ls2fm_launch_scatter_zero(const ls2fm_grid_desc* grid, int64_t n_points, float* dtable1, float* dtable2, hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -191,6 +192,10 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // one memset: reduced weight gradients, the d beta accumulator and the bin counters are adjacent in the workspace
     if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.bins - w.wg) + ls2fm_bin_counts_bytes(), s) != hipSuccess)
         return LS2FM_ERR_LAUNCH;
+    {   // the point-split coarse levels of the gradient table(s) are zeroed up front (one small launch)
+        const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s);
+        if (st != LS2FM_OK) return st;
+    }
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
