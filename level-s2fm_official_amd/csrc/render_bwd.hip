@@ -225,9 +225,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // fork 2: weight-gradient GEMM -> reduce -> finalize run on the side stream, concurrently with the table scatters
     if (forked && (hipEventRecord(sc.fork, s) != hipSuccess || hipStreamWaitEvent(sc.side, sc.fork, 0) != hipSuccess))
         return LS2FM_ERR_LAUNCH;
-    ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, gs);
     ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
-    ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, gs);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     finalize_kernel<<<7, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
                                        ws + w.dbeta);

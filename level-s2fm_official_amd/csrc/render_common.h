@@ -12,7 +12,7 @@
 // opt-in per-kernel timing (profile.hip): a mark before every launch, a mark with id -1 at the end of a call
 enum ls2fm_prof_id {
     LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
-    LS2FM_PROF_RESERVED0, LS2FM_PROF_RESERVED1, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
+    LS2FM_PROF_WGRAD_GEO, LS2FM_PROF_WGRAD_TAIL, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
     LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_BIN, LS2FM_PROF_LOSS_FWD,
     LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_POSE, LS2FM_PROF_COUNT
 };

@@ -362,10 +362,18 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
     float* part1 = ws + w.mpart;
     float* part2 = part1 + (int64_t)kWgradMlpBlocks * 64 * kRegsSdf;
     float* part3 = part2 + (int64_t)kWgradMlpBlocks * 64 * (dual ? kRegsGeo : 0);
+    ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, s);
     wgrad_mlp_kernel<false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles);
-    if (dual) wgrad_mlp_kernel<true><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles);
+    ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
+    if (dual) {
+        ls2fm_prof_begin(LS2FM_PROF_WGRAD_GEO, s);
+        wgrad_mlp_kernel<true><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles);
+        ls2fm_prof_end(LS2FM_PROF_WGRAD_GEO, s);
+    }
+    ls2fm_prof_begin(LS2FM_PROF_WGRAD_TAIL, s);
     wgrad_dec_kernel<<<dec_blocks, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3);
     wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(part1, part2, part3, blocks,
                                                                                              dec_blocks, dual, ws + w.wg);
+    ls2fm_prof_end(LS2FM_PROF_WGRAD_TAIL, s);
     return LS2FM_OK;
 }

@@ -8,9 +8,9 @@ x 4 B = 64 B per level per point):
   shade_fwd       : P * 2 * MACs  (SDF MLP 35*64 + 64*17, normal W0^T 35*64 + 96, second field 35*64 + 64*17,
                     collapsed radiance 3*38)                                    -> f32 MFMA/VALU roofline
   shade_bwd       : P * 2 * MACs  (a, q, dE, r: 4 * 35*64; W1^T g 17*64; second field 2 * 35*64 + 16*64)
-  wgrad_mlp       : 2 * P * sum(M*N) over the weight-gradient GEMMs (f32 MFMA); the span covers its four kernels
-                    (SDF MLP, second MLP, decoder columns, partial sum).  The hidden-layer re-derivation it performs
-                    instead of reading operands back from HBM is NOT counted as algorithmic work.
+  wgrad_mlp_*     : 2 * P * sum(M*N) over the weight-gradient GEMMs of that MLP (f32 MFMA).  The hidden-layer
+                    re-derivation the kernel performs instead of reading operands back from HBM is NOT counted as
+                    algorithmic work.  (wgrad_dec_reduce: decoder columns + the partial sums of all three.)
 While the profiler is enabled the library launches serially (no side-stream overlap), so every span is the duration of
 that kernel alone and agrees with rocprofv3's per-kernel averages.
 """
@@ -43,7 +43,8 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
         "slab_accumulate": ("hbm", table_bytes * (2 if dual else 1)),
         "scatter_fill": ("hbm", table_bytes * (2 if dual else 1)),
         "shade_fwd": ("mfma", 2 * fwd_macs * n_points), "shade_bwd": ("mfma", 2 * bwd_macs * n_points),
-        "wgrad_mlp": ("mfma", 2 * wgrad_mn * n_points),
+        "wgrad_mlp_sdf": ("mfma", 2 * (64 * 36 + 64 * 35 + 17 * 65 + 64) * n_points),
+        "wgrad_mlp_geo": ("mfma", 2 * (64 * 36 + 17 * 65) * n_points),
     }
 
 
