@@ -94,6 +94,9 @@ typedef struct ls2fm_params {
     const float* rad_table;             /* RadF.embed_fn.embedder_obj.params (dual field) or NULL */
     ls2fm_linear geo_mlp[2];            /* RadF.Geo_enc.mlp.{0,1} (dual field) */
     ls2fm_linear rad_mlp[3];            /* RadF.Rad_dec.mlp_radiance.{0,1,2}: (49|65)->64->64->3 */
+    const float* dual_table;            /* optional (dual field): both tables entry-interleaved, [n_entries][4] =
+                                           {sdf f0, sdf f1, rad f0, rad f1}, as ls2fm_interleave_tables writes it and in
+                                           sync with sdf_table / rad_table; NULL: gather from the two tables */
 } ls2fm_params;
 
 typedef struct ls2fm_param_grads {      /* mirrors ls2fm_params */
@@ -172,6 +175,12 @@ int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, c
  * for the same inputs, so it must be kept untouched between the two calls.
  */
 int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n_rays);
+/* Dual field, optional: write both hash tables (same geometry, [n_entries][2] each) entry-interleaved into
+ * dual_table [n_entries][4] for ls2fm_params.dual_table.  The forward then gathers ONE 16-byte entry per corner for both
+ * encodings instead of two 8-byte ones (the gathers are request-rate bound).  The caller owns the
+ * buffer and refreshes it whenever either table changed (the host side keys it on the parameters' version counters). */
+int ls2fm_interleave_tables(const float* sdf_table, const float* rad_table, int64_t n_entries, float* dual_table,
+                            void* stream);
 int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                      const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
                      const float* ray, int64_t n_rays, float* rgb, float* sdfs_volume, float* normals,

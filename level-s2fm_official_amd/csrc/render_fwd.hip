@@ -238,8 +238,79 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
     }
 }
 
+// Dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner serves both
+// grids -- the gathers are bound by the L2->L1 request rate, not by bytes, so this halves the cost of the two encodes.
+__global__ void __launch_bounds__(256)
+ray_encode_dual_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
+                       const float4* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks,
+                       float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int l = xcd + 8 * (j / n_chunks);
+    if (l >= lv.n_levels) return;
+    const int64_t i = (int64_t)(j % n_chunks) * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    const int64_t r = i / fc.n_samples;
+    const int n = (int)(i - r * fc.n_samples);
+    const RayGeom g = load_ray(fc, center, ray, r);
+    float p[3], x[3];
+    sample_position(fc, g, sample_depth(g, n, fc.n_samples), p, x);
+    Cell c;
+    locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = table[c.idx[k]];
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float wt = corner_weight(c.w, k);
+        y0 = fmaf(wt, v[k].x, y0);
+        y1 = fmaf(wt, v[k].y, y1);
+        y2 = fmaf(wt, v[k].z, y2);
+        y3 = fmaf(wt, v[k].w, y3);
+    }
+    __builtin_nontemporal_store(y0, enc1 + (2 * l + 0) * p_pad + i);
+    __builtin_nontemporal_store(y1, enc1 + (2 * l + 1) * p_pad + i);
+    __builtin_nontemporal_store(y2, enc2 + (2 * l + 0) * p_pad + i);
+    __builtin_nontemporal_store(y3, enc2 + (2 * l + 1) * p_pad + i);
+#pragma unroll
+    for (int gd = 0; gd < 3; ++gd) {
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float dw = corner_dweight(c.w, k, gd);
+            g0 = fmaf(dw, v[k].x, g0);
+            g1 = fmaf(dw, v[k].y, g1);
+        }
+        __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+        __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+interleave_tables_kernel(const float2* __restrict__ a, const float2* __restrict__ b, float4* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 512 + 2 * threadIdx.x;      // two entries per thread: 16-byte loads
+    if (i + 1 < n) {
+        const float4 va = *reinterpret_cast<const float4*>(a + i), vb = *reinterpret_cast<const float4*>(b + i);
+        out[i] = make_float4(va.x, va.y, vb.x, vb.y);
+        out[i + 1] = make_float4(va.z, va.w, vb.z, vb.w);
+    } else if (i < n) {
+        out[i] = make_float4(a[i].x, a[i].y, b[i].x, b[i].y);
+    }
+}
 
 }  // namespace
+
+extern "C" int ls2fm_interleave_tables(const float* sdf_table, const float* rad_table, int64_t n_entries, float* dual_table,
+                                       void* stream) {
+    LS2FM_CHECK_ARG(n_entries >= 0 && (n_entries == 0 || (sdf_table && rad_table && dual_table)));
+    LS2FM_CHECK_ARG(((reinterpret_cast<uintptr_t>(sdf_table) | reinterpret_cast<uintptr_t>(rad_table) |
+                      reinterpret_cast<uintptr_t>(dual_table)) & 15u) == 0);
+    if (n_entries == 0) return LS2FM_OK;
+    interleave_tables_kernel<<<(unsigned)((n_entries + 511) / 512), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float2*>(sdf_table), reinterpret_cast<const float2*>(rad_table),
+        reinterpret_cast<float4*>(dual_table), n_entries);
+    return ls2fm_launch_status();
+}
 
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
 int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream) {
@@ -295,11 +366,17 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
     const int n_chunks = (int)((w.p + 255) / 256);
     const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
+    const bool interleaved = dual && params->dual_table;
     ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
-    ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
-                                              n_chunks, ws + w.e1, ws + w.j1);
+    if (interleaved)
+        ray_encode_dual_kernel<<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray,
+                                                  reinterpret_cast<const float4*>(params->dual_table), w.p, w.p_pad, n_chunks,
+                                                  ws + w.e1, ws + w.e2, ws + w.j1);
+    else
+        ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
+                                                  n_chunks, ws + w.e1, ws + w.j1);
     ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
-    if (dual) {
+    if (dual && !interleaved) {
         ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
         ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,
                                                    n_chunks, ws + w.e2, nullptr);

@@ -61,6 +61,7 @@ class Params(Structure):
         ("rad_table", c_void_p),
         ("geo_mlp", Linear * 2),
         ("rad_mlp", Linear * 3),
+        ("dual_table", c_void_p),
     ]
 
 
@@ -89,6 +90,7 @@ _SIGNATURES = {
     "ls2fm_sdf_eval": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P,
                                  _P, _P]),
     "ls2fm_render_workspace_bytes": (c_int64, [POINTER(FieldDesc), POINTER(GridDesc), c_int64]),
+    "ls2fm_interleave_tables": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ls2fm_render_fwd": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(GridDesc), POINTER(Params), _P, _P,
                                    c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "ls2fm_render_bwd": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(GridDesc), POINTER(Params), _P, _P,

@@ -20,6 +20,15 @@ from ._lib import check, ptr, stream_ptr
 
 _DISABLE = os.environ.get("LS2FM_DISABLE_FUSED", "0") == "1"
 _POISON = os.environ.get("LS2FM_POISON_WS", "0") == "1"
+# dual field, opt-in: keep an entry-interleaved copy of the two hash tables so the forward gathers 16 B once per corner
+# instead of 8 B twice (encodes 161 -> 122 us at the benchmark).  The copy costs ~45 us to rebuild, so it only pays when
+# the tables change less often than they are rendered (evaluation renders, frozen fields); a training loop that steps the
+# tables after every backward is faster without it -- hence "off" by default.  "version": refreshed when either parameter's
+# version counter or storage changed (optimizer steps, load_state_dict, any in-place op on the parameter); "always":
+# refreshed on every forward (for code that writes the tables behind autograd's back, e.g. through `.data`).
+_DUAL_TABLE = os.environ.get("LS2FM_DUAL_TABLE", "off")
+if _DUAL_TABLE not in ("version", "always", "off"):
+    raise RuntimeError(f"LS2FM_DUAL_TABLE={_DUAL_TABLE!r}: expected version, always or off")
 
 
 # ------------------------------------------------------------------------------------------------ gating
@@ -50,6 +59,10 @@ def supported(opt, sdf_field, rad_field=None) -> bool:
     if opt.SDF.VolSDF.volsdf_sampling != False or not 1 <= int(opt.SDF.VolSDF.sample_intvs) <= 512:  # noqa: E712
         return False
     dual = opt.Ablate_config.dual_field == True  # noqa: E712
+    # the table-gradient scatter sorts into at most 128 slabs per level (csrc/bin_scatter.hip: 8192-entry slabs, 4096 when
+    # both grids share a pass): tables up to 2^20 (2^19 dual) entries per level; larger ones take the composed form
+    if max(desc.size[:desc.n_levels]) > (128 << (12 if dual else 13)):
+        return False
     if dual:
         d2 = rad_field.embed_fn.embedder_obj.desc
         if d2.n_levels != desc.n_levels or not _geometry_ok(rad_field.Geo_enc, 3 + 2 * d2.n_levels):
@@ -76,7 +89,7 @@ class _Plan:
     """Everything about one (renderer, SDF field, radiance field, opt) combination that does not change from call to
     call: the gating verdict, the descriptor structs, the parameter list.  Rebuilding these costs ~0.2 ms of Python
     per step -- as much as the device work of a kernel -- so they are cached and keyed on the option values read."""
-    __slots__ = ("key", "ok", "cfg", "ts", "ws_bytes", "pkey", "pstruct")
+    __slots__ = ("key", "ok", "cfg", "ts", "ws_bytes", "pkey", "pstruct", "dual_table", "dual_key")
 
 
 _PLANS = {}
@@ -92,7 +105,7 @@ def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
     pl = _Plan()
     pl.key = key
     pl.ok = supported(opt, sdf_field, rad_field)
-    pl.cfg = pl.ts = pl.pkey = pl.pstruct = None
+    pl.cfg = pl.ts = pl.pkey = pl.pstruct = pl.dual_table = pl.dual_key = None
     pl.ws_bytes = {}
     if pl.ok:
         ts, dual = param_tensors(sdf_field, rad_field)
@@ -190,6 +203,25 @@ def _is_table(p) -> bool:
     return p.dim() == 1 and p.numel() > 4096
 
 
+_RAD_TABLE_AT = 8        # param_tensors(): sdf table, 2 x (v, g, b), beta, rad table, ...
+
+
+def _refresh_dual_table(lib, plan, sdf_table, rad_table):
+    """(re)build the interleaved copy of the two tables when they changed (see _DUAL_TABLE)"""
+    key = (sdf_table.data_ptr(), rad_table.data_ptr(), sdf_table._version, rad_table._version)
+    if plan.dual_key == key and _DUAL_TABLE != "always":
+        return
+    if not (_is_table(sdf_table) and _is_table(rad_table) and sdf_table.numel() == rad_table.numel()):
+        raise RuntimeError("ls2fm: dual-field tables of different size")
+    if plan.dual_table is None or plan.dual_table.numel() != 2 * sdf_table.numel() or \
+            plan.dual_table.device != sdf_table.device:
+        plan.dual_table = torch.empty(2 * sdf_table.numel(), device=sdf_table.device, dtype=torch.float32)
+    check(lib.ls2fm_interleave_tables(ptr(sdf_table), ptr(rad_table), sdf_table.numel() // 2, ptr(plan.dual_table),
+                                      stream_ptr()), "ls2fm_interleave_tables")
+    plan.pstruct.dual_table = ptr(plan.dual_table)
+    plan.dual_key = key
+
+
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, center, ray, cfg, *params):
@@ -210,6 +242,9 @@ class _Render(torch.autograd.Function):
                     raise RuntimeError("ls2fm: fused render needs contiguous fp32 GPU parameters")
             plan.pstruct = _params_struct(ps, dual, beta_speed)
             plan.pkey = pkey
+            plan.dual_key = None
+        if dual and _DUAL_TABLE != "off":
+            _refresh_dual_table(lib, plan, ps[0], ps[_RAD_TABLE_AT])
         ws_bytes = plan.ws_bytes.get(n_rays)
         if ws_bytes is None:
             ws_bytes = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(g1), n_rays)

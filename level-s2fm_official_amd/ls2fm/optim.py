@@ -53,4 +53,6 @@ class FusedAdam(torch.optim.Optimizer):
                                                float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
                                                float(group["weight_decay"]), int(step), _lib.stream_ptr()),
                            "ls2fm_adam_step")
+                for p, _, _ in items:       # the kernel wrote through raw pointers: tell autograd (and every cache keyed
+                    torch.autograd.graph.increment_version(p)       # on Tensor._version, e.g. the interleaved tables)
         return loss

@@ -202,3 +202,44 @@ def test_fused_sharding_invariance_large_batch():
     for k in full:
         assert torch.isfinite(full[k]).all(), k
         assert rel_err(full[k], acc[k]) < (1e-4 if k == "beta" else 2e-5), k
+
+
+def test_interleaved_dual_table_is_bit_identical_and_tracks_updates(monkeypatch):
+    """LS2FM_DUAL_TABLE=version: the forward gathers from an entry-interleaved copy of the two tables.  Same arithmetic in
+    the same order -> bit-identical outputs and gradients; the copy follows optimizer steps (torch's and the fused Adam,
+    which writes through raw pointers and bumps the version counters itself) and load_state_dict."""
+    from ls2fm.optim import FusedAdam
+    opt = make_options("ETH3D", device=DEV, dual_field=True, sample_intvs=64)
+    sdf, rad, ren = _randomized(opt, 41)
+    center, ray = _rays(96, 5.0, 42)
+    tgt, nm = torch.rand(1, 96, 3, device=DEV), torch.tensor([0.1, 0.3, -0.2], device=DEV)
+
+    def run(mode):
+        monkeypatch.setattr(fused, "_DUAL_TABLE", mode)
+        sdf.zero_grad(); rad.zero_grad()
+        ret = ren.forward(opt, center, ray, sdf, rad)
+        losses.render_loss(ret, tgt, nm).backward()
+        return ({k: ret[k].detach().clone() for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp")},
+                {**named_grads(sdf), **{"r." + k: v for k, v in named_grads(rad).items()}})
+
+    def same(a, b):
+        for k in a[0]:
+            assert torch.equal(a[0][k], b[0][k]), k
+        for k in a[1]:
+            assert np.array_equal(np.asarray(a[1][k]), np.asarray(b[1][k])), k
+
+    same(run("off"), run("version"))
+    params = [p for m in (sdf, rad) for p in m.parameters()]
+    for make in (lambda: torch.optim.Adam(params, lr=1e-2), lambda: FusedAdam(params, lr=1e-2)):
+        run("version")
+        make().step()                       # moves both tables
+        same(run("version"), run("off"))
+    state = {k: v.clone() for k, v in rad.state_dict().items()}
+    with torch.no_grad():
+        rad.embed_fn.embedder_obj.params.mul_(0.5)
+    moved = run("version")
+    same(moved, run("off"))
+    rad.load_state_dict(state)
+    back = run("version")
+    same(back, run("off"))
+    assert not torch.equal(moved[0]["rgb"], back[0]["rgb"])

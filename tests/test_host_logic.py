@@ -36,7 +36,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.GridDesc) == 4 * (2 + 16 * 4 + 17)
     assert ctypes.sizeof(_lib.FieldDesc) == 4 * (3 + 3 + 1 + 1 + 1 + 1 + 1 + 3 + 1 + 1)
     assert ctypes.sizeof(_lib.Linear) == 24
-    assert ctypes.sizeof(_lib.Params) == 8 + 48 + 8 + 8 + 8 + 48 + 72
+    assert ctypes.sizeof(_lib.Params) == 8 + 48 + 8 + 8 + 8 + 48 + 72 + 8
     assert ctypes.sizeof(_lib.ParamGrads) == 8 + 48 + 8 + 8 + 48 + 72
 
 
