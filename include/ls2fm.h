@@ -162,6 +162,18 @@ int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, c
                    const float* p, int64_t n, float* sdf, float* feat, float* normal, void* workspace,
                    void* stream);
 
+/* No-grad SDF sweep over an n_side^3 lattice generated on the device: sdf[i] = infer_sdf(point(first + i)), i < count.
+ * Replaces: the batchify loop of extract_mesh (utils/util.py:411-424: 16 k-point chunks, each a host->device copy,
+ * infer_sdf, device->host copy) and its host-side numpy lattice (util.py:399-409).
+ * With idx = first + i:  ref_indexing != 0: column c of the point = fl32(f_c * step[c] + origin[c]) in fp64 with
+ * f = (fmod(idx/N/N, N), fmod(idx/N, N), idx mod N) under TRUE division -- exactly the reference's arithmetic (its first
+ * two index columns are fractional); ref_indexing == 0: f = integer lattice indices (idx div N^2, idx div N mod N,
+ * idx mod N).  workspace: ls2fm_sdf_eval_workspace_bytes().
+ */
+int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                     int64_t n_side, int64_t first, int64_t count, int32_t ref_indexing, const double* step,
+                     const double* origin, float* sdf, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused volumetric rendering, forward.
  * Replaces: Renderer.forward (models/Renderer.py:51-116) and everything it calls: ray/AABB near-far

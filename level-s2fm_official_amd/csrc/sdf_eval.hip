@@ -54,14 +54,47 @@ __device__ __forceinline__ float signed_sdf(const FieldC& fc, int bg_sdf, float 
     return sdf;
 }
 
+// Lattice of a volume sweep, generated on the device (ls2fm_sdf_volume).  ref_indexing reproduces the host arithmetic
+// of the reference's extract_mesh (utils/util.py:399-409), fp64 then rounded to fp32 like its `.float()`: with
+// idx = x N^2 + y N + z the reference divides with numpy's TRUE division, so the three index columns are
+// fmod(idx/N/N, N), fmod(idx/N, N), idx % N -- fractional in the first two (a sheared lattice), kept as is.
+struct Lattice {
+    int64_t n_side, first;
+    double step[3], origin[3];
+    int ref_indexing;
+};
+
+__device__ __forceinline__ void lattice_point(const Lattice& lat, int64_t i, float p[3]) {
+    const int64_t idx = lat.first + i;
+    const double n = (double)lat.n_side;
+    double f[3];
+    if (lat.ref_indexing) {
+        const double q = (double)idx / n;
+        f[0] = fmod(q / n, n);
+        f[1] = fmod(q, n);
+        f[2] = (double)(idx % lat.n_side);
+    } else {
+        f[0] = (double)(idx / (lat.n_side * lat.n_side));
+        f[1] = (double)((idx / lat.n_side) % lat.n_side);
+        f[2] = (double)(idx % lat.n_side);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = (float)(f[a] * lat.step[a] + lat.origin[a]);
+}
+
 template <bool WANT_NORMAL>
 __global__ void __launch_bounds__(256)
 sdf_eval_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
-                const float* __restrict__ table, const float* __restrict__ pts, int64_t n, float* __restrict__ sdf_out,
-                float* __restrict__ feat_out, float* __restrict__ normal_out) {
+                const float* __restrict__ table, const float* __restrict__ pts, Lattice lat, int64_t n,
+                float* __restrict__ sdf_out, float* __restrict__ feat_out, float* __restrict__ normal_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float p[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+    float p[3];
+    if (pts) {
+        p[0] = pts[i * 3]; p[1] = pts[i * 3 + 1]; p[2] = pts[i * 3 + 2];
+    } else {
+        lattice_point(lat, i, p);
+    }
     float u[kInMax], f[kOut], rr[kInMax];
     encode_point(lv, fc, table, p, u);
     geometry_forward<WANT_NORMAL>(pk->sdf, u, f, rr);
@@ -181,11 +214,39 @@ extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_de
     const unsigned blocks = (unsigned)((n + 255) / 256);
     ls2fm_prof_begin(LS2FM_PROF_SDF_EVAL, s);
     if (normal)
-        sdf_eval_kernel<true><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, n, sdf,
-                                                     feat, normal);
+        sdf_eval_kernel<true><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, Lattice{},
+                                                     n, sdf, feat, normal);
     else
-        sdf_eval_kernel<false><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, n, sdf,
-                                                      feat, nullptr);
+        sdf_eval_kernel<false><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, Lattice{},
+                                                      n, sdf, feat, nullptr);
+    ls2fm_prof_end(LS2FM_PROF_SDF_EVAL, s);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                int64_t n_side, int64_t first, int64_t count, int32_t ref_indexing, const double* step,
+                                const double* origin, float* sdf, void* workspace, void* stream) {
+    LS2FM_CHECK_ARG(field_ok(field, grid, params) && n_side >= 1 && n_side <= 2097151 && first >= 0 && count >= 0);
+    LS2FM_CHECK_ARG(first + count <= n_side * n_side * n_side && step && origin);
+    if (count == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(sdf);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Packed* pk = (Packed*)workspace;
+    int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
+    if (st != LS2FM_OK) return st;
+    Lattice lat;
+    lat.n_side = n_side; lat.first = first; lat.ref_indexing = ref_indexing ? 1 : 0;
+    for (int a = 0; a < 3; ++a) { lat.step[a] = step[a]; lat.origin[a] = origin[a]; }
+    const int64_t per_launch = (int64_t)1 << 30;           // grid.x stays below 2^31 / 256
+    ls2fm_prof_begin(LS2FM_PROF_SDF_EVAL, s);
+    for (int64_t at = 0; at < count; at += per_launch) {
+        const int64_t n = count - at < per_launch ? count - at : per_launch;
+        lat.first = first + at;
+        sdf_eval_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(make_level_set(grid), make_field_c(field), field->bg_sdf,
+                                                                           field->bg_rad, pk, params->sdf_table, nullptr, lat, n,
+                                                                           sdf + at, nullptr, nullptr);
+    }
     ls2fm_prof_end(LS2FM_PROF_SDF_EVAL, s);
     return ls2fm_launch_status();
 }

@@ -339,6 +339,28 @@ def sdf_eval(sdf_field, xyz, want_feat=False, want_normal=False):
     return out + (normal.view(*shape, 3),) if want_normal else out
 
 
+def sdf_volume(sdf_field, n_side, step, origin, first=0, count=None, reference_indexing=True):
+    """no-graph SDF sweep over an n_side^3 lattice built on the device (ls2fm_sdf_volume): flat float32 [count].
+    step / origin: 3 doubles each, per output column; reference_indexing: the lattice arithmetic of the reference's
+    extract_mesh (utils/util.py:399-409), else integer lattice indices."""
+    lib = _lib.load()
+    dev = sdf_field.beta.device
+    if dev.type != "cuda":
+        raise RuntimeError("ls2fm: the SDF sweep runs on the GPU only (no CPU fallback)")
+    n_side = int(n_side)
+    count = n_side ** 3 - first if count is None else int(count)
+    out = torch.empty(count, device=dev)
+    keep, pstruct = _sdf_only_params(sdf_field)
+    fdesc = field_desc(sdf_field.opt)
+    ws = _sdf_workspace(dev)
+    st = (ctypes.c_double * 3)(*[float(v) for v in step])
+    og = (ctypes.c_double * 3)(*[float(v) for v in origin])
+    check(lib.ls2fm_sdf_volume(ctypes.byref(fdesc), ctypes.byref(sdf_field.embed_fn.embedder_obj.desc), ctypes.byref(pstruct),
+                               n_side, int(first), count, 1 if reference_indexing else 0, st, og, ptr(out), ptr(ws),
+                               stream_ptr()), "ls2fm_sdf_volume")
+    return out
+
+
 def sphere_trace(sdf_field, o, d):
     """the reference's root-find loop (SDF.py:149-200) in one kernel.
     o, d [R,3] -> near [R], far [R], pts_tracks [R,K,3], t_end [R] (far-end distance after K trips), K"""

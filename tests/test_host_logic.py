@@ -145,3 +145,20 @@ def test_loss_head_and_fused_adam_have_no_cpu_path():
     p.grad = torch.ones(8)
     with pytest.raises(RuntimeError):
         FusedAdam([p]).step()
+
+
+def test_extract_mesh_lattice_is_the_references():
+    """utils/util.py:399-409 by hand: idx -> (fmod(idx/N/N, N), fmod(idx/N, N), idx % N) under true division, times
+    volume_size/(N-1), plus the origin in REVERSED column order"""
+    from ls2fm.utils import util
+    N, s = 8, 2.0
+    pts = util.lattice_points(s, N, bound_max=[1.0, 2.0, 3.0], bound_min=[-1.0, -2.0, -3.0])
+    assert pts.shape == (512, 3) and pts.dtype == np.float32
+    for idx in (0, 1, 9, 70, 511):
+        fx, fy, fz = ((idx / N) / N) % N, (idx / N) % N, idx % N
+        want = np.array([fx * (s / 7) - 3.0, fy * (s / 7) - 2.0, fz * (s / 7) - 1.0]).astype(np.float32)
+        assert np.array_equal(pts[idx], want), idx
+    reg = util.lattice_points(s, N, reference_indexing=False)
+    assert np.array_equal(reg[70], np.array([1 * s / 7 - 1, 0 * s / 7 - 1, 6 * s / 7 - 1]).astype(np.float32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        util.sdf_volume(SDF(make_options("DTU", device="cpu")), N=4)
