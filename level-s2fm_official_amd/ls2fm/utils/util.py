@@ -75,3 +75,54 @@ def extract_mesh(implicit_surface, log=None, volume_size=2.0, level=0.0, N=512, 
     if log is not None:
         log.info("saving mesh to %s" % str(filepath))
     return vol
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+# The reference's `model.ckpt` (utils/util.py:198-259): {epoch, iter, sdf_func, color_func, cam_info, pts3d_info,
+# optim_* / sched_*}.  SDF / RadF here expose the reference's state_dict keys and shapes, so its
+# checkpoints load into these classes and checkpoints written here load into the reference.
+def save_checkpoint_sfm(opt, model, ep, it, latest=False):
+    """utils/util.py:239-259"""
+    import os
+    import shutil
+    os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
+    cams = getattr(model, "camera_set", None)
+    pts = getattr(model, "point_set", None)
+    checkpoint = dict(
+        epoch=ep,
+        iter=it,
+        sdf_func=model.sdf_func.state_dict(),
+        color_func=model.color_func.state_dict(),
+        cam_info=cams.get_all_parameters() if cams is not None else None,
+        pts3d_info=pts.get_all_parameters() if pts is not None else None,
+    )
+    for key in model.__dict__:
+        if key.split("_")[0] in ["optim", "sched"]:
+            checkpoint.update({key: getattr(model, key).state_dict()})
+    torch.save(checkpoint, "{0}/model.ckpt".format(opt.output_path))
+    if not latest:
+        shutil.copy("{0}/model.ckpt".format(opt.output_path),
+                    "{0}/model/{1}.ckpt".format(opt.output_path, ep or it))   # ep None: track the iteration instead
+
+
+def restore_checkpoint_sfm(opt, model, load_name=None, resume=False):
+    """utils/util.py:198-218: (epoch, iteration) when resuming, else (None, None)"""
+    assert ((load_name is None) == (resume is not False))       # resume: True / False / an epoch or iteration number
+    if resume:
+        load_name = "{0}/model.ckpt".format(opt.output_path) if resume is True else \
+            "{0}/model/{1}.ckpt".format(opt.output_path, resume)
+    checkpoint = torch.load(load_name, map_location=opt.device, weights_only=False)
+    model.sdf_func.load_state_dict(checkpoint["sdf_func"], False)      # non-strict, like the reference
+    model.color_func.load_state_dict(checkpoint["color_func"])
+    model.cam_info_reloaded = checkpoint["cam_info"]
+    model.pts_info_reloaded = checkpoint["pts3d_info"]
+    for key in model.__dict__:
+        if key.split("_")[0] in ["optim", "sched"] and key in checkpoint and resume:
+            getattr(model, key).load_state_dict(checkpoint[key])
+    if resume:
+        ep, it = checkpoint["epoch"], checkpoint["iter"]
+        if resume is not True:
+            assert (resume == (ep or it))
+    else:
+        ep, it = None, None
+    return ep, it

@@ -162,3 +162,47 @@ def test_extract_mesh_lattice_is_the_references():
     assert np.array_equal(reg[70], np.array([1 * s / 7 - 1, 0 * s / 7 - 1, 6 * s / 7 - 1]).astype(np.float32))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         util.sdf_volume(SDF(make_options("DTU", device="cpu")), N=4)
+
+
+def test_checkpoint_layout_round_trip(tmp_path, manifest):
+    """model.ckpt in the reference's layout (utils/util.py:198-259): a checkpoint assembled key by key from the recorded
+    state_dict manifest of the reference loads; one written here has exactly those keys and restores optimizer state"""
+    from types import SimpleNamespace
+    from ls2fm.utils import util
+    opt = make_options("DTU", device="cpu", dual_field=True)
+    opt.output_path = str(tmp_path)
+    ref = manifest["_state_dict_full_dtu"]["dual"]
+    gen = torch.Generator().manual_seed(0)
+    ckpt = dict(epoch=None, iter=120,
+                sdf_func={k: torch.randn(*shape, generator=gen) for k, shape in ref["sdf"].items()},
+                color_func={k: torch.randn(*shape, generator=gen) for k, shape in ref["rad"].items()},
+                cam_info={"se3": torch.zeros(2, 6)}, pts3d_info=None)
+    torch.save(ckpt, tmp_path / "theirs.ckpt")
+    model = SimpleNamespace(sdf_func=SDF(opt), color_func=RadF(opt))
+    assert util.restore_checkpoint_sfm(opt, model, load_name=str(tmp_path / "theirs.ckpt")) == (None, None)
+    for k, v in model.sdf_func.state_dict().items():
+        assert torch.equal(v, ckpt["sdf_func"][k]), k
+    for k, v in model.color_func.state_dict().items():
+        assert torch.equal(v, ckpt["color_func"][k]), k
+    assert torch.equal(model.cam_info_reloaded["se3"], torch.zeros(2, 6))
+    # write -> read, with an optimizer and a scheduler riding along
+    model.optim_sdf = torch.optim.Adam(model.sdf_func.parameters(), lr=1e-3)
+    model.sched_sdf = torch.optim.lr_scheduler.ExponentialLR(model.optim_sdf, 0.9)
+    for p in model.sdf_func.parameters():
+        p.grad = torch.ones_like(p)
+    model.optim_sdf.step(); model.sched_sdf.step()
+    util.save_checkpoint_sfm(opt, model, ep=None, it=121, latest=False)
+    assert os.path.exists(tmp_path / "model.ckpt") and os.path.exists(tmp_path / "model" / "121.ckpt")
+    mine = torch.load(tmp_path / "model.ckpt", weights_only=False)
+    assert {k: list(v.shape) for k, v in mine["sdf_func"].items()} == ref["sdf"]
+    assert {k: list(v.shape) for k, v in mine["color_func"].items()} == ref["rad"]
+    assert set(mine) == {"epoch", "iter", "sdf_func", "color_func", "cam_info", "pts3d_info", "optim_sdf", "sched_sdf"}
+    other = SimpleNamespace(sdf_func=SDF(opt), color_func=RadF(opt))
+    other.optim_sdf = torch.optim.Adam(other.sdf_func.parameters(), lr=1e-3)
+    other.sched_sdf = torch.optim.lr_scheduler.ExponentialLR(other.optim_sdf, 0.9)
+    assert util.restore_checkpoint_sfm(opt, other, resume=True) == (None, 121)
+    assert util.restore_checkpoint_sfm(opt, other, resume=121) == (None, 121)
+    for (k, a), b in zip(other.sdf_func.state_dict().items(), model.sdf_func.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert other.optim_sdf.state_dict()["state"][0]["step"] == model.optim_sdf.state_dict()["state"][0]["step"]
+    assert other.sched_sdf.last_epoch == 1
