@@ -185,3 +185,15 @@ __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
     }
     return v;
 }
+
+// exclusive suffix sum across the 64 lanes: sum of v over the lanes above this one
+__device__ __forceinline__ float wave_suffix_excl(float v, int lane) {
+    float s = __shfl_down(v, 1, 64);
+    if (lane == 63) s = 0.f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_down(s, o, 64);
+        if (lane + o < 64) s += t;
+    }
+    return s;
+}

@@ -104,18 +104,18 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             v_term = fmaf(g_nm[c], nrm[c], v_term);
         }
         const float u_w = interval ? (v_term - b_term) * wgt : 0.f;
-        const float incl_uw = wave_scan_incl(u_w, lane);
+        // sum_{i>k} U_i w_i as a true suffix sum (not total - prefix: that difference loses the small late-ray values to
+        // the rounding of the ray total, coherently over the samples of a ray, which d beta's cancelling sum then exposes)
+        const float sfx_w = wave_suffix_excl(u_w, lane);
+        const float wsum_uw = wave_sum(u_w);
         const float wsum_w = wave_sum(wgt);
-        if (lane == 63) s_part[wave][1] = incl_uw;
-        if (lane == 0) s_part[wave][2] = wsum_w;
+        if (lane == 0) { s_part[wave][1] = wsum_uw; s_part[wave][2] = wsum_w; }
         __syncthreads();
-        float uw_total = 0.f, opacity = 0.f, uw_before = 0.f;
+        float opacity = 0.f, suffix = sfx_w;
         for (int q = 0; q < n_waves; ++q) {
-            uw_total += s_part[q][1];
             opacity += s_part[q][2];
-            if (q < wave) uw_before += s_part[q][1];
+            if (q > wave) suffix += s_part[q][1];
         }
-        const float suffix = uw_total - (incl_uw + uw_before);
         const float d_tau = interval ? (v_term - b_term) * trans * ex - suffix : 0.f;
         const float g_sigma = d_tau * delta;
         const float rest = 1.0f - opacity;

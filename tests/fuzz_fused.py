@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""Randomised sweep: fused render (fwd + bwd, with and without pose gradients) against the composed autograd form over
+random ray counts, sample counts, datasets, level counts / table sizes, field modes and upstream-gradient subsets.
+Quantities the fp32 composed form itself cannot resolve to the bar (sums of terms of both signs over every sample: d beta,
+the last layer's bias / weight_g under random cotangents) are re-judged against the CPU oracle run in fp64.
+usage: python tests/fuzz_fused.py [n_cases] [seed]    (pytest entry: tests/test_hip_fuzz.py)"""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "level-s2fm_official_amd"))
+sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch  # noqa: E402
+from conftest import rel_err  # noqa: E402
+from helpers import named_grads  # noqa: E402
+from test_hip_fused_render import _randomized, _rays  # noqa: E402
+from ls2fm import fused  # noqa: E402
+from ls2fm.options import make_options  # noqa: E402
+from oracle import fields as OF  # noqa: E402
+
+DEV = "cuda"
+KEYS = ["rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"]
+
+
+def _tol(name):
+    return 5e-4 if name == "s.beta" else 1e-4
+
+
+def oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot):
+    """the same scalar through the CPU oracle in float64 -> {name: gradient}"""
+    cfg = OF.dataset_config(ds, dual_field=dual, sample_intvs=n_samples, n_levels=L, log2_hashmap_size=log2_T,
+                            base_resolution=base, bgcolor=tuple(bg), inside=bool(opt.data.inside))
+    osd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in sdf.state_dict().items()}
+    ord_ = {k: v.detach().cpu().double().requires_grad_(True) for k, v in rad.state_dict().items()}
+    ret = OF.render(cfg, center.cpu().double(), ray.cpu().double(), osd, ord_)
+    sum((ret[k] * cot[k].cpu().double()).sum() for k in used).backward()
+    out = {"s." + k: v.grad for k, v in osd.items() if v.grad is not None}
+    out.update({"r." + k: v.grad for k, v in ord_.items() if v.grad is not None})
+    return out
+
+
+def one_case(case, rng):
+    ds = rng.choice(["DTU", "ETH3D", "BlendedMVS", "scannet"])
+    dual = rng.random() < 0.6
+    n_samples = rng.choice([1, 3, 17, 32, 64, 100, 128, 129, 200, 256, 257, 400, 512])
+    n_rays = rng.choice([1, 2, 5, 63, 64, 65, 130, 257, 700, 1024])
+    if n_rays * n_samples > 140000:
+        n_rays = max(1, 140000 // n_samples)
+    L = rng.choice([2, 3, 5, 8, 12, 16])              # L = 1 divides by zero in the reference's per_level_scale too
+    log2_T = rng.choice([8, 12, 15, 19])
+    base = rng.choice([4, 16])
+    pose = rng.random() < 0.4
+    bg = rng.choice([[1.0, 1.0, 1.0], [0.0, 0.0, 0.0], [0.3, 0.6, 0.1]])
+    opt = make_options(ds, device=DEV, dual_field=dual, sample_intvs=n_samples,
+                       hash_encoding=dict(n_levels=L, n_features_per_level=2, log2_hashmap_size=log2_T, base_resolution=base),
+                       bgcolor=bg)
+    if rng.random() < 0.3:
+        opt.data.inside = not opt.data.inside
+    sdf, rad, ren = _randomized(opt, 100 + case)
+    s = float(opt.data.bound_max[0])
+    center, ray = _rays(max(n_rays, 6), s, 200 + case)
+    center, ray = center[:, :n_rays].contiguous(), ray[:, :n_rays].contiguous()
+    used = [k for k in KEYS if rng.random() < 0.7] or ["rgb"]
+    gen = torch.Generator(device=DEV).manual_seed(case)
+    cot, res = None, {}
+    took = fused.can_render(ren, opt, center, ray, sdf, rad)
+    for form in ("fused", "composed"):
+        c = center.clone().requires_grad_(pose)
+        r = ray.clone().requires_grad_(pose)
+        sdf.zero_grad(); rad.zero_grad()
+        ret = (ren.forward if form == "fused" else ren.forward_composed)(opt, c, r, sdf, rad)
+        if cot is None:
+            cot = {k: torch.randn(ret[k].shape, device=DEV, generator=gen) for k in KEYS}
+        sum((ret[k] * cot[k]).sum() for k in used).backward()
+        g = {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
+        if pose:
+            g["d_center"], g["d_ray"] = c.grad.cpu(), r.grad.cpu()
+        res[form] = ({k: ret[k].detach().cpu() for k in KEYS}, g)
+    errs, bad = {}, []
+    for k in KEYS:
+        errs[k] = rel_err(res["fused"][0][k], res["composed"][0][k])
+        if not errs[k] < 2e-5:
+            bad.append((k, errs[k]))
+    for k, a in res["fused"][1].items():
+        errs["g:" + k] = rel_err(a, res["composed"][1][k])
+        if not errs["g:" + k] < _tol(k):
+            bad.append((k, errs["g:" + k]))
+    judged = ""
+    if bad and all(k[:2] in ("s.", "r.") for k, _ in bad):
+        o64 = oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot)
+        still = []
+        for k, _ in bad:
+            ef, ec = rel_err(res["fused"][1][k], o64[k]), rel_err(res["composed"][1][k], o64[k])
+            judged += f" [{k}: fused vs fp64 oracle {ef:.1e}, composed vs fp64 oracle {ec:.1e}]"
+            if not ef < max(_tol(k), 2.0 * ec):      # as good as fp32 autograd on an ill-conditioned sum is good enough
+                still.append((k, ef))
+        bad = still
+    tag = (f"case {case}: {ds} dual={dual} rays={n_rays} N={n_samples} L={L} T=2^{log2_T} base={base} pose={pose} "
+           f"inside={opt.data.inside} used={used} fused={took}")
+    return tag, bad, judged, errs
+
+
+def run(n_cases, seed, verbose=True):
+    rng = random.Random(seed)
+    worst, failures = {}, []
+    for case in range(n_cases):
+        tag, bad, judged, errs = one_case(case, rng)
+        for k, e in errs.items():
+            worst[k] = max(worst.get(k, 0.0), e)
+        if bad:
+            failures.append((tag, bad))
+        if verbose:
+            print(("FAIL " if bad else "ok   ") + tag + (f"  {bad}" if bad else "") + judged, flush=True)
+    return failures, worst
+
+
+if __name__ == "__main__":
+    fails, worst = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("worst relative errors (fused vs composed fp32):", {k: float(f"{v:.2e}") for k, v in sorted(worst.items())})
+    print(f"{len(fails)} failing case(s)")
+    sys.exit(1 if fails else 0)
