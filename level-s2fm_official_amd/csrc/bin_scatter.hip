@@ -353,6 +353,14 @@ __device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float
     to_float = ldexp(1.0, -shift);
 }
 
+// -DLS2FM_STAMPS: per-workgroup phase time stamps (100 MHz), read back by tools/acc_stamps.py
+#ifdef LS2FM_STAMPS
+__device__ long long g_acc_stamps[8 * 4096];
+#define ACC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define ACC_STAMP(k) do {} while (0)
+#endif
+
 template <bool DUAL>
 __global__ void __launch_bounds__(kAccThreads)
 slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
@@ -360,6 +368,7 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
     constexpr int F = DUAL ? 4 : 2;
     __shared__ u64 acc[kAccSlots];
     const int tid = threadIdx.x;
+    ACC_STAMP(0);
     int l = 0;
     while ((int)blockIdx.x >= plan.first[l + 1]) ++l;
     const int parts = plan.parts[l];
@@ -387,6 +396,7 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
     quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
     quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
     __syncthreads();
+    ACC_STAMP(1);
 
     // streamed, 32 bytes per lane, fully coalesced
     for (int j = j_lo + tid; j < j_hi; j += kAccThreads) {
@@ -414,6 +424,7 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
         }
     }
     __syncthreads();
+    ACC_STAMP(2);
     // ---- flush: fixed point -> fp32 (one rounding of the exact sum); slot e = F * entry + feature
     float* dst1 = dtable1 + 2ull * (lv.offset[l] + lo);
     float* dst2 = DUAL ? dtable2 + 2ull * (lv.offset[l] + lo) : nullptr;
@@ -425,6 +436,11 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
         if (parts == 1) *dst = v;                                 // sole owner of the entry
         else if (acc[e] != 0ull) atomicAdd(dst, v);               // point-split coarse level, zeroed by the host
     }
+#ifdef LS2FM_STAMPS
+    __syncthreads();
+    ACC_STAMP(3);
+    if (tid == 0 && blockIdx.x < 4096) { g_acc_stamps[8 * blockIdx.x + 4] = l; g_acc_stamps[8 * blockIdx.x + 5] = j_hi - j_lo; }
+#endif
 }
 
 constexpr int kFillTile = kFillThreads;          // sample points per count / fill workgroup (must agree)
@@ -543,6 +559,12 @@ int ls2fm_launch_scatter_zero(const ls2fm_grid_desc* grid, int64_t n_points, flo
         reinterpret_cast<float4*>(dtable1 + 2ull * first), dual ? reinterpret_cast<float4*>(dtable2 + 2ull * first) : nullptr, n4);
     return ls2fm_launch_status();
 }
+
+#ifdef LS2FM_STAMPS
+extern "C" int ls2fm_debug_acc_stamps(long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_acc_stamps), sizeof(long long) * 8 * 4096) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid; ls2fm_launch_scatter_zero must
 // have run on them before.
