@@ -186,6 +186,8 @@ int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid,
  * workspace: ls2fm_render_workspace_bytes(...) bytes; its contents are consumed by ls2fm_render_bwd
  * for the same inputs, so it must be kept untouched between the two calls.
  */
+#define LS2FM_MAX_RENDER_POINTS (1 << 23)   /* n_rays * n_samples per call (32-bit offsets and item counts inside);
+                                               more: LS2FM_ERR_UNSUPPORTED -- split the rays over several calls */
 int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n_rays);
 /* Dual field, optional: write both hash tables (same geometry, [n_entries][2] each) entry-interleaved into
  * dual_table [n_entries][4] for ls2fm_params.dual_table.  The forward then gathers ONE 16-byte entry per corner for both

@@ -331,6 +331,7 @@ static bool render_config_ok(const ls2fm_field_desc* field, const ls2fm_grid_des
 extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid,
                                                 int64_t n_rays) {
     if (!field || !grid_desc_ok(grid) || n_rays < 0) return LS2FM_ERR_INVALID_ARGUMENT;
+    if (n_rays * (int64_t)field->n_samples > LS2FM_MAX_RENDER_POINTS) return LS2FM_ERR_UNSUPPORTED;
     // the second grid (dual field) uses the same encoding config as the first (models/RadF.py:35-39)
     const WsLayout w = make_ws_layout(n_rays, field->n_samples, grid->n_levels, grid->n_levels, field->dual_field);
     return w.total * (int64_t)sizeof(float);
@@ -343,6 +344,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LS2FM_CHECK_ARG(render_config_ok(field, sdf_grid, rad_grid) && params && n_rays >= 0);
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;       // min(sdf, bg_rad-|p|): general (composed) form only
     if (field->dual_field && !same_grid_geometry(sdf_grid, rad_grid)) return LS2FM_ERR_UNSUPPORTED;
+    if (n_rays * (int64_t)field->n_samples > LS2FM_MAX_RENDER_POINTS) return LS2FM_ERR_UNSUPPORTED;
     if (n_rays == 0) return LS2FM_OK;
     LS2FM_CHECK_ARG(center && ray && rgb && sdfs_volume && normals && depth_mlp && normal_mlp);
     if (!workspace) return LS2FM_ERR_WORKSPACE;

@@ -16,6 +16,7 @@ MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
 ABI_VERSION = 1
+MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LS2FM_LIB") or os.path.join(_HERE, "libls2fm_hip.so")

@@ -122,6 +122,9 @@ def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
 def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
     if not (center.is_cuda and ray.is_cuda) or not _plan(renderer, opt, sdf_field, rad_field).ok:
         return False
+    n_points = center.shape[0] * center.shape[1] * int(opt.SDF.VolSDF.sample_intvs) if center.dim() == 3 else 0
+    if n_points > _lib.MAX_RENDER_POINTS:       # 32-bit offsets inside one call: bigger batches take the composed form
+        return False
     return True                 # pose gradients (center / ray requiring grad) are part of the fused backward
 
 

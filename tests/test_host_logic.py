@@ -206,3 +206,15 @@ def test_checkpoint_layout_round_trip(tmp_path, manifest):
         assert torch.equal(a, b), k
     assert other.optim_sdf.state_dict()["state"][0]["step"] == model.optim_sdf.state_dict()["state"][0]["step"]
     assert other.sched_sdf.last_epoch == 1
+
+
+def test_render_size_limit_is_reported_not_overflowed():
+    """more sample points than one call indexes with 32 bits: UNSUPPORTED from the size query (no launch, no overflow)"""
+    lib = _lib.load()
+    opt = make_options("DTU", device="cpu", dual_field=True, sample_intvs=128)
+    from ls2fm import fused
+    fdesc = fused.field_desc(opt)
+    desc = SDF(opt).embed_fn.embedder_obj.desc
+    ok = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(desc), 65536)          # 2^23 points: allowed
+    assert ok > 0
+    assert lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(desc), 65537) == -2  # LS2FM_ERR_UNSUPPORTED
