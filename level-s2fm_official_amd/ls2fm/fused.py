@@ -212,7 +212,10 @@ _RAD_TABLE_AT = 8        # param_tensors(): sdf table, 2 x (v, g, b), beta, rad 
 def _refresh_dual_table(lib, plan, sdf_table, rad_table):
     """(re)build the interleaved copy of the two tables when they changed (see _DUAL_TABLE)"""
     key = (sdf_table.data_ptr(), rad_table.data_ptr(), sdf_table._version, rad_table._version)
-    if plan.dual_key == key and _DUAL_TABLE != "always":
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
+        key = None          # a captured step cannot re-check versions at replay: the refresh becomes part of the graph
+    elif plan.dual_key == key and _DUAL_TABLE != "always":
         return
     if not (_is_table(sdf_table) and _is_table(rad_table) and sdf_table.numel() == rad_table.numel()):
         raise RuntimeError("ls2fm: dual-field tables of different size")
@@ -248,6 +251,9 @@ class _Render(torch.autograd.Function):
             plan.dual_key = None
         if dual and _DUAL_TABLE != "off":
             _refresh_dual_table(lib, plan, ps[0], ps[_RAD_TABLE_AT])
+        elif plan.pstruct.dual_table:
+            plan.pstruct.dual_table = None      # mode switched off after use: gather from the two tables again
+            plan.dual_key = None
         ws_bytes = plan.ws_bytes.get(n_rays)
         if ws_bytes is None:
             ws_bytes = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(g1), n_rays)
