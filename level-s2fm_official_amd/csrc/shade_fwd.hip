@@ -75,7 +75,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     bool live_c[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int ns = 64 * wave + 16 * c + jl;
+        const int ns = 64 * wave + 4 * jl + c;          // a lane's four columns are CONSECUTIVE samples: 16-byte loads
         live_c[c] = ns < N;
         const int nn = live_c[c] ? ns : N - 1;
         is[c] = r * N + nn;
@@ -83,12 +83,24 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         sample_position(fc, gm, sample_depth(gm, nn, N), pw[c], x);
     }
 
+    // all four samples live and 16-byte aligned (p_pad is a multiple of 64): one float4 per channel row
+    const bool vec4 = live_c[3] && ((is[0] & 3) == 0);
+    auto load4 = [&](const float* __restrict__ row, float (&dst)[4]) {
+        if (vec4) {
+            const float4 v = *reinterpret_cast<const float4*>(row + is[0]);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[c] = row[is[c]];
+        }
+    };
     // ---- B operands of layer 0: ub[t][c] = U[k' = 4t + g][sample c]
     float ub[9][4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ub[t][c] = (4 * t + g) < ch1 ? E1[(int64_t)(4 * t + g) * p_pad + is[c]] : 0.f;
+    for (int t = 0; t < 8; ++t) {
+        if ((4 * t + g) < ch1) load4(E1 + (int64_t)(4 * t + g) * p_pad, ub[t]);
+        else { ub[t][0] = ub[t][1] = ub[t][2] = ub[t][3] = 0.f; }
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) ub[8][c] = g < 3 ? (g == 0 ? pw[c][0] : (g == 1 ? pw[c][1] : pw[c][2])) / fc.rescale : 1.0f;
 
@@ -146,32 +158,47 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
     // sdf and the analytic normal  n = kappa (R_p / rescale + inv_ext . J^T R_enc)
     float sdf[4], nrm[4][3];
+    float part[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[c][0] = part[c][1] = part[c][2] = 0.f;
+#pragma unroll
+    for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = 16 * mk + 4 * g + q;
+            if (ch < ch1) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float jv[4];
+                    load4(J1 + (int64_t)(ch * 3 + a) * p_pad, jv);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) part[c][a] = fmaf(jv[c], racc[mk][c][q], part[c][a]);
+                }
+            }
+        }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float f0 = sum_over_groups(f0p[c]) + mw.b10[0];
         sdf[c] = fc.inside ? f0 / fc.scale_mlp : -f0 / fc.scale_mlp;
-        float part[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mk = 0; mk < 2; ++mk)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = 16 * mk + 4 * g + q;
-                if (ch < ch1) {
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) part[a] = fmaf(J1[(int64_t)(ch * 3 + a) * p_pad + is[c]], racc[mk][c][q], part[a]);
-                }
-            }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            float v = part[a] * fc.inv_ext[a];
+            float v = part[c][a] * fc.inv_ext[a];
             if (g == 0) v += racc[2][c][a] / fc.rescale;          // rows 32..34 = the p / rescale inputs (group 0)
             nrm[c][a] = fc.kappa * sum_over_groups(v);
         }
-        if (live_c[c]) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) FE[(int64_t)(4 * g + q) * p_pad + is[c]] = facc[c][q];
-        }
     }
+    auto store4 = [&](float* __restrict__ row, float v0, float v1, float v2, float v3) {
+        if (vec4) {
+            *reinterpret_cast<float4*>(row + is[0]) = make_float4(v0, v1, v2, v3);
+        } else {
+            const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (live_c[c]) row[is[c]] = v[c];
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store4(FE + (int64_t)(4 * g + q) * p_pad, facc[0][q], facc[1][q], facc[2][q], facc[3][q]);
 
     // ---- second field (Geometry_feat of RadF): features only
     f32x4 facc2[4];
@@ -183,9 +210,10 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             for (int q = n; q < kMfmaFieldFloats / 4; q += blockDim.x) dst[q] = src[q];
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ub[t][c] = (4 * t + g) < ch2 ? E2[(int64_t)(4 * t + g) * p_pad + is[c]] : 0.f;
+        for (int t = 0; t < 8; ++t) {
+            if ((4 * t + g) < ch2) load4(E2 + (int64_t)(4 * t + g) * p_pad, ub[t]);
+            else { ub[t][0] = ub[t][1] = ub[t][2] = ub[t][3] = 0.f; }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -210,11 +238,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (live_c[c]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) FE2[(int64_t)(4 * g + q) * p_pad + is[c]] = facc2[c][q];
-            }
+        for (int q = 0; q < 4; ++q) store4(FE2 + (int64_t)(4 * g + q) * p_pad, facc2[0][q], facc2[1][q], facc2[2][q], facc2[3][q]);
     }
     __syncthreads();          // s_view ready
 
@@ -246,7 +270,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             col[k] = 1.0f / (1.0f + expf(-z));
         }
         if (g == 0) {
-            float* dst = s_x[64 * wave + 16 * c + jl];
+            float* dst = s_x[64 * wave + 4 * jl + c];
             dst[0] = sdf[c];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { dst[1 + a] = nrm[c][a]; dst[4 + a] = col[a]; }
