@@ -85,21 +85,18 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
     // all four samples live and 16-byte aligned (p_pad is a multiple of 64): one float4 per channel row
     const bool vec4 = live_c[3] && ((is[0] & 3) == 0);
-    auto load4 = [&](const float* __restrict__ row, float (&dst)[4]) {
-        if (vec4) {
-            const float4 v = *reinterpret_cast<const float4*>(row + is[0]);
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dst[c] = row[is[c]];
-        }
+    const int64_t i0 = is[0], i1 = is[1], i2 = is[2], i3 = is[3];
+    auto load4 = [=](const float* __restrict__ row) -> float4 {      // by value: by-reference captures cost spilled registers
+        if (vec4) return *reinterpret_cast<const float4*>(row + i0);
+        return make_float4(row[i0], row[i1], row[i2], row[i3]);
     };
     // ---- B operands of layer 0: ub[t][c] = U[k' = 4t + g][sample c]
     float ub[9][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        if ((4 * t + g) < ch1) load4(E1 + (int64_t)(4 * t + g) * p_pad, ub[t]);
-        else { ub[t][0] = ub[t][1] = ub[t][2] = ub[t][3] = 0.f; }
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((4 * t + g) < ch1) e = load4(E1 + (int64_t)(4 * t + g) * p_pad);
+        ub[t][0] = e.x; ub[t][1] = e.y; ub[t][2] = e.z; ub[t][3] = e.w;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) ub[8][c] = g < 3 ? (g == 0 ? pw[c][0] : (g == 1 ? pw[c][1] : pw[c][2])) / fc.rescale : 1.0f;
@@ -169,10 +166,11 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             if (ch < ch1) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    float jv[4];
-                    load4(J1 + (int64_t)(ch * 3 + a) * p_pad, jv);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) part[c][a] = fmaf(jv[c], racc[mk][c][q], part[c][a]);
+                    const float4 jv = load4(J1 + (int64_t)(ch * 3 + a) * p_pad);
+                    part[0][a] = fmaf(jv.x, racc[mk][0][q], part[0][a]);
+                    part[1][a] = fmaf(jv.y, racc[mk][1][q], part[1][a]);
+                    part[2][a] = fmaf(jv.z, racc[mk][2][q], part[2][a]);
+                    part[3][a] = fmaf(jv.w, racc[mk][3][q], part[3][a]);
                 }
             }
         }
@@ -187,14 +185,15 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             nrm[c][a] = fc.kappa * sum_over_groups(v);
         }
     }
-    auto store4 = [&](float* __restrict__ row, float v0, float v1, float v2, float v3) {
+    const bool l0 = live_c[0], l1 = live_c[1], l2 = live_c[2], l3 = live_c[3];
+    auto store4 = [=](float* __restrict__ row, float v0, float v1, float v2, float v3) {
         if (vec4) {
-            *reinterpret_cast<float4*>(row + is[0]) = make_float4(v0, v1, v2, v3);
+            *reinterpret_cast<float4*>(row + i0) = make_float4(v0, v1, v2, v3);
         } else {
-            const float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (live_c[c]) row[is[c]] = v[c];
+            if (l0) row[i0] = v0;
+            if (l1) row[i1] = v1;
+            if (l2) row[i2] = v2;
+            if (l3) row[i3] = v3;
         }
     };
 #pragma unroll
@@ -211,8 +210,9 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            if ((4 * t + g) < ch2) load4(E2 + (int64_t)(4 * t + g) * p_pad, ub[t]);
-            else { ub[t][0] = ub[t][1] = ub[t][2] = ub[t][3] = 0.f; }
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((4 * t + g) < ch2) e = load4(E2 + (int64_t)(4 * t + g) * p_pad);
+            ub[t][0] = e.x; ub[t][1] = e.y; ub[t][2] = e.z; ub[t][3] = e.w;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
