@@ -189,6 +189,17 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     const float* __restrict__ s_w1ta = s_w + 4 * 9 * 64;                // [m][5][lane]
     const float* __restrict__ s_w0ta = s_w1ta + 4 * 5 * 64;             // [mk][m][r][lane]
     const float* __restrict__ s_w10 = s_w0ta + 2 * 4 * 4 * 64;          // [m][r][lane]
+    // pass 0: the SDF field for both halves of the wave's samples; pass 1 (dual): the second field for both halves -- each
+    // field's weights are staged into LDS once per workgroup
+#pragma unroll 1
+    for (int pass = 0; pass < (DUAL ? 2 : 1); ++pass) {
+    if (pass == 1) {
+        __syncthreads();          // every wave is done with the SDF weights
+        const float4* src = reinterpret_cast<const float4*>(&pk->bg);
+        float4* dst = reinterpret_cast<float4*>(s_w);
+        for (int q = n; q < kMfmaBwdGeoFloats / 4; q += blockDim.x) dst[q] = src[q];
+        __syncthreads();          // second field's weights staged
+    }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         uint32_t is[NC];                  // point index (32-bit offsets: uniform base + VGPR offset addressing)
@@ -210,8 +221,16 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             }
             gsdf[cc] = y[6];
         }
+        float ub[9][NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
+            ub[8][cc] = g < 3 ? pg / fc.rescale : 1.0f;
+        }
+        f32x4 dex[NC];
+        if (pass == 0) {
         // ---- B operands: u, v (rows k' = 4t + g) and the MLP-output upstream gf (rows o = 4t + g)
-        float ub[9][NC], vb[9][NC], gfb[5][NC];
+        float vb[9][NC], gfb[5][NC];
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -226,9 +245,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             }
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
-            const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
             const float kg = g == 0 ? gnk[cc][0] : (g == 1 ? gnk[cc][1] : gnk[cc][2]);
-            ub[8][cc] = g < 3 ? pg / fc.rescale : 1.0f;
             vb[8][cc] = g < 3 ? kg / fc.rescale : 0.f;
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
@@ -273,7 +290,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             }
 
         // ---- SDF field
-        f32x4 de[2][NC], rr[2][NC], dex[NC];
+        f32x4 de[2][NC], rr[2][NC];
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) dex[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -359,14 +376,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     }
                 }
 
+        }   // pass 0
         // ---- second field: plain first-order backward of its Geometry MLP
-        if (DUAL) {
-            __syncthreads();      // every wave is done with the SDF weights
-            {
-                const float4* src = reinterpret_cast<const float4*>(&pk->bg);
-                float4* dst = reinterpret_cast<float4*>(s_w);
-                for (int q = n; q < kMfmaBwdGeoFloats / 4; q += blockDim.x) dst[q] = src[q];
-            }
+        if (DUAL && pass == 1) {
             const float* __restrict__ g_w1ta = s_w + 4 * 9 * 64;        // [m][4][lane]
             const float* __restrict__ g_w0ta = g_w1ta + 4 * 4 * 64;     // [mk][m][r][lane]
             float gf2b[4][NC];
@@ -386,7 +398,6 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 }
                 if (live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
             }
-            __syncthreads();      // second field's weights staged
             f32x4 de2[2][NC];
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) dex[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -459,14 +470,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                             atomicMax(&s_bound[16 + l], __float_as_int(fmaxf(fabsf(d0), fabsf(d1))));
                         }
                     }
-            if (half == 0) {      // restore the SDF weights for the second pass
-                __syncthreads();
-                const float4* src = reinterpret_cast<const float4*>(&pk->bs);
-                float4* dst = reinterpret_cast<float4*>(s_w);
-                for (int q = n; q < kMfmaBwdSdfFloats / 4; q += blockDim.x) dst[q] = src[q];
-                __syncthreads();
-            }
         }
+    }
     }
     // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
     __syncthreads();
