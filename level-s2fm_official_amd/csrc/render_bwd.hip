@@ -192,10 +192,6 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // one memset: reduced weight gradients, the d beta accumulator and the bin counters are adjacent in the workspace
     if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.bins - w.wg) + ls2fm_bin_counts_bytes(), s) != hipSuccess)
         return LS2FM_ERR_LAUNCH;
-    {   // the point-split coarse levels of the gradient table(s) are zeroed up front (one small launch)
-        const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s);
-        if (st != LS2FM_OK) return st;
-    }
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
@@ -204,6 +200,11 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
                         hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
+    {   // the point-split coarse levels of the gradient table(s) are zeroed up front (one small launch, off the main chain:
+        // only slab_accumulate, which waits for this stream's `mid` event, needs it)
+        const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, gs);
+        if (st != LS2FM_OK) return st;
+    }
     ls2fm_prof_begin(LS2FM_PROF_BIN, gs);
     {
         const int st = ls2fm_launch_bin_build(sdf_grid, fc, center, ray, w.p, ws + w.bins, dual, gs);
