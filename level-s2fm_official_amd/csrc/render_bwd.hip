@@ -48,7 +48,7 @@ __device__ void weight_norm_bwd_rows(const float* v, const float* g, const float
 
 __global__ void __launch_bounds__(256)
 finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, int rad_in, int dual,
-                const Packed* __restrict__ pk, const float* __restrict__ wg, const float* __restrict__ dbeta) {
+                const Packed* __restrict__ pk, const float* __restrict__ wg, const float* __restrict__ dbeta, int64_t n_rays) {
     __shared__ float s_dwc[3][68];
     __shared__ float s_dbc[4];
     __shared__ float s_dt1[3][64];
@@ -116,8 +116,20 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
             for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][tid], s_dbc[c], acc);
             G.rad_mlp[0].bias[tid] = acc;
         }
-        // beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed
-        if (tid == 0) G.beta[0] = (float)(*reinterpret_cast<const double*>(dbeta) * (double)pk->beta * (double)P.beta_speed);
+        // beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed ; dL/dbeta = fixed-order sum of the
+        // per-ray partials of shade_bwd (fp64)
+        {
+            __shared__ double s_db[256];
+            double acc = 0.0;
+            for (int64_t r = tid; r < n_rays; r += 256) acc += reinterpret_cast<const double*>(dbeta)[r];
+            s_db[tid] = acc;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) s_db[tid] += s_db[tid + o];
+                __syncthreads();
+            }
+            if (tid == 0) G.beta[0] = (float)(s_db[0] * (double)pk->beta * (double)P.beta_speed);
+        }
         return;
     }
     __syncthreads();          // s_dt1 complete
@@ -189,9 +201,6 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
     const int64_t P = w.p_pad;
 
-    // one memset: reduced weight gradients, the d beta accumulator and the bin counters are adjacent in the workspace
-    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.bins - w.wg) + ls2fm_bin_counts_bytes(), s) != hipSuccess)
-        return LS2FM_ERR_LAUNCH;
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
@@ -200,6 +209,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
                         hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
+    // the reduced-weight-gradient accumulators are zeroed off the main chain as well (consumed by the wgrad kernels, which run
+    // on this stream later)
+    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), gs) != hipSuccess) return LS2FM_ERR_LAUNCH;
     {   // the point-split coarse levels of the gradient table(s) are zeroed up front (one small launch, off the main chain:
         // only slab_accumulate, which waits for this stream's `mid` event, needs it)
         const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, gs);
@@ -229,7 +241,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     finalize_kernel<<<7, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
-                                       ws + w.dbeta);
+                                       ws + w.dbeta, n_rays);
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
 

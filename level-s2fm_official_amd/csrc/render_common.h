@@ -268,7 +268,7 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.renc = take(27 * w.r_pad);
     w.mpart = take(ls2fm_wgrad_mlp_part_floats(dual));
     w.wg = take(WgLayout::total);
-    w.dbeta = take(64);
+    w.dbeta = take(2 * w.r_pad);     // one double per ray: d L / d beta partials (summed in fixed order by finalize)
     // bin meta (counts first) directly after wg / dbeta: one memset zeroes all three (render_bwd.hip)
     w.bins = take(ls2fm_bins_workspace_floats(l1, w.p));   // per-slab item lists of the scatter (bin_scatter.hip)
     w.smax = take(32 * w.r_pad); // [32][r_pad]: per-ray bound of one scatter contribution per level ([0,16) SDF grid, [16,32) second grid)

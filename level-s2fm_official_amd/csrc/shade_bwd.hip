@@ -174,7 +174,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         if (n == 3) {
             double s = 0.0;
             for (int q = 0; q < n_waves; ++q) s += s_db[q];
-            atomicAdd(reinterpret_cast<double*>(out + w.dbeta), s);
+            reinterpret_cast<double*>(out + w.dbeta)[r] = s;         // per-ray partial: no atomic, nothing to zero
         }
         if (n < kView) out[w.renc + n * w.r_pad + r] = view_component(gm.d, n);
         if (n == 4 && want_pose) {
