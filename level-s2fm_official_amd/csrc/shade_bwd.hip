@@ -200,6 +200,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         for (int q = n; q < kMfmaBwdGeoFloats / 4; q += blockDim.x) dst[q] = src[q];
         __syncthreads();          // second field's weights staged
     }
+    // this lane's levels are the same in every half and column (l = 8 mk + 2 g + hv): keep the running maxima of the
+    // contribution bounds in registers and publish them once per pass (a per-item LDS atomicMax: 16 lanes per address)
+    float bnd[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         uint32_t is[NC];                  // point index (32-bit offsets: uniform base + VGPR offset addressing)
@@ -372,7 +375,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         const float r0 = rr[mk][cc][2 * hv], r1 = rr[mk][cc][2 * hv + 1];
                         *reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + is[cc]) * 4) = make_float4(d0, d1, r0, r1);
                         const float b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[l] * g1[cc] * fmaxf(fabsf(r0), fabsf(r1));
-                        atomicMax(&s_bound[l], __float_as_int(b));
+                        bnd[mk][hv] = fmaxf(bnd[mk][hv], b);
                     }
                 }
 
@@ -467,11 +470,18 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         if (2 * l < ch2 && live_c[cc]) {
                             const float d0 = de2[mk][cc][2 * hv], d1 = de2[mk][cc][2 * hv + 1];
                             *reinterpret_cast<float2*>(out + w.rec2 + ((int64_t)l * P + is[cc]) * 2) = make_float2(d0, d1);
-                            atomicMax(&s_bound[16 + l], __float_as_int(fmaxf(fabsf(d0), fabsf(d1))));
+                            bnd[mk][hv] = fmaxf(bnd[mk][hv], fmaxf(fabsf(d0), fabsf(d1)));
                         }
                     }
         }
     }
+#pragma unroll
+    for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+            const int l = 8 * mk + 2 * g + hv;
+            if (2 * l < (pass == 0 ? ch1 : ch2)) atomicMax(&s_bound[16 * pass + l], __float_as_int(bnd[mk][hv]));
+        }
     }
     // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
     __syncthreads();
