@@ -186,8 +186,12 @@ sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pack
     if (live && side == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + iters_max) * 3 + a] = p[a];
-        atomicMax(trips, kfin < 0 ? iters_max : kfin);
     }
+    // global trip count = max over rays: one atomic per wave (same-address global atomics serialise: ~6 ns each)
+    int kmax = (live && side == 0) ? (kfin < 0 ? iters_max : kfin) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && kmax > 0) atomicMax(trips, kmax);
 }
 
 }  // namespace
