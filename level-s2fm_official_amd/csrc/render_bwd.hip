@@ -204,26 +204,30 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
-    // fork 1: the per-slab item counts / offsets depend on the sample positions only -> side stream, under shade_bwd
+    // fork 1: the per-slab item counts / offsets depend on the sample positions only.  They run beside shade_bwd on the
+    // HIGHEST-PRIORITY stream: at normal priority their few workgroups queue behind shade_bwd's and the chain (42 us alone)
+    // takes ~110 us -- longer than shade_bwd itself, i.e. scatter_fill ended up waiting for it.
     SideCtx sc;
     const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
-                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess &&
+                        hipStreamWaitEvent(sc.fast, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
-    // the reduced-weight-gradient accumulators are zeroed off the main chain as well (consumed by the wgrad kernels, which run
-    // on this stream later)
+    hipStream_t fs = forked ? sc.fast : s;
+    // the reduced-weight-gradient accumulators are zeroed off the main chain (consumed by the wgrad kernels, which run on the
+    // side stream later)
     if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), gs) != hipSuccess) return LS2FM_ERR_LAUNCH;
     {   // the point-split coarse levels of the gradient table(s) are zeroed up front (one small launch, off the main chain:
-        // only slab_accumulate, which waits for this stream's `mid` event, needs it)
-        const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, gs);
+        // only slab_accumulate, which waits for the `mid` event of this stream, needs it)
+        const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, fs);
         if (st != LS2FM_OK) return st;
     }
-    ls2fm_prof_begin(LS2FM_PROF_BIN, gs);
+    ls2fm_prof_begin(LS2FM_PROF_BIN, fs);
     {
-        const int st = ls2fm_launch_bin_build(sdf_grid, fc, center, ray, w.p, ws + w.bins, dual, gs);
+        const int st = ls2fm_launch_bin_build(sdf_grid, fc, center, ray, w.p, ws + w.bins, dual, fs);
         if (st != LS2FM_OK) return st;
     }
-    ls2fm_prof_end(LS2FM_PROF_BIN, gs);
-    if (forked && hipEventRecord(sc.mid, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    ls2fm_prof_end(LS2FM_PROF_BIN, fs);
+    if (forked && hipEventRecord(sc.mid, sc.fast) != hipSuccess) return LS2FM_ERR_LAUNCH;
 
     const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);

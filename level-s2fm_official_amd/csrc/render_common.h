@@ -21,7 +21,7 @@ void ls2fm_prof_begin(int id, hipStream_t stream);      // bracket one kernel la
 void ls2fm_prof_end(int id, hipStream_t stream);
 
 // internal fork/join (streams.hip)
-struct SideCtx { hipStream_t side; hipEvent_t fork, mid, join; };
+struct SideCtx { hipStream_t side, fast; hipEvent_t fork, mid, join; };      // fast: highest-priority stream
 bool ls2fm_side_stream(SideCtx* out);
 
 constexpr int kHidden = LS2FM_HIDDEN;     // 64

@@ -9,7 +9,7 @@
 #include "render_common.h"
 
 namespace {
-struct DeviceCtx { bool init = false; hipStream_t side = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; };
+struct DeviceCtx { bool init = false; hipStream_t side = nullptr, fast = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; };
 std::mutex g_mu;
 DeviceCtx g_ctx[64];
 }  // namespace
@@ -24,11 +24,17 @@ bool ls2fm_side_stream(SideCtx* out) {
     DeviceCtx& c = g_ctx[dev];
     if (!c.init) {
         if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return false;
+        {   // small latency-critical chains (the scatter's count / scan) go to a stream of the highest priority, so that their
+            // few workgroups are dispatched ahead of the wide kernel they run beside
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+            if (hipStreamCreateWithPriority(&c.fast, hipStreamNonBlocking, hi) != hipSuccess) return false;
+        }
         if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&c.mid, hipEventDisableTiming) != hipSuccess) return false;
         c.init = true;
     }
-    out->side = c.side; out->fork = c.fork; out->mid = c.mid; out->join = c.join;
+    out->side = c.side; out->fast = c.fast; out->fork = c.fork; out->mid = c.mid; out->join = c.join;
     return true;
 }
