@@ -207,10 +207,16 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // fork 1: the per-slab item counts / offsets depend on the sample positions only.  They run beside shade_bwd on the
     // HIGHEST-PRIORITY stream: at normal priority their few workgroups queue behind shade_bwd's and the chain (42 us alone)
     // takes ~110 us -- longer than shade_bwd itself, i.e. scatter_fill ended up waiting for it.
+    // (Inside a stream capture the chain stays on the side stream: a captured graph maps a third concurrent branch onto the
+    // main branch's queue, which serialises it with shade_bwd -- measured 0.716 vs 0.700 ms/step.)
     SideCtx sc;
-    const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
-                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess &&
-                        hipStreamWaitEvent(sc.fast, sc.fork, 0) == hipSuccess;
+    bool forked = ls2fm_side_stream(&sc);
+    if (forked) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) sc.fast = sc.side;
+        forked = hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess &&
+                 (sc.fast == sc.side || hipStreamWaitEvent(sc.fast, sc.fork, 0) == hipSuccess);
+    }
     hipStream_t gs = forked ? sc.side : s;
     hipStream_t fs = forked ? sc.fast : s;
     // the reduced-weight-gradient accumulators are zeroed off the main chain (consumed by the wgrad kernels, which run on the
