@@ -238,6 +238,58 @@ ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, cons
     }
 }
 
+// Dual field, both grids in ONE launch: workgroups of XCD x walk SDF levels x, x + 8, then second-grid levels x, x + 8 (the
+// level's 4 MB table slice stays in that XCD's L2, as in the single-grid kernel); saves a launch boundary (ramp-down of one
+// gather pass + ramp-up of the next) on the critical path.
+__global__ void __launch_bounds__(256)
+ray_encode_pair_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
+                       const float* __restrict__ table1, const float* __restrict__ table2, int64_t n_points, int64_t p_pad,
+                       int n_chunks, int rounds, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slot = j / n_chunks;                       // 0 .. 2 * rounds - 1
+    const bool second = slot >= rounds;
+    const int l = xcd + 8 * (second ? slot - rounds : slot);
+    const LevelSet& lv = second ? lv2 : lv1;
+    if (l >= lv.n_levels) return;
+    const int64_t i = (int64_t)(j % n_chunks) * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    const int64_t r = i / fc.n_samples;
+    const int n = (int)(i - r * fc.n_samples);
+    const RayGeom g = load_ray(fc, center, ray, r);
+    float p[3], x[3];
+    sample_position(fc, g, sample_depth(g, n, fc.n_samples), p, x);
+    Cell c;
+    locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
+    const float* __restrict__ table = second ? table2 : table1;
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+    float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float wt = corner_weight(c.w, k);
+        y0 = fmaf(wt, v[k].x, y0);
+        y1 = fmaf(wt, v[k].y, y1);
+    }
+    float* __restrict__ enc = second ? enc2 : enc1;
+    __builtin_nontemporal_store(y0, enc + (2 * l + 0) * p_pad + i);
+    __builtin_nontemporal_store(y1, enc + (2 * l + 1) * p_pad + i);
+    if (!second) {
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dw = corner_dweight(c.w, k, gd);
+                g0 = fmaf(dw, v[k].x, g0);
+                g1 = fmaf(dw, v[k].y, g1);
+            }
+            __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+            __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+        }
+    }
+}
+
 // Dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner serves both
 // grids -- the gathers are bound by the L2->L1 request rate, not by bytes, so this halves the cost of the two encodes.
 __global__ void __launch_bounds__(256)
@@ -369,8 +421,14 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const int n_chunks = (int)((w.p + 255) / 256);
     const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
     const bool interleaved = dual && params->dual_table;
+    const bool pair = dual && !interleaved;      // one launch for both grids (span: ray_encode_sdf, covering both)
     ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
-    if (interleaved)
+    if (pair) {
+        const int rounds = (L1 > L2 ? L1 : L2) > 8 ? 2 : 1;
+        ray_encode_pair_kernel<<<(unsigned)(8 * 2 * rounds * n_chunks), 256, 0, s>>>(
+            make_level_set(sdf_grid), make_level_set(rad_grid), fc, center, ray, params->sdf_table, params->rad_table, w.p, w.p_pad,
+            n_chunks, rounds, ws + w.e1, ws + w.e2, ws + w.j1);
+    } else if (interleaved)
         ray_encode_dual_kernel<<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray,
                                                   reinterpret_cast<const float4*>(params->dual_table), w.p, w.p_pad, n_chunks,
                                                   ws + w.e1, ws + w.e2, ws + w.j1);
@@ -378,7 +436,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
         ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
                                                   n_chunks, ws + w.e1, ws + w.j1);
     ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
-    if (dual && !interleaved) {
+    if (dual && !interleaved && !pair) {
         ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
         ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,
                                                    n_chunks, ws + w.e2, nullptr);
