@@ -14,7 +14,7 @@ enum ls2fm_prof_id {
     LS2FM_PROF_PREP = 0, LS2FM_PROF_ENCODE_SDF, LS2FM_PROF_ENCODE_RAD, LS2FM_PROF_SHADE_FWD, LS2FM_PROF_SHADE_BWD,
     LS2FM_PROF_WGRAD_GEO, LS2FM_PROF_WGRAD_TAIL, LS2FM_PROF_SCATTER_SDF, LS2FM_PROF_SCATTER_RAD, LS2FM_PROF_FINALIZE,
     LS2FM_PROF_SDF_EVAL, LS2FM_PROF_SPHERE_TRACE, LS2FM_PROF_BIN, LS2FM_PROF_LOSS_FWD,
-    LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_POSE, LS2FM_PROF_COUNT
+    LS2FM_PROF_LOSS_BWD, LS2FM_PROF_WGRAD_MLP, LS2FM_PROF_POSE, LS2FM_PROF_ENCODE_PAIR, LS2FM_PROF_COUNT
 };
 bool ls2fm_prof_enabled();
 void ls2fm_prof_begin(int id, hipStream_t stream);      // bracket one kernel launch on the stream it is enqueued on

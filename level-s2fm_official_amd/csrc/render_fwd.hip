@@ -421,8 +421,9 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const int n_chunks = (int)((w.p + 255) / 256);
     const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
     const bool interleaved = dual && params->dual_table;
-    const bool pair = dual && !interleaved;      // one launch for both grids (span: ray_encode_sdf, covering both)
-    ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
+    const bool pair = dual && !interleaved;      // one launch for both grids
+    const int enc_span = pair ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;
+    ls2fm_prof_begin(enc_span, s);
     if (pair) {
         const int rounds = (L1 > L2 ? L1 : L2) > 8 ? 2 : 1;
         ray_encode_pair_kernel<<<(unsigned)(8 * 2 * rounds * n_chunks), 256, 0, s>>>(
@@ -435,7 +436,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     else
         ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
                                                   n_chunks, ws + w.e1, ws + w.j1);
-    ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
+    ls2fm_prof_end(enc_span, s);
     if (dual && !interleaved && !pair) {
         ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
         ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,

@@ -3,7 +3,7 @@ timing") and the roofline bookkeeping of bench.py.
 
 Algorithmic work per launch (P = sample points of one batch, L = hash levels, 8 corners x 2 features
 x 4 B = 64 B per level per point):
-  ray_encode_*    : P * L * 64 B  gathered from the table                       -> HBM roofline
+  ray_encode_*    : P * L * 64 B  gathered from the table (ray_encode_pair: both grids)  -> HBM roofline
   slab_scatter_*  : P * L * 64 B  accumulated into the table gradient          -> HBM roofline
   shade_fwd       : P * 2 * MACs  (SDF MLP 35*64 + 64*17, normal W0^T 35*64 + 96, second field 35*64 + 64*17,
                     collapsed radiance 3*38)                                    -> f32 MFMA/VALU roofline
@@ -39,6 +39,7 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
     wgrad_mn = 64 * 36 + 64 * 35 + 17 * 65 + 64 + 3 * 39 + (64 * 36 + 17 * 65 if dual else 0)
     return {
         "ray_encode_sdf": ("hbm", table_bytes), "ray_encode_rad": ("hbm", table_bytes),
+        "ray_encode_pair": ("hbm", 2 * table_bytes),             # dual field: both grids gathered by one launch
         # table-gradient scatter = scatter_fill (payload sort) + slab_accumulate; dual field: both grids in one pass
         "slab_accumulate": ("hbm", table_bytes * (2 if dual else 1)),
         "scatter_fill": ("hbm", table_bytes * (2 if dual else 1)),
@@ -66,8 +67,6 @@ def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float
     if not times:
         return None
     work = algorithmic_work(n_points, dual)
-    if dual and "ray_encode_rad" not in times and "ray_encode_sdf" in work:      # both grids gathered by one launch
-        work["ray_encode_sdf"] = (work["ray_encode_sdf"][0], 2 * work["ray_encode_sdf"][1])
     name = max(times, key=lambda k: times[k][2])
     avg_us, launches, total_ms = times[name]
     grand = sum(t[2] for t in times.values())
