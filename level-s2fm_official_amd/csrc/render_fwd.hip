@@ -7,6 +7,9 @@
 //                  Jacobian, written as SoA channels
 //   shade_fwd    : block per ray, lane per sample: SDF MLP + analytic normal + (second field) + collapsed
 //                  radiance + VolSDF sigma, then the front-to-back composite as a wave/block scan
+#include <cmath>
+#include <cstdlib>
+
 #include "render_common.h"
 
 namespace {
@@ -188,71 +191,36 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
 }
 
 // ------------------------------------------------------------------------------------------- ray_encode
-// Block -> (level, point chunk) mapping is XCD-aware: workgroup b is observed to run on XCD b % 8, and each XCD has a
+// One launch gathers every level of the SDF grid (value + Jacobian) and, dual field, of the second grid (value).
+// Block -> (grid, level, point chunk) mapping is XCD-aware: workgroup b is observed to run on XCD b % 8, and each XCD has a
 // private 4 MiB L2 -- exactly one 2^19-entry level of one table.  All workgroups of one XCD therefore work on the same
-// level at a time (levels xcd, xcd + 8, ...), so a level's table slice is fetched into ONE L2 once instead of into all
-// eight.  This is a speed choice only; any placement gives the same result.
-template <bool WITH_JAC>
-__global__ void __launch_bounds__(256)
-ray_encode_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
-                  const float* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks,
-                  float* __restrict__ enc, float* __restrict__ jac) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int l = xcd + 8 * (j / n_chunks);
-    if (l >= lv.n_levels) return;
-    const int64_t i = (int64_t)(j % n_chunks) * 256 + threadIdx.x;
-    if (i >= n_points) return;
-    const int64_t r = i / fc.n_samples;
-    const int n = (int)(i - r * fc.n_samples);
-    const RayGeom g = load_ray(fc, center, ray, r);
-    float p[3], x[3];
-    sample_position(fc, g, sample_depth(g, n, fc.n_samples), p, x);
-    Cell c;
-    locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
-    float2 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
-    float y0 = 0.f, y1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float wt = corner_weight(c.w, k);
-        y0 = fmaf(wt, v[k].x, y0);
-        y1 = fmaf(wt, v[k].y, y1);
-    }
-    // streaming outputs: non-temporal so they do not evict the table slice from the XCD's L2
-    __builtin_nontemporal_store(y0, enc + (2 * l + 0) * p_pad + i);
-    __builtin_nontemporal_store(y1, enc + (2 * l + 1) * p_pad + i);
-    if (WITH_JAC) {
-#pragma unroll
-        for (int gd = 0; gd < 3; ++gd) {
-            float g0 = 0.f, g1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float dw = corner_dweight(c.w, k, gd);
-                g0 = fmaf(dw, v[k].x, g0);
-                g1 = fmaf(dw, v[k].y, g1);
-            }
-            __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-            __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
-        }
-    }
-}
+// level at a time, so a level's table slice is fetched into ONE L2 once instead of into all eight.  The walking order
+// [grid 1: level 0 chunks .., level 1 chunks, .. ; grid 2: ..] is cut into 8 contiguous pieces of equal COST: dense levels
+// are much cheaper per chunk than hashed ones (their gathers hit the L1: measured 0.28 of a fine level, tools/enc_ticks.py),
+// so a fixed "levels x, x + 8 per XCD" split leaves the XCDs that own the dense levels idle at the end (152 -> 125 us for
+// both grids).  At most two XCDs share a level.  This is a speed choice only; any placement gives the same result.
+struct XcdPlan { int start[9]; };
 
-// Dual field, both grids in ONE launch: workgroups of XCD x walk SDF levels x, x + 8, then second-grid levels x, x + 8 (the
-// level's 4 MB table slice stays in that XCD's L2, as in the single-grid kernel); saves a launch boundary (ramp-down of one
-// gather pass + ramp-up of the next) on the critical path.
+#ifdef LS2FM_STAMPS
+__device__ unsigned long long g_enc_ticks[2 * LS2FM_MAX_LEVELS];     // summed workgroup durations per pass-level (100 MHz)
+#endif
+
 __global__ void __launch_bounds__(256)
-ray_encode_pair_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
+ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
                        const float* __restrict__ table1, const float* __restrict__ table2, int64_t n_points, int64_t p_pad,
-                       int n_chunks, int rounds, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
+                       int n_chunks, XcdPlan plan, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int slot = j / n_chunks;                       // 0 .. 2 * rounds - 1
-    const bool second = slot >= rounds;
-    const int l = xcd + 8 * (second ? slot - rounds : slot);
+    const int unit = plan.start[xcd] + j;
+    if (unit >= plan.start[xcd + 1]) return;
+    const int pl = unit / n_chunks;                      // pass-level: grid 1 levels, then grid 2 levels
+    const bool second = pl >= lv1.n_levels;
+    const int l = second ? pl - lv1.n_levels : pl;
     const LevelSet& lv = second ? lv2 : lv1;
-    if (l >= lv.n_levels) return;
-    const int64_t i = (int64_t)(j % n_chunks) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)(unit % n_chunks) * 256 + threadIdx.x;
     if (i >= n_points) return;
+#ifdef LS2FM_STAMPS
+    const long long t_begin = wall_clock64();
+#endif
     const int64_t r = i / fc.n_samples;
     const int n = (int)(i - r * fc.n_samples);
     const RayGeom g = load_ray(fc, center, ray, r);
@@ -288,18 +256,23 @@ ray_encode_pair_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __res
             __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
         }
     }
+#ifdef LS2FM_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&g_enc_ticks[pl], (unsigned long long)(wall_clock64() - t_begin));
+#endif
 }
 
 // Dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner serves both
 // grids -- the gathers are bound by the L2->L1 request rate, not by bytes, so this halves the cost of the two encodes.
 __global__ void __launch_bounds__(256)
 ray_encode_dual_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
-                       const float4* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks,
+                       const float4* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks, XcdPlan plan,
                        float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int l = xcd + 8 * (j / n_chunks);
-    if (l >= lv.n_levels) return;
-    const int64_t i = (int64_t)(j % n_chunks) * 256 + threadIdx.x;
+    const int unit = plan.start[xcd] + j;
+    if (unit >= plan.start[xcd + 1]) return;
+    const int l = unit / n_chunks;
+    const int64_t i = (int64_t)(unit % n_chunks) * 256 + threadIdx.x;
     if (i >= n_points) return;
     const int64_t r = i / fc.n_samples;
     const int n = (int)(i - r * fc.n_samples);
@@ -352,6 +325,12 @@ interleave_tables_kernel(const float2* __restrict__ a, const float2* __restrict_
 
 }  // namespace
 
+#ifdef LS2FM_STAMPS
+extern "C" int ls2fm_debug_enc_ticks(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enc_ticks), sizeof(unsigned long long) * 2 * LS2FM_MAX_LEVELS) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int ls2fm_interleave_tables(const float* sdf_table, const float* rad_table, int64_t n_entries, float* dual_table,
                                        void* stream) {
     LS2FM_CHECK_ARG(n_entries >= 0 && (n_entries == 0 || (sdf_table && rad_table && dual_table)));
@@ -362,6 +341,47 @@ extern "C" int ls2fm_interleave_tables(const float* sdf_table, const float* rad_
         reinterpret_cast<const float2*>(sdf_table), reinterpret_cast<const float2*>(rad_table),
         reinterpret_cast<float4*>(dual_table), n_entries);
     return ls2fm_launch_status();
+}
+
+// cost-balanced cut of the walking order [grid 1 levels .., grid 2 levels ..] x chunks into 8 XCD pieces
+static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid_desc* g2, int l2, int n_samples, int n_chunks,
+                             int* most) {
+    static const double dense_w = [] { const char* e = getenv("LS2FM_DENSE_W"); return e ? atof(e) : -1.0; }();   // experiments
+    double cost[2 * LS2FM_MAX_LEVELS], total = 0.0;
+    const int n_pl = l1 + l2;
+    for (int pl = 0; pl < n_pl; ++pl) {
+        const ls2fm_grid_desc* gd = pl < l1 ? g1 : g2;
+        const int l = pl < l1 ? pl : pl - l1;
+        if (dense_w >= 0.0) {
+            cost[pl] = gd->hashed[l] ? 1.0 : dense_w;
+        } else {        // measured (tools/enc_ticks.py): dense levels ~0.28 of a fine hashed level; hashed levels grow with the
+                        // number of distinct cells a wave's consecutive samples touch (scale / n_samples)
+            const double rho = (double)gd->scale[l] / (double)n_samples;
+            const double h = 0.45 + 0.25 * log2(1.0 + rho);
+            cost[pl] = gd->hashed[l] ? (h > 0.95 ? 0.95 : h) : 0.28;
+        }
+        total += cost[pl];
+    }
+    XcdPlan plan;
+    plan.start[0] = 0;
+    *most = 0;
+    for (int x = 1; x <= 8; ++x) {
+        const double target = total * x / 8.0;       // cumulative cost at the end of XCD x - 1's piece
+        double acc = 0.0;
+        int unit = n_pl * n_chunks;
+        for (int pl = 0; pl < n_pl; ++pl) {
+            if (acc + cost[pl] >= target - 1e-9) {
+                unit = pl * n_chunks + (int)((target - acc) / cost[pl] * n_chunks + 0.5);
+                break;
+            }
+            acc += cost[pl];
+        }
+        if (x == 8 || unit > n_pl * n_chunks) unit = n_pl * n_chunks;
+        if (unit < plan.start[x - 1]) unit = plan.start[x - 1];
+        plan.start[x] = unit;
+        *most = *most > unit - plan.start[x - 1] ? *most : unit - plan.start[x - 1];
+    }
+    return plan;
 }
 
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
@@ -419,30 +439,21 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ls2fm_prof_end(LS2FM_PROF_PREP, ps);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
     const int n_chunks = (int)((w.p + 255) / 256);
-    const unsigned eg = (unsigned)(8 * ((L1 + 7) / 8) * n_chunks);          // 1-D grid, XCD-aware (level, chunk) mapping
     const bool interleaved = dual && params->dual_table;
-    const bool pair = dual && !interleaved;      // one launch for both grids
+    const bool pair = dual && !interleaved;      // both grids, one launch
     const int enc_span = pair ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;
+    int most = 0;
+    const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, &most);
     ls2fm_prof_begin(enc_span, s);
-    if (pair) {
-        const int rounds = (L1 > L2 ? L1 : L2) > 8 ? 2 : 1;
-        ray_encode_pair_kernel<<<(unsigned)(8 * 2 * rounds * n_chunks), 256, 0, s>>>(
-            make_level_set(sdf_grid), make_level_set(rad_grid), fc, center, ray, params->sdf_table, params->rad_table, w.p, w.p_pad,
-            n_chunks, rounds, ws + w.e1, ws + w.e2, ws + w.j1);
-    } else if (interleaved)
-        ray_encode_dual_kernel<<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray,
-                                                  reinterpret_cast<const float4*>(params->dual_table), w.p, w.p_pad, n_chunks,
-                                                  ws + w.e1, ws + w.e2, ws + w.j1);
+    if (interleaved)
+        ray_encode_dual_kernel<<<(unsigned)(8 * most), 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray,
+                                                                    reinterpret_cast<const float4*>(params->dual_table), w.p,
+                                                                    w.p_pad, n_chunks, plan, ws + w.e1, ws + w.e2, ws + w.j1);
     else
-        ray_encode_kernel<true><<<eg, 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray, params->sdf_table, w.p, w.p_pad,
-                                                  n_chunks, ws + w.e1, ws + w.j1);
+        ray_encode_kernel<<<(unsigned)(8 * most), 256, 0, s>>>(
+            make_level_set(sdf_grid), make_level_set(pair ? rad_grid : sdf_grid), fc, center, ray, params->sdf_table,
+            pair ? params->rad_table : nullptr, w.p, w.p_pad, n_chunks, plan, ws + w.e1, pair ? ws + w.e2 : nullptr, ws + w.j1);
     ls2fm_prof_end(enc_span, s);
-    if (dual && !interleaved && !pair) {
-        ls2fm_prof_begin(LS2FM_PROF_ENCODE_RAD, s);
-        ray_encode_kernel<false><<<eg, 256, 0, s>>>(make_level_set(rad_grid), fc, center, ray, params->rad_table, w.p, w.p_pad,
-                                                   n_chunks, ws + w.e2, nullptr);
-        ls2fm_prof_end(LS2FM_PROF_ENCODE_RAD, s);
-    }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
     ls2fm_launch_shade_fwd(fc, dual, 2 * L1, 2 * L2, pk, center, ray, n_rays, w, ws, rgb, sdfs_volume, normals, depth_mlp,
