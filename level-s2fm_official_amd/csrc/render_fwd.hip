@@ -202,7 +202,8 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
 struct XcdPlan { int start[9]; };
 
 #ifdef LS2FM_STAMPS
-__device__ unsigned long long g_enc_ticks[2 * LS2FM_MAX_LEVELS];     // summed workgroup durations per pass-level (100 MHz)
+__device__ unsigned long long g_enc_ticks[2 * LS2FM_MAX_LEVELS + 24];    // [0,32) summed workgroup durations per pass-level
+                                                                          // (100 MHz); [32,40) last end per XCD; [40,48) first start
 #endif
 
 __global__ void __launch_bounds__(256)
@@ -258,7 +259,12 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     }
 #ifdef LS2FM_STAMPS
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&g_enc_ticks[pl], (unsigned long long)(wall_clock64() - t_begin));
+    if (threadIdx.x == 0) {
+        const long long t_end = wall_clock64();
+        atomicAdd(&g_enc_ticks[pl], (unsigned long long)(t_end - t_begin));
+        atomicMax(&g_enc_ticks[32 + xcd], (unsigned long long)t_end);
+        atomicMin(&g_enc_ticks[40 + xcd], (unsigned long long)t_begin);
+    }
 #endif
 }
 
@@ -326,8 +332,13 @@ interleave_tables_kernel(const float2* __restrict__ a, const float2* __restrict_
 }  // namespace
 
 #ifdef LS2FM_STAMPS
+extern "C" int ls2fm_debug_enc_reset(void) {
+    unsigned long long init[2 * LS2FM_MAX_LEVELS + 24];
+    for (int i = 0; i < 2 * LS2FM_MAX_LEVELS + 24; ++i) init[i] = i >= 40 && i < 48 ? ~0ull : 0ull;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_enc_ticks), init, sizeof(init)) == hipSuccess ? 0 : -1;
+}
 extern "C" int ls2fm_debug_enc_ticks(unsigned long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enc_ticks), sizeof(unsigned long long) * 2 * LS2FM_MAX_LEVELS) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enc_ticks), sizeof(unsigned long long) * (2 * LS2FM_MAX_LEVELS + 24)) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -15,12 +15,25 @@ sdf, rad, ren = SDF(opt).to("cuda"), RadF(opt).to("cuda"), Renderer(opt)
 bench.randomize([sdf, rad])
 center, ray = bench.synthetic_rays(1024, 5.0, "cuda")
 n = 20
+lib = _lib.load()
 with torch.no_grad():
+    for _ in range(3):
+        ren.forward(opt, center, ray, sdf, rad)
+    torch.cuda.synchronize()
+    assert lib.ls2fm_debug_enc_reset() == 0
+    ren.forward(opt, center, ray, sdf, rad)            # one launch: per-XCD first start / last end
+    torch.cuda.synchronize()
+    one = (ctypes.c_ulonglong * 56)()
+    assert lib.ls2fm_debug_enc_ticks(one) == 0
+    t0 = min(one[40:48])
+    print("per XCD: start %s  end %s (us after the first start)" % ([round((v - t0) / 100.0, 1) for v in one[40:48]],
+                                                                   [round((v - t0) / 100.0, 1) for v in one[32:40]]))
+    assert lib.ls2fm_debug_enc_reset() == 0
     for _ in range(n):
         ren.forward(opt, center, ray, sdf, rad)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 32)()
-assert _lib.load().ls2fm_debug_enc_ticks(buf) == 0
+buf = (ctypes.c_ulonglong * 56)()
+assert lib.ls2fm_debug_enc_ticks(buf) == 0
 t = [b / n / 100.0 for b in buf]          # us of summed workgroup time per launch
 ref = max(t)
 d = sdf.embed_fn.embedder_obj.desc
