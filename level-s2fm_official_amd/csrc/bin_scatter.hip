@@ -2,7 +2,7 @@
 // that STREAM their payload lists and accumulate in exact 64-bit fixed point.
 // No table-wide global atomics, no floating-point atomics, no gathers in the accumulate phase.
 //
-// Measurements on MI355X that shaped this design (profiles/r01_*, tools/atomic_bench.hip, tools/stamps.py):
+// Measurements on MI355X that shaped this design (profiles/r01_*, tools/atomic_bench.hip, tools/acc_stamps.py):
 //   * global fp32 atomics: 17-21 G/s at every scope (memory side; the 8 XCD L2s are not coherent): a tcnn-style scatter
 //     was 80 % of the step
 //   * LDS ds_add_f32 ~0.26 lane/clk/CU, but LDS ds_add_u64 ~3160 G/s chip-wide (30x): accumulate in 64-bit fixed point
