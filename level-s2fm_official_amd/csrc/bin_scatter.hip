@@ -38,9 +38,9 @@ namespace {
 constexpr int kAccSlots = 2 << kSlabShift;       // 16384 u64 accumulators = 128 KiB of LDS per workgroup
 constexpr int kSlabBins = 128;                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
 constexpr int kBins = kSlabBins;
-constexpr int kCountThreads = 256;
-constexpr int kFillThreads = 256;                // one sample point per thread
-constexpr int kFillCap = kFillThreads * 5;       // items staged in LDS per workgroup (4 per point + split pairs)
+constexpr int kCountThreads = 512;
+constexpr int kFillThreads = 512;                // one sample point per thread
+constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
 constexpr int kAccThreads = 1024;
 constexpr int kMaxParts = 16;
 
