@@ -175,7 +175,7 @@ extern "C" int ls2fm_loss_head_fwd(const float* rgb, const float* rgb_gt, const 
     unsigned* ticket = reinterpret_cast<unsigned*>(workspace);
     double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 64);
     const int64_t n_points = n_rays * n_samples;
-    int64_t blocks = (n_points + kLossThreads * 4 - 1) / (kLossThreads * 4);
+    int64_t blocks = (n_points + kLossThreads * 8 - 1) / (kLossThreads * 8);      // 8 points per thread: measured optimum (4: 18.8 us, 8: 16.2, 16: 17.6)
     blocks = blocks < 1 ? 1 : (blocks > kLossMaxBlocks ? kLossMaxBlocks : blocks);
     ls2fm_prof_begin(LS2FM_PROF_LOSS_FWD, s);
     loss_head_fwd_kernel<<<(unsigned)blocks, kLossThreads, 0, s>>>(
