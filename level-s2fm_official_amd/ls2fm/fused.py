@@ -217,7 +217,7 @@ def _refresh_dual_table(lib, plan, sdf_table, rad_table):
         key = None          # a captured step cannot re-check versions at replay: the refresh becomes part of the graph
     elif plan.dual_key == key and _DUAL_TABLE != "always":
         return
-    if not (_is_table(sdf_table) and _is_table(rad_table) and sdf_table.numel() == rad_table.numel()):
+    if not (sdf_table.dim() == 1 and rad_table.dim() == 1 and sdf_table.numel() == rad_table.numel()):
         raise RuntimeError("ls2fm: dual-field tables of different size")
     if plan.dual_table is None or plan.dual_table.numel() != 2 * sdf_table.numel() or \
             plan.dual_table.device != sdf_table.device:

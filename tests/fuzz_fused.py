@@ -3,7 +3,7 @@
 random ray counts, sample counts, datasets, level counts / table sizes, field modes and upstream-gradient subsets.
 Quantities the fp32 composed form itself cannot resolve to the bar (sums of terms of both signs over every sample: d beta,
 the last layer's bias / weight_g under random cotangents) are re-judged against the CPU oracle run in fp64.
-usage: python tests/fuzz_fused.py [n_cases] [seed]    (pytest entry: tests/test_hip_fuzz.py)"""
+usage: python tests/fuzz_fused.py [n_cases] [seed] [only_case]    (pytest entry: tests/test_hip_fuzz.py)"""
 import os
 import random
 import sys
@@ -27,20 +27,24 @@ def _tol(name):
     return 5e-4 if name == "s.beta" else 1e-4
 
 
-def oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot):
+def oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot, pose=False):
     """the same scalar through the CPU oracle in float64 -> {name: gradient}"""
     cfg = OF.dataset_config(ds, dual_field=dual, sample_intvs=n_samples, n_levels=L, log2_hashmap_size=log2_T,
                             base_resolution=base, bgcolor=tuple(bg), inside=bool(opt.data.inside))
     osd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in sdf.state_dict().items()}
     ord_ = {k: v.detach().cpu().double().requires_grad_(True) for k, v in rad.state_dict().items()}
-    ret = OF.render(cfg, center.cpu().double(), ray.cpu().double(), osd, ord_)
+    c64 = center.cpu().double().requires_grad_(pose)
+    r64 = ray.cpu().double().requires_grad_(pose)
+    ret = OF.render(cfg, c64, r64, osd, ord_)
     sum((ret[k] * cot[k].cpu().double()).sum() for k in used).backward()
     out = {"s." + k: v.grad for k, v in osd.items() if v.grad is not None}
     out.update({"r." + k: v.grad for k, v in ord_.items() if v.grad is not None})
+    if pose:
+        out["d_center"], out["d_ray"] = c64.grad, r64.grad
     return out
 
 
-def one_case(case, rng):
+def one_case(case, rng, skip=False):
     ds = rng.choice(["DTU", "ETH3D", "BlendedMVS", "scannet"])
     dual = rng.random() < 0.6
     n_samples = rng.choice([1, 3, 17, 32, 64, 100, 128, 129, 200, 256, 257, 400, 512])
@@ -57,11 +61,13 @@ def one_case(case, rng):
                        bgcolor=bg)
     if rng.random() < 0.3:
         opt.data.inside = not opt.data.inside
+    used = [k for k in KEYS if rng.random() < 0.7] or ["rgb"]
+    if skip:                       # every random draw of the case is done: the stream stays aligned for the cases after it
+        return None
     sdf, rad, ren = _randomized(opt, 100 + case)
     s = float(opt.data.bound_max[0])
     center, ray = _rays(max(n_rays, 6), s, 200 + case)
     center, ray = center[:, :n_rays].contiguous(), ray[:, :n_rays].contiguous()
-    used = [k for k in KEYS if rng.random() < 0.7] or ["rgb"]
     gen = torch.Generator(device=DEV).manual_seed(case)
     cot, res = None, {}
     took = fused.can_render(ren, opt, center, ray, sdf, rad)
@@ -87,8 +93,8 @@ def one_case(case, rng):
         if not errs["g:" + k] < _tol(k):
             bad.append((k, errs["g:" + k]))
     judged = ""
-    if bad and all(k[:2] in ("s.", "r.") for k, _ in bad):
-        o64 = oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot)
+    if bad and all(k[:2] in ("s.", "r.", "d_") for k, _ in bad):
+        o64 = oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot, pose)
         still = []
         for k, _ in bad:
             ef, ec = rel_err(res["fused"][1][k], o64[k]), rel_err(res["composed"][1][k], o64[k])
@@ -101,11 +107,14 @@ def one_case(case, rng):
     return tag, bad, judged, errs
 
 
-def run(n_cases, seed, verbose=True):
+def run(n_cases, seed, verbose=True, only=None):
     rng = random.Random(seed)
     worst, failures = {}, []
     for case in range(n_cases):
-        tag, bad, judged, errs = one_case(case, rng)
+        res = one_case(case, rng, skip=only is not None and case != only)
+        if res is None:
+            continue
+        tag, bad, judged, errs = res
         for k, e in errs.items():
             worst[k] = max(worst.get(k, 0.0), e)
         if bad:
@@ -116,7 +125,8 @@ def run(n_cases, seed, verbose=True):
 
 
 if __name__ == "__main__":
-    fails, worst = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    fails, worst = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                       only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
     print("worst relative errors (fused vs composed fp32):", {k: float(f"{v:.2e}") for k, v in sorted(worst.items())})
     print(f"{len(fails)} failing case(s)")
     sys.exit(1 if fails else 0)
