@@ -7,6 +7,8 @@
 //   sphere_trace  two lanes per ray (start end / far end), the reference's `while True` (models/SDF.py:149-200)
 //                 run to completion per ray without host round trips; the global trip count K of the reference is
 //                 recovered as max over rays of the first trip at which the ray's start end is finished.
+#include <cstdlib>
+
 #include "render_common.h"
 
 int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream);
@@ -194,6 +196,119 @@ sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pack
     if ((threadIdx.x & 63) == 0 && kmax > 0) atomicMax(trips, kmax);
 }
 
+// ---- sphere tracing, one 16-lane group per ray END (four ends = two rays per wave).  The thread-per-end kernel above is
+// bound by the latency of its serial chain -- 11 SDF evaluations, each 16 levels of dependent gathers and 3.3 k scalar-operand
+// FMAs in ONE lane: 477 us for 8192 rays with one wave per CU.  Here lane jl of a group gathers level jl, the 35 inputs are
+// exchanged by shuffles, the lane evaluates hidden units jl, jl + 16, jl + 32, jl + 48 from an LDS copy of W0 and the sdf row is a
+// 16-lane reduction: the same loop (steps 1-7 below are those of sphere_trace_kernel) with a ~10x shorter step.
+constexpr int kW0Stride = 36;       // W0[j][0..34], b0[j] : 16-byte aligned rows, 2-way bank conflicts at most
+
+__device__ __forceinline__ float group_sdf(const LevelSet& lv, const FieldC& fc, int bg_sdf, float bg_rad,
+                                           const float* __restrict__ table, const float* __restrict__ s_w0,
+                                           const float* __restrict__ s_w1, float b1_0, const float p[3], int jl, int gbase) {
+    float x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+    float y0 = 0.f, y1 = 0.f;
+    if (jl < lv.n_levels) {
+        Cell c;
+        locate(x, lv.scale[jl], lv.res[jl], lv.size[jl], lv.offset[jl], lv.hashed[jl], c);
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float wt = corner_weight(c.w, k);
+            y0 = fmaf(wt, v[k].x, y0);
+            y1 = fmaf(wt, v[k].y, y1);
+        }
+    }
+    float u[kInMax];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = p[a] / fc.rescale;
+#pragma unroll
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+        u[3 + 2 * l] = __shfl(y0, gbase + l, 64);
+        u[4 + 2 * l] = __shfl(y1, gbase + l, 64);
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* __restrict__ w = s_w0 + (jl + 16 * q) * kW0Stride;
+        float a0 = w[kRecB0], a1 = 0.0f;           // same two-chain order as geometry_forward
+#pragma unroll
+        for (int k = 0; k + 1 < kInMax; k += 2) {
+            a0 = fmaf(w[k], u[k], a0);
+            a1 = fmaf(w[k + 1], u[k + 1], a1);
+        }
+        a0 = fmaf(w[kInMax - 1], u[kInMax - 1], a0);
+        part = fmaf(s_w1[jl + 16 * q], softplus100_value(a0 + a1), part);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o, 64);
+    bool bg;
+    return signed_sdf(fc, bg_sdf, bg_rad, part + b1_0, p, &bg);
+}
+
+__global__ void __launch_bounds__(256)
+sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
+                         const float* __restrict__ table, const float* __restrict__ ray0, const float* __restrict__ ray_dir,
+                         int64_t n_rays, float thr, int iters_max, float* __restrict__ near_out, float* __restrict__ far_out,
+                         float* __restrict__ track, float* __restrict__ t_end, int* __restrict__ trips) {
+    __shared__ float s_w0[kHidden * kW0Stride];
+    __shared__ float s_w1[kHidden];
+    for (int q = threadIdx.x; q < kHidden * kW0Stride; q += 256) s_w0[q] = pk->sdf[(q / kW0Stride) * kRecStride + q % kW0Stride];
+    for (int q = threadIdx.x; q < kHidden; q += 256) s_w1[q] = pk->sdf[q * kRecStride + kRecW1];
+    const float b1_0 = pk->sdf[kHidden * kRecStride];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, jl = lane & 15, gq = lane >> 4, gbase = lane & 48;
+    const int side = gq & 1;
+    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (gq >> 1);
+    const bool live = r < n_rays;
+    const int64_t rr_ = live ? r : n_rays - 1;
+    const RayGeom g = load_ray(fc, ray0, ray_dir, rr_);
+    const float far = g.t_far;
+    float t_me = side ? g.t_far : g.t_near;
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
+    float sdf_me = group_sdf(lv, fc, bg_sdf, bg_rad, table, s_w0, s_w1, b1_0, p, jl, gbase);
+    const bool writer = live && jl == 0;
+    if (writer && side == 0) { near_out[r] = g.t_near; far_out[r] = g.t_far; }
+    if (writer && side == 1) t_end[r * (iters_max + 1)] = t_me;
+    bool unf = false;
+    int kfin = -1;
+    for (int k = 0;; ++k) {
+        if (fabsf(sdf_me) <= thr) sdf_me = 0.f;                          // (1) converged values are zeroed
+        const bool m = fabsf(sdf_me) > thr;
+        unf = k == 0 ? m : (unf && m);                                    // (2)
+        const int unf_start = __shfl((int)unf, lane & ~16, 64);           // the start end's group of this ray
+        if (!unf_start && kfin < 0) kfin = k;                             // (3) this ray's start end is done at trip k
+        if (k == iters_max) break;
+        if (writer && side == 0) {                                        // (5) pre-update start point -> track
+#pragma unroll
+            for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + k) * 3 + a] = p[a];
+        }
+        t_me = t_me + sdf_me;                                             // (4) both ends step with '+', clamp to far
+        if (t_me > far) t_me = far;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
+        if (unf) sdf_me = group_sdf(lv, fc, bg_sdf, bg_rad, table, s_w0, s_w1, b1_0, p, jl, gbase);   // (6) group-uniform
+        const float t_other = __shfl_xor(t_me, 16, 64);
+        const float t_s = side ? t_other : t_me, t_e = side ? t_me : t_other;
+        unf = unf && (t_s < t_e);                                         // (7) crossed ends drop out
+        if (writer && side == 1) t_end[r * (iters_max + 1) + k + 1] = t_me;
+    }
+    if (writer && side == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + iters_max) * 3 + a] = p[a];
+    }
+    int kmax = (writer && side == 0) ? (kfin < 0 ? iters_max : kfin) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+    if (lane == 0 && kmax > 0) atomicMax(trips, kmax);
+}
+
 }  // namespace
 
 static bool field_ok(const ls2fm_field_desc* f, const ls2fm_grid_desc* g, const ls2fm_params* p) {
@@ -269,11 +384,19 @@ extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_gri
     Packed* pk = (Packed*)workspace;
     int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
     if (st != LS2FM_OK) return st;
-    const unsigned blocks = (unsigned)((2 * n_rays + 255) / 256);
+    // latency-bound below ~40 k rays (wide: 16 lanes per ray end, 8192 rays 131 us against 479), throughput-bound above (one
+    // lane per ray end: no redundant lanes; 65536 rays 0.84 against 1.04 ms)
+    static const int force = [] { const char* e = getenv("LS2FM_TRACE_KERNEL"); return e ? atoi(e) : 0; }();      // 1 narrow, 2 wide
+    const bool narrow = force == 1 || (force != 2 && n_rays > 40000);
     ls2fm_prof_begin(LS2FM_PROF_SPHERE_TRACE, s);
-    sphere_trace_kernel<<<blocks, 256, 0, s>>>(make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk,
-                                               params->sdf_table, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far,
-                                               track, t_end, trips);
+    if (narrow)
+        sphere_trace_kernel<<<(unsigned)((2 * n_rays + 255) / 256), 256, 0, s>>>(
+            make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk, params->sdf_table, ray0, ray_dir, n_rays,
+            sdf_threshold, iters_max, near, far, track, t_end, trips);
+    else            // 8 rays per 256-thread workgroup
+        sphere_trace_wide_kernel<<<(unsigned)((n_rays + 7) / 8), 256, 0, s>>>(
+            make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk, params->sdf_table, ray0, ray_dir, n_rays,
+            sdf_threshold, iters_max, near, far, track, t_end, trips);
     ls2fm_prof_end(LS2FM_PROF_SPHERE_TRACE, s);
     return ls2fm_launch_status();
 }
