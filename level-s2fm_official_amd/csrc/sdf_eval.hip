@@ -199,9 +199,21 @@ sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pack
 // ---- sphere tracing, one 16-lane group per ray END (four ends = two rays per wave).  The thread-per-end kernel above is
 // bound by the latency of its serial chain -- 11 SDF evaluations, each 16 levels of dependent gathers and 3.3 k scalar-operand
 // FMAs in ONE lane: 477 us for 8192 rays with one wave per CU.  Here lane jl of a group gathers level jl, the 35 inputs are
-// exchanged by shuffles, the lane evaluates hidden units jl, jl + 16, jl + 32, jl + 48 from an LDS copy of W0 and the sdf row is a
-// 16-lane reduction: the same loop (steps 1-7 below are those of sphere_trace_kernel) with a ~10x shorter step.
+// exchanged by shuffles, the lane evaluates hidden units jl, jl + 16, jl + 32, jl + 48 from an LDS copy of W0 and the sdf row is summed
+// in the thread-per-end kernel's order (bit-identical results): the same loop (steps 1-7 below are those of sphere_trace_kernel) with a ~10x shorter step.
 constexpr int kW0Stride = 36;       // W0[j][0..34], b0[j] : 16-byte aligned rows, 2-way bank conflicts at most
+
+// f += w[J] * (lane J of this lane's 16-lane row).h for J = 0 .. 15, one fmaf chain; the broadcast is a DPP row_share operand
+// (full-rate VALU), not an LDS permute
+template <int J>
+__device__ __forceinline__ float row_chain(const float* __restrict__ w, float h, float f) {
+    if constexpr (J < 16) {
+        const float hv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(h), 0x150 + J, 0xF, 0xF, false));
+        return row_chain<J + 1>(w, h, fmaf(w[J], hv, f));
+    } else {
+        return f;
+    }
+}
 
 __device__ __forceinline__ float group_sdf(const LevelSet& lv, const FieldC& fc, int bg_sdf, float bg_rad,
                                            const float* __restrict__ table, const float* __restrict__ s_w0,
@@ -231,7 +243,7 @@ __device__ __forceinline__ float group_sdf(const LevelSet& lv, const FieldC& fc,
         u[3 + 2 * l] = __shfl(y0, gbase + l, 64);
         u[4 + 2 * l] = __shfl(y1, gbase + l, 64);
     }
-    float part = 0.f;
+    float h[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float* __restrict__ w = s_w0 + (jl + 16 * q) * kW0Stride;
@@ -242,12 +254,34 @@ __device__ __forceinline__ float group_sdf(const LevelSet& lv, const FieldC& fc,
             a1 = fmaf(w[k + 1], u[k + 1], a1);
         }
         a0 = fmaf(w[kInMax - 1], u[kInMax - 1], a0);
-        part = fmaf(s_w1[jl + 16 * q], softplus100_value(a0 + a1), part);
+        h[q] = softplus100_value(a0 + a1);
     }
+    // the sdf row in geometry_forward's order (j = 0 .. 63, one fmaf chain): every lane of the group forms the same sum, and
+    // the result is BIT-IDENTICAL to the thread-per-point kernels (a point evaluates the same in a small and in a large call)
+    float f0 = b1_0;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o, 64);
+    for (int q = 0; q < 4; ++q) f0 = row_chain<0>(s_w1 + 16 * q, h[q], f0);
     bool bg;
-    return signed_sdf(fc, bg_sdf, bg_rad, part + b1_0, p, &bg);
+    return signed_sdf(fc, bg_sdf, bg_rad, f0, p, &bg);
+}
+
+// sdf only, 16 lanes per point: the latency-bound small calls of infer_sdf(mode="ret_sdf") (thread-per-point: ~90 us however
+// few the points)
+__global__ void __launch_bounds__(256)
+sdf_eval_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
+                     const float* __restrict__ table, const float* __restrict__ pts, int64_t n, float* __restrict__ sdf_out) {
+    __shared__ float s_w0[kHidden * kW0Stride];
+    __shared__ float s_w1[kHidden];
+    for (int q = threadIdx.x; q < kHidden * kW0Stride; q += 256) s_w0[q] = pk->sdf[(q / kW0Stride) * kRecStride + q % kW0Stride];
+    for (int q = threadIdx.x; q < kHidden; q += 256) s_w1[q] = pk->sdf[q * kRecStride + kRecW1];
+    const float b1_0 = pk->sdf[kHidden * kRecStride];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, jl = lane & 15, gbase = lane & 48;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t ii = i < n ? i : n - 1;
+    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+    const float v = group_sdf(lv, fc, bg_sdf, bg_rad, table, s_w0, s_w1, b1_0, p, jl, gbase);
+    if (i < n && jl == 0) sdf_out[i] = v;
 }
 
 __global__ void __launch_bounds__(256)
@@ -332,7 +366,10 @@ extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_de
     const LevelSet lv = make_level_set(grid);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     ls2fm_prof_begin(LS2FM_PROF_SDF_EVAL, s);
-    if (normal)
+    if (!normal && !feat && n <= 65536)       // sdf only, few points: latency-bound -> 16 lanes per point (bit-identical)
+        sdf_eval_wide_kernel<<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table,
+                                                                      p, n, sdf);
+    else if (normal)
         sdf_eval_kernel<true><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, Lattice{},
                                                      n, sdf, feat, normal);
     else
@@ -384,10 +421,11 @@ extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_gri
     Packed* pk = (Packed*)workspace;
     int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
     if (st != LS2FM_OK) return st;
-    // latency-bound below ~40 k rays (wide: 16 lanes per ray end, 8192 rays 131 us against 479), throughput-bound above (one
-    // lane per ray end: no redundant lanes; 65536 rays 0.84 against 1.04 ms)
+    // latency-bound at stage-loop sizes (wide: 16 lanes per ray end; 8192 rays 0.26 ms per call against 0.52, 1024 rays 0.13
+    // against 0.53), throughput-bound at tens of thousands of rays (one lane per ray end: no redundant lanes).  Both kernels
+    // give bit-identical results.
     static const int force = [] { const char* e = getenv("LS2FM_TRACE_KERNEL"); return e ? atoi(e) : 0; }();      // 1 narrow, 2 wide
-    const bool narrow = force == 1 || (force != 2 && n_rays > 40000);
+    const bool narrow = force == 1 || (force != 2 && n_rays > 20000);
     ls2fm_prof_begin(LS2FM_PROF_SPHERE_TRACE, s);
     if (narrow)
         sphere_trace_kernel<<<(unsigned)((2 * n_rays + 255) / 256), 256, 0, s>>>(

@@ -11,7 +11,7 @@ from ls2fm.models.SDF import SDF
 opt = make_options("DTU", device="cuda", dual_field=True)
 sdf = SDF(opt).to("cuda")
 bench.randomize([sdf])
-for R in (1024, 8192, 16384, 32768, 65536):
+for R in (1024, 8192, 16384, 24576, 32768, 65536):
     c, d = bench.synthetic_rays(R, 1.0, "cuda")
     o, dd = c.view(-1, 3), d.view(-1, 3)
     with torch.no_grad():
@@ -43,3 +43,20 @@ with torch.no_grad():
 torch.cuda.synchronize()
 lib.ls2fm_profile_enable(0)
 print({k: round(v[0], 1) for k, v in prof.kernel_times(lib).items()})
+# small-batch latency of the no-graph SDF evaluation
+for n_pts in (1024, 8192, 65536):
+    p = (torch.rand(n_pts, 3, device="cuda") * 2 - 1)
+    lib.ls2fm_profile_reset(); lib.ls2fm_profile_enable(1)
+    with torch.no_grad():
+        for _ in range(20):
+            fused.sdf_eval(sdf, p, want_feat=True, want_normal=True)
+    torch.cuda.synchronize(); lib.ls2fm_profile_enable(0)
+    print(n_pts, "points, sdf+feat+normal:", {k: round(v[0], 1) for k, v in prof.kernel_times(lib).items()})
+for n_pts in (1024, 8192, 65536, 131072, 262144):
+    p = (torch.rand(n_pts, 3, device="cuda") * 2 - 1)
+    lib.ls2fm_profile_reset(); lib.ls2fm_profile_enable(1)
+    with torch.no_grad():
+        for _ in range(20):
+            sdf.infer_sdf(p)
+    torch.cuda.synchronize(); lib.ls2fm_profile_enable(0)
+    print(n_pts, "points, sdf only:", {k: round(v[0], 1) for k, v in prof.kernel_times(lib).items()})
