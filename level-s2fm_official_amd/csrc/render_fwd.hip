@@ -46,6 +46,7 @@ __device__ __forceinline__ int row_base(int li) {
 __global__ void __launch_bounds__(256)
 prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad,
                     Packed* __restrict__ out) {
+    // with_rad == 0: the no-graph SDF evaluation / sphere tracing -- scalar records of the SDF MLP only, no MFMA-ordered copies
     __shared__ float row_scale[296];
     const int tid = threadIdx.x;
     // one workgroup per independent task (a single workgroup doing everything was a 72 us latency chain that gated
@@ -88,6 +89,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             dst[idx] = val;
         }
         for (int o = tid; o < 32; o += 256) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
+        if (!with_rad) continue;
         // MFMA-operand-ordered copies (shade kernels): see MfmaW
         auto w0p = [&](int j, int kp) -> float {
             if (kp < 32) return 3 + kp < ind ? L0.v[j * ind + 3 + kp] * s0[j] : 0.f;
