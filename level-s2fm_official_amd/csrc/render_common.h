@@ -218,7 +218,9 @@ struct WsLayout {
 
 constexpr int kSlabShift = 13;          // table-gradient scatter: 8192-entry slabs of one grid, or 4096-entry slabs of both
 static inline int ls2fm_slab_shift(int dual) { return dual ? kSlabShift - 1 : kSlabShift; }
-constexpr int kWgradMlpBlocks = 512;   // persistent workgroups of wgrad_mlp (2 per CU)
+constexpr int kWgradMlpBlocks = 256;   // persistent workgroups of wgrad_mlp: ONE per CU -- alone the kernels are slower than with two
+                                      // (63 + 43 vs 52 + 34 us), but they run beside scatter_fill / slab_accumulate and leave them
+                                      // more of the CU: step 0.656 -> 0.638 ms (graph), 128 or 192 workgroups are slower again
 int64_t ls2fm_wgrad_mlp_part_floats(int dual);
 
 // reduced raw weight gradients (floats)
