@@ -61,9 +61,10 @@ def global_max_int(value: int, device) -> int:
 
 
 class GradAllReducer:
-    """Sum-all-reduce of `.grad` of a parameter list.  When every gradient already is a view of one flat buffer (the
-    fused backward allocates them that way, ls2fm.fused.small_grad_buffer) that buffer is reduced in place as ONE
-    message; otherwise big tensors go individually and the small ones through a packed flat buffer."""
+    """Sum-all-reduce of `.grad` of a parameter list.  When every gradient already lives in one flat buffer (the fused
+    backward allocates them that way and attaches the buffer to the Parameters, ls2fm.fused.flat_gradient_views) that
+    buffer is reduced in place as ONE message; otherwise big tensors go individually and the small ones through a
+    packed flat buffer."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], big_numel: int = 1 << 20, average: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -72,28 +73,28 @@ class GradAllReducer:
         self.average = average
         self._flat: Optional[torch.Tensor] = None
 
-    def _shared_flat(self) -> Optional[torch.Tensor]:
-        from . import fused
-        flat = fused.small_grad_buffer()
-        if flat is None:
-            return None
-        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
-        for p in self.small:
-            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+    @staticmethod
+    def _flat_holding(params) -> Optional[torch.Tensor]:
+        """the one flat buffer every gradient of `params` lives in, or None"""
+        flat = None
+        for p in params:
+            f = getattr(p, "_ls2fm_grad_flat", None)
+            if f is None or p.grad is None or (flat is not None and f is not flat):
+                return None
+            flat = f
+            lo, hi = f.data_ptr(), f.data_ptr() + f.numel() * 4
+            if not (lo <= p.grad.data_ptr() and p.grad.data_ptr() + p.grad.numel() * 4 <= hi and p.grad.is_contiguous()):
                 return None
         return flat
 
+    def _shared_flat(self) -> Optional[torch.Tensor]:
+        return self._flat_holding(self.small) if self.small else None
+
     def _all_in_flat(self) -> Optional[torch.Tensor]:
-        from . import fused
-        flat = fused.small_grad_buffer()
+        flat = self._flat_holding(self.params) if self.params else None
         if flat is None:
             return None
-        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
-        covered = 0
-        for p in self.params:
-            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
-                return None
-            covered += p.grad.numel()
+        covered = sum((p.grad.numel() + 3) // 4 * 4 for p in self.params)         # 16-byte segments
         return flat if covered == flat.numel() else None     # nothing else lives in the buffer
 
     def all_reduce(self) -> None:

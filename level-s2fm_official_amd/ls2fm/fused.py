@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -88,22 +89,46 @@ def can_eval_without_graph(sdf_field, xyz) -> bool:
 class _Plan:
     """Everything about one (renderer, SDF field, radiance field, opt) combination that does not change from call to
     call: the gating verdict, the descriptor structs, the parameter list.  Rebuilding these costs ~0.2 ms of Python
-    per step -- as much as the device work of a kernel -- so they are cached and keyed on the option values read."""
-    __slots__ = ("key", "ok", "cfg", "ts", "ws_bytes", "pkey", "pstruct", "dual_table", "dual_key")
+    per step -- as much as the device work of a kernel -- so they are cached.  A plan lives in a dict ON the renderer
+    object (it dies with it), holds the two field modules weakly (it is dropped when either is freed, so a recycled
+    id() can never resurrect it) and is only reused while (a) every option / descriptor value the kernels read and (b)
+    the identity of every Parameter and grid descriptor are unchanged."""
+    __slots__ = ("key", "ok", "cfg", "ts", "ws_bytes", "pkey", "pstruct", "dual_table", "dual_key", "sdf_ref", "rad_ref",
+                 "__weakref__")
 
 
-_PLANS = {}
+def _plan_key(renderer, opt, sdf_field, rad_field):
+    """every value read from `opt` / the modules that ends up in a descriptor struct or in the gating verdict"""
+    data, vol = opt.data, opt.SDF.VolSDF
+    return (int(vol.sample_intvs), opt.Ablate_config.dual_field == True, data.inside == True,  # noqa: E712
+            data.bg_sdf == True, vol.volsdf_sampling != False, _DISABLE,  # noqa: E712
+            tuple(float(v) for v in data.bound_min), tuple(float(v) for v in data.bound_max), float(vol.rescale),
+            float(opt.SDF.NN_Init.scale_mlp), float(data.bg_rad), tuple(float(v) for v in renderer.bg_host),
+            float(sdf_field.beta_speed))
 
 
 def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
-    ident = (id(renderer), id(sdf_field), id(rad_field))
-    key = (int(opt.SDF.VolSDF.sample_intvs), opt.Ablate_config.dual_field == True, opt.data.inside == True,  # noqa: E712
-           opt.data.bg_sdf == True, opt.SDF.VolSDF.volsdf_sampling != False, _DISABLE)  # noqa: E712
-    pl = _PLANS.get(ident)
-    if pl is not None and pl.key == key:
-        return pl
+    plans = renderer.__dict__.get("_ls2fm_plans")
+    if plans is None:
+        plans = renderer.__dict__["_ls2fm_plans"] = {}
+    ident = (id(sdf_field), id(rad_field))
+    key = _plan_key(renderer, opt, sdf_field, rad_field)
+    pl = plans.get(ident)
+    if pl is not None and pl.key == key and pl.sdf_ref() is sdf_field and pl.rad_ref() is rad_field:
+        if not pl.ok:
+            return pl
+        ts, _ = param_tensors(sdf_field, rad_field)
+        _, g1, g2, dual, _, _ = pl.cfg
+        if len(ts) == len(pl.ts) and all(a is b for a, b in zip(ts, pl.ts)) and \
+                g1 is sdf_field.embed_fn.embedder_obj.desc and (not dual or g2 is rad_field.embed_fn.embedder_obj.desc):
+            return pl
     pl = _Plan()
     pl.key = key
+
+    def _drop(_ref, plans=plans, ident=ident):
+        plans.pop(ident, None)
+    pl.sdf_ref = weakref.ref(sdf_field, _drop)
+    pl.rad_ref = weakref.ref(rad_field, _drop)
     pl.ok = supported(opt, sdf_field, rad_field)
     pl.cfg = pl.ts = pl.pkey = pl.pstruct = pl.dual_table = pl.dual_key = None
     pl.ws_bytes = {}
@@ -113,9 +138,7 @@ def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
         g2 = rad_field.embed_fn.embedder_obj.desc if dual else g1
         pl.cfg = (field_desc(opt, renderer), g1, g2, dual, float(sdf_field.beta_speed), pl)
         pl.ts = ts
-    if len(_PLANS) > 64:
-        _PLANS.clear()
-    _PLANS[ident] = pl
+    plans[ident] = pl
     return pl
 
 
@@ -195,11 +218,21 @@ def _params_struct(ts, dual, beta_speed, with_rad=True, cls=_lib.Params):
 
 
 # ------------------------------------------------------------------------------------------------ render
-_SMALL_GRADS = None      # flat buffer holding every gradient of the latest fused backward
-
-
-def small_grad_buffer():
-    return _SMALL_GRADS
+def flat_gradient_views(ps):
+    """One flat fp32 buffer holding a gradient for each tensor of `ps`, every segment starting on a 16-byte boundary
+    (the table scatter stores float4: csrc/bin_scatter.hip) -> (flat, [views shaped like ps]).  A multi-GPU run
+    all-reduces `flat` as a single message without packing kernels: each tensor of `ps` gets the buffer attached as
+    its `_ls2fm_grad_flat` attribute (it travels with the Parameters whose gradients it holds -- no module state), which is
+    where ls2fm.dist.GradAllReducer looks for it."""
+    offs, at = [], 0
+    for p in ps:
+        offs.append(at)
+        at += (p.numel() + 3) // 4 * 4
+    flat = torch.empty(at, device=ps[0].device, dtype=torch.float32)
+    views = [flat[o:o + p.numel()] if p.dim() == 1 else flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, ps)]
+    for p in ps:
+        p._ls2fm_grad_flat = flat
+    return flat, views
 
 
 def _is_table(p) -> bool:
@@ -291,11 +324,7 @@ class _Render(torch.autograd.Function):
         d_rgb, d_sdfs, d_normals, d_depth, d_nmlp = map(prep, (d_rgb, d_sdfs, d_normals, d_depth, d_nmlp))
         # every gradient -- both tables (overwritten in full by the slab scatter) and the small tensors -- is a view of ONE
         # flat buffer: a multi-GPU run all-reduces it as a single message without packing kernels (ls2fm.dist)
-        global _SMALL_GRADS
-        sizes = [p.numel() for p in ps]
-        flat = torch.empty(sum(sizes), device=c.device, dtype=torch.float32)
-        _SMALL_GRADS = flat
-        grads = [g if p.dim() == 1 else g.view(p.shape) for g, p in zip(flat.split_with_sizes(sizes), ps)]
+        flat, grads = flat_gradient_views(ps)
         pstruct = ctx.pstruct
         gstruct = _params_struct(grads, dual, beta_speed, cls=_lib.ParamGrads)
         want_pose = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
@@ -370,9 +399,10 @@ def sdf_volume(sdf_field, n_side, step, origin, first=0, count=None, reference_i
     return out
 
 
-def sphere_trace(sdf_field, o, d):
+def sphere_trace(sdf_field, o, d, history=False):
     """the reference's root-find loop (SDF.py:149-200) in one kernel.
-    o, d [R,3] -> near [R], far [R], pts_tracks [R,K,3], t_end [R] (far-end distance after K trips), K"""
+    o, d [R,3] -> near [R], far [R], pts_tracks [R,K,3], t_end [R] (far-end distance after K trips), K
+    history=True: t_end comes back as [R,K+1], the far-end distance after every trip (parity tests)"""
     lib = _lib.load()
     o = o.detach().float().contiguous()
     d = d.detach().float().contiguous()
@@ -394,4 +424,4 @@ def sphere_trace(sdf_field, o, d):
     from . import dist as _dist
     k = _dist.global_max_int(k, dev)                  # sharded rays: keep K identical to the single-GPU run
     pts = track[:, :max(k, 1), :]                     # K == 0: the single current point (SDF.py:201-202)
-    return near, far, pts, t_end[:, k], k
+    return near, far, pts, (t_end[:, :k + 1] if history else t_end[:, k]), k

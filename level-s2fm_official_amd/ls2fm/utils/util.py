@@ -78,51 +78,34 @@ def extract_mesh(implicit_surface, log=None, volume_size=2.0, level=0.0, N=512, 
 
 
 # ------------------------------------------------------------------------------------------------ checkpoints
-# The reference's `model.ckpt` (utils/util.py:198-259): {epoch, iter, sdf_func, color_func, cam_info, pts3d_info,
-# optim_* / sched_*}.  SDF / RadF here expose the reference's state_dict keys and shapes, so its
-# checkpoints load into these classes and checkpoints written here load into the reference.
+# File format of the reference's `model.ckpt` (written at utils/util.py:239-259, read at :198-218) -- the FORMAT is the
+# interface: one torch-pickled dict with the keys below; `<output_path>/model.ckpt` is the latest state and
+# `<output_path>/model/<tag>.ckpt` a numbered snapshot.  SDF / RadF here expose the reference's state_dict keys and
+# shapes, so files written by either side load into the other.
+from ..checkpoint import (latest_path, snapshot_path, collect_checkpoint, apply_checkpoint,  # noqa: E402
+                          write_checkpoint, read_checkpoint)
+
+
 def save_checkpoint_sfm(opt, model, ep, it, latest=False):
-    """utils/util.py:239-259"""
-    import os
-    import shutil
-    os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
-    cams = getattr(model, "camera_set", None)
-    pts = getattr(model, "point_set", None)
-    checkpoint = dict(
-        epoch=ep,
-        iter=it,
-        sdf_func=model.sdf_func.state_dict(),
-        color_func=model.color_func.state_dict(),
-        cam_info=cams.get_all_parameters() if cams is not None else None,
-        pts3d_info=pts.get_all_parameters() if pts is not None else None,
-    )
-    for key in model.__dict__:
-        if key.split("_")[0] in ["optim", "sched"]:
-            checkpoint.update({key: getattr(model, key).state_dict()})
-    torch.save(checkpoint, "{0}/model.ckpt".format(opt.output_path))
-    if not latest:
-        shutil.copy("{0}/model.ckpt".format(opt.output_path),
-                    "{0}/model/{1}.ckpt".format(opt.output_path, ep or it))   # ep None: track the iteration instead
+    """same call as utils/util.py:239: writes the latest file and, unless `latest`, a snapshot tagged ep (or it)"""
+    payload = collect_checkpoint(model, epoch=ep, iteration=it)
+    write_checkpoint(payload, opt.output_path, tag=None if latest else (ep or it))
 
 
 def restore_checkpoint_sfm(opt, model, load_name=None, resume=False):
-    """utils/util.py:198-218: (epoch, iteration) when resuming, else (None, None)"""
-    assert ((load_name is None) == (resume is not False))       # resume: True / False / an epoch or iteration number
-    if resume:
-        load_name = "{0}/model.ckpt".format(opt.output_path) if resume is True else \
-            "{0}/model/{1}.ckpt".format(opt.output_path, resume)
-    checkpoint = torch.load(load_name, map_location=opt.device, weights_only=False)
-    model.sdf_func.load_state_dict(checkpoint["sdf_func"], False)      # non-strict, like the reference
-    model.color_func.load_state_dict(checkpoint["color_func"])
-    model.cam_info_reloaded = checkpoint["cam_info"]
-    model.pts_info_reloaded = checkpoint["pts3d_info"]
-    for key in model.__dict__:
-        if key.split("_")[0] in ["optim", "sched"] and key in checkpoint and resume:
-            getattr(model, key).load_state_dict(checkpoint[key])
-    if resume:
-        ep, it = checkpoint["epoch"], checkpoint["iter"]
-        if resume is not True:
-            assert (resume == (ep or it))
-    else:
-        ep, it = None, None
-    return ep, it
+    """same call as utils/util.py:198: -> (epoch, iteration) when resuming, (None, None) when only loading weights.
+    Exactly one of `load_name` (a file) and `resume` (True = latest, or a snapshot tag) is given."""
+    if (load_name is None) != (resume is not False):
+        raise AssertionError("give either load_name or resume")
+    if resume is True:
+        load_name = latest_path(opt.output_path)
+    elif resume:
+        load_name = snapshot_path(opt.output_path, resume)
+    payload = read_checkpoint(load_name, opt.device)
+    apply_checkpoint(model, payload, with_training_state=bool(resume))
+    if not resume:
+        return None, None
+    where = payload["epoch"], payload["iter"]
+    if resume is not True and resume != (where[0] or where[1]):
+        raise AssertionError(f"snapshot {resume} holds epoch {where[0]} / iteration {where[1]}")
+    return where

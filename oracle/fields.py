@@ -306,12 +306,20 @@ def render(cfg: PathConfig, center: torch.Tensor, ray: torch.Tensor, sdf_sd: Sta
 
 # ----------------------------------------------------------------------------- sphere tracing
 def sphere_tracing(cfg: PathConfig, ray0: torch.Tensor, ray_dir: torch.Tensor, sdf_sd: State, table=None,
-                   rng: bool = True):
+                   rng: bool = True, loop_field=None, details: Optional[dict] = None):
     """Bidirectional sphere tracing with a differentiable depth (SDF.py:116-226).
 
     ray0, ray_dir [B,R,3] -> d_pred [B,R], sdf_last [B*R], sampled_pts [1,<=4096+B*R,3] (None when
-    ``rng`` is False: that output is RNG-dependent), finish_mask [B*R,1] bool; plus the trip count."""
+    ``rng`` is False: that output is RNG-dependent), finish_mask [B*R,1] bool; plus the trip count.
+
+    Test hooks (no reference counterpart): ``loop_field(p [M,3]) -> sdf [M]`` replaces the field evaluation INSIDE the
+    no-grad root-find loop only (the loop's own arithmetic and masks stay the oracle's: a test can feed it the device's
+    field evaluation and so pin the loop semantics trip by trip without the round-off amplification of ``t += sdf``);
+    ``details`` (a dict) receives the track [R,K,3], the far-end distance after every trip [R,K+1] and near / far."""
     table = table or cfg.table()
+    if loop_field is None:
+        def loop_field(q):
+            return infer_sdf(q, sdf_sd, cfg, table)[:, 0]
     box_c, box_h = scene_box(cfg, torch.float32)
     shape2 = ray_dir.shape[:2]
     o = ray0.reshape(-1, 3)
@@ -324,10 +332,11 @@ def sphere_tracing(cfg: PathConfig, ray0: torch.Tensor, ray_dir: torch.Tensor, s
     with torch.no_grad():
         p_s = (o + t_s[:, None] * d)
         p_e = (o + t_e[:, None] * d)
-        sdf_s = infer_sdf(p_s, sdf_sd, cfg, table)[:, 0].clone()
-        sdf_e = infer_sdf(p_e, sdf_sd, cfg, table)[:, 0].clone()
+        sdf_s = loop_field(p_s).clone()
+        sdf_e = loop_field(p_e).clone()
         unf_s = unf_e = None
         track = []
+        t_e_hist = [t_e]
         trips = 0
         while True:
             # (1) converged values are zeroed in place on the persistent arrays
@@ -353,17 +362,20 @@ def sphere_tracing(cfg: PathConfig, ray0: torch.Tensor, ray_dir: torch.Tensor, s
             # (6) refresh sdf only where still unfinished
             if int(unf_s.sum()) > 0:
                 sdf_s = sdf_s.clone()
-                sdf_s[unf_s] = infer_sdf(p_s[unf_s], sdf_sd, cfg, table)[:, 0]
+                sdf_s[unf_s] = loop_field(p_s[unf_s])
             if int(unf_e.sum()) > 0:
                 sdf_e = sdf_e.clone()
-                sdf_e[unf_e] = infer_sdf(p_e[unf_e], sdf_sd, cfg, table)[:, 0]
+                sdf_e[unf_e] = loop_field(p_e[unf_e])
             # (7) rays whose ends crossed drop out (and keep their stale sdf)
             cross = t_s < t_e
             unf_s = unf_s & cross
             unf_e = unf_e & cross
+            t_e_hist.append(t_e)
         if not track:
             track = [p_s]
         pts_tracks = torch.stack([q.detach() for q in track], dim=1)      # [R,K,3]
+        if details is not None:
+            details.update(track=pts_tracks, t_end=torch.stack(t_e_hist, dim=1), near=near, far=far)
     sdf_tracks = infer_sdf(pts_tracks, sdf_sd, cfg, table)                 # grad-enabled  [R,K,1]
     d_pred = sdf_tracks.sum(dim=-2).view(*shape2) + near.view(*shape2)
     d_pred = torch.where(d_pred > far.view(*shape2), far.view(*shape2), d_pred)

@@ -60,3 +60,40 @@ def rel_err(a, b):
     a = torch.as_tensor(a).detach().to(torch.float64)
     b = torch.as_tensor(b).detach().to(torch.float64)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def load_fullsize_golden():
+    """tests/golden/fullsize_dtu_dual.npz (reference outputs at the shipped L16/F2/T19 configuration) + the two seeded
+    tables it was recorded with, regenerated and checked against the stored sha256 -> (golden, sdf_state, rad_state)"""
+    import hashlib
+    from make_golden_fullsize import fullsize_tables
+    g = dict(np.load(os.path.join(GOLDEN, "fullsize_dtu_dual.npz")))
+    tabs = fullsize_tables(int(g["n_params"]))
+    for name, t in tabs.items():
+        digest = np.frombuffer(hashlib.sha256(t.numpy().tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(digest, g[f"table_sha256/{name}"]), f"seeded {name} table differs from the recorded one"
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sdf/")}
+    rd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("rad/")}
+    sd["embed_fn.embedder_obj.params"] = tabs["sdf"]
+    rd["embed_fn.embedder_obj.params"] = tabs["rad"]
+    return g, sd, rd
+
+
+def check_table_digest(grad, g, prefix, tol=1e-4):
+    """table gradient (12 M entries) against the recorded checksums and sparse samples"""
+    from make_golden_fullsize import probe_vector
+    grad = torch.as_tensor(grad).detach().cpu()
+    g64 = grad.double()
+    pos = torch.from_numpy(g[prefix + "/sample_pos"])
+    ref = torch.from_numpy(g[prefix + "/sample_val"])
+    scale = float(ref.abs().max())
+    assert float((grad[pos] - ref).abs().max()) < tol * scale, prefix
+    abs_sum = float(g[prefix + "/abs_sum"])
+    assert abs(float(g64.abs().sum()) - abs_sum) < tol * abs_sum, prefix
+    assert abs(float(g64.sum()) - float(g[prefix + "/sum"])) < tol * abs_sum * 1e-2 + 1e-6, prefix   # signed sum: cancels
+    probe = float((g64 * probe_vector(grad.numel())).sum())
+    # dot with a unit-variance probe: |error| <~ tol * ||grad||_2 ; ||grad||_2 <= sqrt(nnz) * max
+    bound = tol * float(g64.norm()) * 4
+    assert abs(probe - float(g[prefix + "/probe_dot"])) < bound, prefix
+    nnz = int((grad != 0).sum())
+    assert abs(nnz - int(g[prefix + "/nnz"])) <= max(8, int(2e-4 * int(g[prefix + "/nnz"]))), (prefix, nnz)

@@ -24,7 +24,7 @@ KEYS = ["rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"]
 
 
 def _tol(name):
-    return 5e-4 if name == "s.beta" else 1e-4
+    return 1e-4          # d beta included: failures against the fp32 composed form are re-judged against the fp64 oracle
 
 
 def oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot, pose=False):
@@ -99,7 +99,9 @@ def one_case(case, rng, skip=False):
         for k, _ in bad:
             ef, ec = rel_err(res["fused"][1][k], o64[k]), rel_err(res["composed"][1][k], o64[k])
             judged += f" [{k}: fused vs fp64 oracle {ef:.1e}, composed vs fp64 oracle {ec:.1e}]"
-            if not ef < max(_tol(k), 2.0 * ec):      # as good as fp32 autograd on an ill-conditioned sum is good enough
+            # as good as fp32 autograd on an ill-conditioned sum is good enough -- except d beta, which the kernel sums in
+            # fp64 and which is held to the bar against the true (fp64) value outright
+            if not ef < (_tol(k) if k == "s.beta" else max(_tol(k), 2.0 * ec)):
                 still.append((k, ef))
         bad = still
     tag = (f"case {case}: {ds} dual={dual} rays={n_rays} N={n_samples} L={L} T=2^{log2_T} base={base} pose={pose} "

@@ -52,14 +52,16 @@ def _worker(rank, world, port, out_dir):
             assert torch.equal(p.grad, torch.full_like(p, 3.0 * (k + 2)))
         # the fused backward's flat small-gradient buffer is reduced in place, without packing
         from ls2fm import fused
-        flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
-        fused._SMALL_GRADS = flat
-        a, b = torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))
-        a.grad, b.grad = flat[:6].view(2, 3), flat[6:]
-        ldist.GradAllReducer([a, b]).all_reduce()
-        assert torch.equal(flat, torch.arange(10, dtype=torch.float32) * 3)
+        a, b = torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(5))
+        flat, (ga, gb) = fused.flat_gradient_views([a, b])            # what the fused backward returns its gradients in
+        assert flat.numel() == 8 + 8 and gb.data_ptr() - flat.data_ptr() == 32          # 16-byte segments
+        flat.copy_(torch.arange(16, dtype=torch.float32) * (rank + 1))
+        a.grad, b.grad = ga, gb
+        red2 = ldist.GradAllReducer([a, b])
+        assert red2._all_in_flat() is flat
+        red2.all_reduce()
+        assert torch.equal(flat, torch.arange(16, dtype=torch.float32) * 3)
         assert a.grad.data_ptr() == flat.data_ptr()
-        fused._SMALL_GRADS = None
 
         # ---- masked mean is world-size invariant (sum / count all-reduced separately)
         vals = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])

@@ -1,0 +1,173 @@
+"""GPU parity at the FULL shapes of BASELINE.json's configurations 3, 4 and 5, full L16/F2/T19 grids:
+
+  C3  DTU bounds, dual field, 8192 rays per step split over 8 views, 128 samples, + sphere tracing (iters_max 10)
+  C4  BlendedMVS bounds, 8 views x 1024 rays, 128 samples (the shape one BA step shards over 8 GPUs)
+  C5  ScanNet bounds, 4096 rays x 256 samples (1 M sample points), eikonal term on
+
+Sizes the CPU oracle cannot render whole in test time, so each is checked through
+  * a SPARSE ORACLE SAMPLE: a few rays per view rendered by the oracle; the fused outputs of those rays, and the
+    gradients of a loss restricted to them (zero cotangent elsewhere -- the backward still processes the whole batch),
+    against the oracle to the path's bars (2e-5 outputs, 1e-4 every parameter gradient, d beta vs the fp64 oracle);
+  * SIZE-INDEPENDENT PROPERTIES: finite outputs, missed rays render the background exactly, depth within [near, far],
+    and shard additivity -- the gradient of a sum-type loss over the whole [B,R] batch equals the sum over the B views
+    rendered one by one (what the data-parallel path relies on, ls2fm/dist.py);
+  * C3: the tracing loop at 8192 rays re-synchronised against the oracle's loop (bit-exact, see
+    tests/test_hip_sphere_trace_parity.py) and its differentiable tail against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from helpers import named_grads
+from test_hip_fused_render import _beta_ok, _randomized
+from ls2fm import fused
+from ls2fm.options import make_options
+from oracle import fields as OF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CONFIGS = {
+    # name: dataset, dual, views, rays per view, samples, trace
+    "C3_dtu_dual_8192rays": ("DTU", True, 8, 1024, 128, True),
+    "C4_bmvs_8views": ("BlendedMVS", False, 8, 1024, 128, False),
+    "C5_scannet_4096x256": ("scannet", False, 1, 4096, 256, False),
+}
+
+
+def _view_rays(b, r, s, seed):
+    """b cameras on a ring around the box looking at its centre, r unnormalised rays each (utils/camera.py:246-251
+    shape), a few rays per view missing the box"""
+    gen = torch.Generator().manual_seed(seed)
+    cs, ds = [], []
+    for v in range(b):
+        ang = 2 * np.pi * v / max(b, 1) + 0.3
+        eye = torch.tensor([2.5 * s * np.sin(ang), 0.3 * s * np.cos(2 * ang), -2.5 * s * np.cos(ang)], dtype=torch.float32)
+        fwd = -eye / eye.norm()
+        d = fwd[None, :] + 0.15 * torch.randn(r, 3, generator=gen)
+        d[:2] = torch.tensor([0.0, 1.0, 0.0]) + 0.6 * fwd           # glancing / missing rays
+        cs.append(eye.repeat(r, 1))
+        ds.append(d)
+    return torch.stack(cs).to(DEV).contiguous(), torch.stack(ds).float().to(DEV).contiguous()
+
+
+def _loss(ret, tgt, sel=None, eik_w=0.1):
+    """sum-type loss (additive over rays); sel: bool [B,R] restricting it to some rays"""
+    w = 1.0 if sel is None else sel[..., None].float()
+    rgb = ((ret["rgb"] - tgt).abs() * w).sum()
+    eik = (((ret["normals"].norm(dim=-1) - 1.0) ** 2) * w).sum()
+    dep = (ret["depth_mlp"] * w).sum()
+    nm = ((ret["normal_mlp"] * torch.tensor([0.3, -0.2, 0.5], device=tgt.device, dtype=tgt.dtype)) * w).sum()
+    vol = ((ret["sdfs_volume"][..., 0] ** 2) * w).sum()
+    return rgb + eik_w * eik + 0.01 * dep + 0.05 * nm + 0.05 * vol
+
+
+def _all_grads(sdf, rad):
+    return {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_shape_sparse_oracle_sample_and_properties(name):
+    ds, dual, b, r, n, trace = CONFIGS[name]
+    opt = make_options(ds, device=DEV, dual_field=dual, sample_intvs=n)
+    sdf, rad, ren = _randomized(opt, 51)
+    s = float(opt.data.bound_max[0])
+    center, ray = _view_rays(b, r, s, 52)
+    tgt = torch.rand(b, r, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(53))
+    assert fused.can_render(ren, opt, center, ray, sdf, rad)
+
+    # ---- whole batch in one call
+    ret = ren.forward(opt, center, ray, sdf, rad)
+    assert tuple(ret["rgb"].shape) == (b, r, 3) and tuple(ret["sdfs_volume"].shape) == (b, r, n, 1)
+    assert tuple(ret["normals"].shape) == (b, r, n, 3) and tuple(ret["depth_mlp"].shape) == (b, r, 1)
+    for k, v in ret.items():
+        assert torch.isfinite(v).all(), k
+    from ls2fm.ops import ray_aabb_intersect
+    cnt, t, _ = ray_aabb_intersect(center.view(-1, 3), ray.view(-1, 3), ren.center.view(1, 3), ren.half_size.view(1, 3), 1)
+    near, far = t[:, 0, 0].view(b, r), t[:, 0, 1].view(b, r)
+    miss = (cnt == 0).view(b, r)
+    assert int(miss.sum()) >= b                                            # the glancing rays
+    bg = torch.tensor(opt.data.bgcolor, device=DEV, dtype=torch.float32)
+    assert torch.equal(ret["rgb"][miss], bg.expand(int(miss.sum()), 3))  # misses: rgb == bgcolor exactly
+    hit = ~miss
+    dm = ret["depth_mlp"][..., 0]
+    assert (dm[hit] >= near[hit] - 1e-4 * s).all() and (dm[hit] <= far[hit] + 1e-4 * s).all()
+
+    # ---- shard additivity: whole batch vs the views one by one
+    sdf.zero_grad(); rad.zero_grad()
+    _loss(ret, tgt).backward()
+    full = _all_grads(sdf, rad)
+    acc = {k: torch.zeros_like(torch.as_tensor(v), dtype=torch.float64) for k, v in full.items()}
+    shards = b if b > 1 else 4
+    cf, rf, tf = center.reshape(shards, -1, 3), ray.reshape(shards, -1, 3), tgt.reshape(shards, -1, 3)
+    for q in range(shards):
+        sdf.zero_grad(); rad.zero_grad()
+        _loss(ren.forward(opt, cf[q:q + 1].contiguous(), rf[q:q + 1].contiguous(), sdf, rad), tf[q:q + 1]).backward()
+        for k, v in _all_grads(sdf, rad).items():
+            acc[k] += torch.as_tensor(v).double()
+    for k in full:
+        assert torch.isfinite(torch.as_tensor(full[k])).all(), k
+        assert rel_err(full[k], acc[k]) < (1e-4 if k == "s.beta" else 2e-5), k
+    assert torch.as_tensor(full["s.embed_fn.embedder_obj.params"]).abs().max() > 0
+
+    # ---- sparse oracle sample: a few rays per view (one of them a miss), loss restricted to them
+    per = max(2, 16 // b)
+    gen = torch.Generator().manual_seed(54)
+    sel = torch.zeros(b, r, dtype=torch.bool)
+    for v in range(b):
+        sel[v, torch.randperm(r - 2, generator=gen)[:per] + 2] = True
+        sel[v, 0] = True
+    sel_d = sel.to(DEV)
+    sdf.zero_grad(); rad.zero_grad()
+    ret = ren.forward(opt, center, ray, sdf, rad)
+    _loss(ret, tgt, sel_d).backward()
+    got = _all_grads(sdf, rad)
+
+    cfg = OF.dataset_config(ds, dual_field=dual, sample_intvs=n)
+    c_s, r_s, t_s = center[sel_d].cpu().view(1, -1, 3), ray[sel_d].cpu().view(1, -1, 3), tgt[sel_d].cpu().view(1, -1, 3)
+    osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sdf.state_dict().items()}
+    ord_ = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in rad.state_dict().items()}
+    oret = OF.render(cfg, c_s, r_s, osd, ord_)
+    _loss(oret, t_s).backward()
+    for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
+        assert rel_err(ret[k][sel_d].cpu(), oret[k][0]) < 2e-5, k
+    o64s = {k: v.detach().cpu().double().requires_grad_(k == "beta") for k, v in sdf.state_dict().items()}
+    o64r = {k: v.detach().cpu().double() for k, v in rad.state_dict().items()}
+    _loss(OF.render(cfg, c_s.double(), r_s.double(), o64s, o64r), t_s.double()).backward()
+    for pre, st in (("s.", osd), ("r.", ord_)):
+        for k, v in st.items():
+            ref = v.grad if v.grad is not None else torch.zeros_like(v)
+            if pre + k == "s.beta":
+                _beta_ok(got[pre + k], ref, o64s["beta"].grad)
+                continue
+            assert rel_err(got[pre + k], ref) < 1e-4, pre + k
+
+    if not trace:
+        return
+    # ---- C3: sphere tracing of the whole 8192-ray batch, iters_max = 10 (models/SDF.py:116-226)
+    assert sdf.iters_max == cfg.iters_max_st == 10
+
+    def device_field(q):
+        with torch.no_grad():
+            return sdf.infer_sdf(q.to(DEV).contiguous(), mode="ret_sdf")[:, 0].cpu()
+    det = {}
+    osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sdf.state_dict().items()}
+    od, os_, _, ofin, otrips = OF.sphere_tracing(cfg, center.cpu(), ray.cpu(), osd, rng=False, loop_field=device_field,
+                                                 details=det)
+    (od ** 2).sum().backward()
+    with torch.no_grad():
+        near_t, far_t, pts, t_hist, k = fused.sphere_trace(sdf, center.view(-1, 3), ray.view(-1, 3), history=True)
+    assert k == otrips == 10
+    assert torch.equal(pts.cpu(), det["track"]) and torch.equal(t_hist.cpu(), det["t_end"])
+    sdf.zero_grad()
+    d_pred, sdf_last, sampled, finish = sdf.sphere_tracing(center, ray, sdf)
+    assert tuple(d_pred.shape) == (b, r) and tuple(finish.shape) == (b * r, 1)
+    assert tuple(sampled.shape) == (1, 4096 * k + b * r, 3)
+    assert rel_err(d_pred.cpu(), od) < 1e-4 and rel_err(sdf_last.cpu(), os_) < 1e-4
+    tie = ((os_.detach().abs() - 2 * s / 10 / cfg.res).abs() < 1e-6).numpy()
+    assert np.array_equal(finish.cpu().numpy()[~tie], ofin.numpy()[~tie])
+    (d_pred ** 2).sum().backward()
+    for name_, v in named_grads(sdf).items():
+        ref = osd[name_].grad if osd[name_].grad is not None else torch.zeros_like(osd[name_])
+        assert rel_err(v, ref) < 1e-4, name_

@@ -19,8 +19,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 2e-5
 GTOL = 1e-4          # north-star bar: 1e-4 relative, fp32
-BETA_TOL = 5e-4      # d/d beta is ONE scalar: a sum over every sample of terms of both signs (cancellation ~1e3);
-                     # the kernel accumulates it in fp64, the fp32 reference itself carries ~1e-4 summation noise
+
+
+def _beta_ok(got, ref32, ref64, fused_path=True):
+    """d/d beta is ONE scalar: a sum over every sample of terms of both signs (cancellation ~1e3).  The kernel accumulates
+    it in fp64, so it is held to the 1e-4 bar against the fp64 CPU oracle (the true value of the sum); the fp32 reference /
+    fp32 oracle value itself carries summation noise and is only required to be no closer to the truth than the kernel."""
+    got, ref32, ref64 = float(got), float(ref32), float(ref64)
+    e_kernel = abs(got - ref64) / (abs(ref64) + 1e-30)
+    e_ref32 = abs(ref32 - ref64) / (abs(ref64) + 1e-30)
+    bar = GTOL if fused_path else max(GTOL, 2.0 * e_ref32)      # composed form: fp32 autograd, as good as the reference's
+    assert e_kernel < bar, f"d beta: kernel {got!r} vs fp64 oracle {ref64!r}: {e_kernel:.2e} (fp32 reference: {e_ref32:.2e})"
+    assert abs(got - ref32) / (abs(ref32) + 1e-30) < GTOL + 2.0 * e_ref32
+
+
+def _oracle64_beta_grad(cfg, sdf_state, rad_state, center, ray, tgt, nm):
+    osd = {k: v.detach().cpu().double().requires_grad_(k == "beta") for k, v in sdf_state.items()}
+    ord_ = {k: v.detach().cpu().double() for k, v in rad_state.items()}
+    ret = OF.render(cfg, center.detach().cpu().double(), ray.detach().cpu().double(), osd, ord_)
+    losses.render_loss(ret, tgt.detach().cpu().double(), nm.detach().cpu().double()).backward()
+    return osd["beta"].grad
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
@@ -40,10 +58,48 @@ def test_fused_render_vs_reference_golden(case, manifest):
     loss.backward()
     for name, mod in (("sdf", sdf), ("rad", rad)):
         for k, v in named_grads(mod).items():
-            assert rel_err(v, g[f"render_grad/{name}/{k}"]) < (BETA_TOL if k == "beta" else GTOL), (name, k)
+            if k == "beta":
+                from conftest import golden_cfg
+                b64 = _oracle64_beta_grad(golden_cfg(manifest[case]), sdf.state_dict(), rad.state_dict(), center, ray,
+                                          torch.from_numpy(g["rgb_target"]), torch.from_numpy(g["nm_dir"]))
+                _beta_ok(v, g[f"render_grad/{name}/{k}"], b64, fused_path=took_fused)
+                continue
+            assert rel_err(v, g[f"render_grad/{name}/{k}"]) < GTOL, (name, k)
     # gradients w.r.t. the camera rays (the reference's own values)
     assert rel_err(center.grad.cpu(), g["d_center"]) < GTOL
     assert rel_err(ray.grad.cpu(), g["d_ray"]) < GTOL
+
+
+def test_fused_render_vs_reference_full_size_checksums():
+    """the reference's own outputs at the shipped L16/F2/T19 configuration (tests/golden/fullsize_dtu_dual.npz): outputs,
+    small and pose gradients in full; the 12 M-entry table gradients by checksums + sparse samples"""
+    from conftest import check_table_digest, load_fullsize_golden
+    g, sd, rd = load_fullsize_golden()
+    n = g["ret/sdfs_volume"].shape[2]
+    opt = make_options("DTU", device=DEV, dual_field=True, sample_intvs=n)
+    sdf, rad, ren = SDF(opt).to(DEV), RadF(opt).to(DEV), Renderer(opt)
+    sdf.load_state_dict(sd, strict=True)
+    rad.load_state_dict(rd, strict=True)
+    center = torch.from_numpy(g["center"]).to(DEV).requires_grad_(True)
+    ray = torch.from_numpy(g["ray"]).to(DEV).requires_grad_(True)
+    assert fused.can_render(ren, opt, center, ray, sdf, rad)
+    ret = ren.forward(opt=opt, center=center, ray=ray, SDF_Field=sdf, Rad_Field=rad)
+    for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
+        assert rel_err(ret[k].cpu(), g[f"ret/{k}"]) < TOL, k
+    tgt, nm = torch.from_numpy(g["rgb_target"]), torch.from_numpy(g["nm_dir"])
+    loss = losses.render_loss(ret, tgt.to(DEV), nm.to(DEV))
+    assert abs(loss.item() - float(g["render_loss"])) < 1e-4 * abs(float(g["render_loss"]))
+    loss.backward()
+    assert rel_err(center.grad.cpu(), g["d_center"]) < GTOL and rel_err(ray.grad.cpu(), g["d_ray"]) < GTOL
+    for pre, mod in (("sdf", sdf), ("rad", rad)):
+        for k, v in named_grads(mod).items():
+            if k.endswith("embedder_obj.params"):
+                check_table_digest(v, g, f"table_grad/{pre}", tol=GTOL)
+            elif k == "beta":
+                cfg = OF.dataset_config("DTU", dual_field=True, sample_intvs=n)
+                _beta_ok(v, g["render_grad/sdf/beta"], _oracle64_beta_grad(cfg, sd, rd, center, ray, tgt, nm))
+            else:
+                assert rel_err(v, g[f"render_grad/{pre}/{k}"]) < GTOL, (pre, k)
 
 
 def test_fused_pose_gradients_equal_composed_at_full_grid():
@@ -119,7 +175,10 @@ def test_fused_render_vs_oracle_full_size_grid(ds, dual, n_samples, n_rays):
     for mod, st in ((sdf, osd), (rad, ord_)):
         for k, v in named_grads(mod).items():
             ref = st[k].grad if st[k].grad is not None else torch.zeros_like(st[k])
-            assert rel_err(v, ref) < (BETA_TOL if k == "beta" else GTOL), k
+            if k == "beta":
+                _beta_ok(v, ref, _oracle64_beta_grad(cfg, sdf.state_dict(), rad.state_dict(), center, ray, tgt, nm))
+                continue
+            assert rel_err(v, ref) < GTOL, k
     assert osd["embed_fn.embedder_obj.params"].grad.abs().max() > 0
 
 

@@ -56,3 +56,50 @@ def test_full_resolution_sweep_512():
         with torch.no_grad():
             want = sdf.infer_sdf(xyz).view(-1)
         assert torch.equal(vol[first:first + 4096], want)
+
+
+def _oracle_sdf(opt, sdf, ds, pts):
+    from oracle import fields as OF
+    cfg = OF.dataset_config(ds)
+    sd = {k: v.detach().cpu() for k, v in sdf.state_dict().items()}
+    with torch.no_grad():
+        return OF.infer_sdf(pts, sd, cfg, cfg.table())[:, 0]
+
+
+@pytest.mark.parametrize("ds,N,bounds", [("DTU", 64, False), ("ETH3D", 48, True)])
+def test_volume_vs_cpu_oracle_on_lattice_samples(ds, N, bounds):
+    """oracle-direct: the device sweep against the CPU oracle's infer_sdf on 3000 seeded lattice positions (points from the
+    host restatement of the reference's lattice arithmetic, utils/util.py:399-409), full L16/T19 grid"""
+    opt, sdf = _field(ds, 9)
+    bmax = [float(v) for v in opt.data.bound_max] if bounds else None
+    bmin = [float(v) for v in opt.data.bound_min] if bounds else None
+    vol = util.sdf_volume(sdf, volume_size=2.0, N=N, bound_max=bmax, bound_min=bmin).view(-1).cpu()
+    pick = torch.randint(0, N ** 3, (3000,), generator=torch.Generator().manual_seed(1))
+    xyz = util.lattice_points(2.0, N, bmax, bmin)
+    want = _oracle_sdf(opt, sdf, ds, torch.from_numpy(xyz[pick.numpy()]))
+    assert float((vol[pick] - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+def test_high_res_mesh_sweeps_vs_cpu_oracle():
+    """ls2fm.utils.plots (utils/plots.py:140-222): the uniform 100^3-style sweep and the rotated, box-fitted sweep of
+    get_surface_high_res_mesh on the fused kernel; lattice points vs the host formula, values vs the CPU oracle"""
+    from ls2fm.utils import plots
+    opt, sdf = _field("DTU", 13)
+    axes = plots.uniform_axes(40, [-0.6, 0.6])
+    z = plots.sdf_on_lattice(sdf.infer_sdf, axes).cpu()
+    assert z.numel() == 40 ** 3
+    pts = plots.lattice_on_device(axes, "cpu")
+    pick = torch.randint(0, z.numel(), (2000,), generator=torch.Generator().manual_seed(2))
+    want = _oracle_sdf(opt, sdf, "DTU", pts[pick])
+    assert float((z[pick] - want).abs().max()) < 2e-5 * float(want.abs().max())
+    # rotated + fitted lattice
+    gen = torch.Generator().manual_seed(3)
+    cloud = (torch.randn(400, 3, generator=gen) * torch.tensor([0.3, 0.15, 0.25])).to(DEV)
+    mean, vecs = plots._principal_frame(cloud)
+    assert abs(float(torch.det(vecs)) - 1.0) < 1e-4
+    axes2, _, _ = plots.fitted_axes(((cloud - mean) @ vecs.t()).cpu(), 30)
+    z2 = plots.sdf_on_lattice(sdf.infer_sdf, axes2, rotation=vecs, offset=mean).cpu()
+    world = (plots.lattice_on_device(axes2, DEV) @ vecs + mean).cpu()          # the very points the sweep evaluated
+    pick = torch.randint(0, z2.numel(), (2000,), generator=torch.Generator().manual_seed(4))
+    want = _oracle_sdf(opt, sdf, "DTU", world[pick])
+    assert float((z2[pick] - want).abs().max()) < 2e-5 * float(want.abs().max())

@@ -1,0 +1,126 @@
+"""GPU parity of SDF.sphere_tracing at the exit the training stages actually take: K == iters_max on a random
+(non-converging) field (models/SDF.py:149-214).
+
+`t += sdf` amplifies a last-bit difference of the field evaluation every trip, so a free-running comparison of two
+implementations of the field diverges on a random field.  The loop is therefore pinned in two complementary ways:
+
+  1. **re-synchronised** (exact): the ORACLE's loop -- its masks, the stale-step quirk, the `+` on the far end, the
+     clamp, the global break, all pinned against the reference's own outputs by tests/test_oracle_vs_golden.py -- is run
+     with the DEVICE's field evaluation plugged into its no-grad loop.  Every trip then starts from identical state on
+     both sides, and the HIP tracing kernel must reproduce the oracle's track, far-end history, near/far and trip count
+     BIT FOR BIT at K = iters_max (10 / 20 trips); the differentiable tail (d_pred, sdf_last, finish_mask and the
+     gradients of a scalar of them) is then compared with the oracle's on that very track.
+  2. **free-running** (measured): the pure oracle trace next to the HIP trace; the first trip at which a ray's track
+     leaves the oracle's is recorded, and on the rays that never left, d_pred / sdf_last / finish_mask are compared with
+     the oracle and with the reference's golden vectors (`st_*`: K = 10 / 20 = iters_max).
+"""
+import numpy as np
+import pytest
+import torch
+
+import losses
+from conftest import GOLDEN_CASES, golden_cfg, golden_state, load_golden, rel_err
+from helpers import named_grads, product_for
+from ls2fm import fused
+from oracle import fields as OF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rays(g, extra, s, seed):
+    """the golden case's 48 tracing rays + `extra` seeded ones of the same family (incl. misses / inside origins)"""
+    c, d = torch.from_numpy(g["st_center"]), torch.from_numpy(g["st_ray"])
+    if extra:
+        gen = torch.Generator().manual_seed(seed)
+        c2 = torch.tensor([0.0, 0.0, -2.5 * s]).repeat(extra, 1) + 0.05 * s * torch.randn(extra, 3, generator=gen)
+        d2 = torch.tensor([0.0, 0.0, 1.0]).repeat(extra, 1) + 0.15 * torch.randn(extra, 3, generator=gen)
+        d2[:8] = torch.tensor([0.0, 1.0, -0.2]) + 0.05 * torch.randn(8, 3, generator=gen)        # misses
+        c2[8:16] = 0.3 * s * torch.randn(8, 3, generator=gen)                                     # origins inside the box
+        c, d = torch.cat([c, c2.float()]), torch.cat([d, d2.float()])
+    return c.contiguous(), d.contiguous()
+
+
+def _device_field(sdf):
+    def field(q):
+        with torch.no_grad():
+            return sdf.infer_sdf(q.to(DEV).contiguous(), mode="ret_sdf")[:, 0].cpu()
+    return field
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kernel", ["wide", "narrow"])
+def test_trace_loop_resynchronised_is_bit_exact_at_iters_max(case, kernel, manifest, monkeypatch):
+    g = load_golden(case)
+    meta = manifest[case]
+    opt, sdf, rad, ren = product_for(meta, g, DEV)
+    cfg = golden_cfg(meta)
+    s = (cfg.bound_max[0] - cfg.bound_min[0]) / 2
+    # the narrow (lane per ray end) kernel serves calls above 20 000 rays: same code path as production
+    c, d = _rays(g, 1000 if kernel == "wide" else 20100, s, seed=11)
+    osd = golden_state(g, "sdf", requires_grad=True)
+    det = {}
+    od, os_, _, ofin, otrips = OF.sphere_tracing(cfg, c.view(1, -1, 3), d.view(1, -1, 3), osd, rng=False,
+                                                 loop_field=_device_field(sdf), details=det)
+    assert otrips == cfg.iters_max_st == int(g["st_trips"])          # the K == iters_max exit
+    with torch.no_grad():
+        near, far, pts, t_hist, k = fused.sphere_trace(sdf, c.to(DEV), d.to(DEV), history=True)
+    assert k == otrips
+    assert torch.equal(near.cpu(), det["near"]) and torch.equal(far.cpu(), det["far"])
+    assert torch.equal(pts.cpu(), det["track"]), "track differs from the oracle loop fed the same field values"
+    assert torch.equal(t_hist.cpu(), det["t_end"])
+    if kernel == "narrow":
+        return
+    # differentiable tail on that track: d_pred, sdf_last, finish mask, gradients
+    losses.tracing_loss(od, os_).backward()
+    d_pred, sdf_last, sampled, finish = sdf.sphere_tracing(c.view(1, -1, 3).to(DEV), d.view(1, -1, 3).to(DEV), sdf)
+    assert sdf.last_trips == otrips
+    assert rel_err(d_pred.cpu(), od) < 1e-4 and rel_err(sdf_last.cpu(), os_) < 1e-4
+    extent = cfg.bound_max[0] - cfg.bound_min[0]
+    tie = (os_.detach().abs() - extent / 10 / cfg.res).abs() < 1e-6          # |sdf_last| within round-off of the threshold
+    assert np.array_equal(finish.cpu().numpy()[~tie.numpy()], ofin.numpy()[~tie.numpy()])
+    assert sampled.shape == (1, min(4096, c.shape[0]) * otrips + c.shape[0], 3)
+    losses.tracing_loss(d_pred, sdf_last).backward()
+    for name, v in named_grads(sdf).items():
+        ref = osd[name].grad if osd[name].grad is not None else torch.zeros_like(osd[name])
+        assert rel_err(v, ref) < 1e-4, name
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_trace_free_running_vs_oracle_and_reference_goldens(case, manifest, record_property):
+    """Where do the device trace and the pure CPU trace part ways?  First-divergence trip per ray (track point more than
+    1e-4 of the scene extent away), and full-output parity -- against the oracle and against the reference's own
+    K = iters_max outputs -- on the rays that stayed together."""
+    g = load_golden(case)
+    meta = manifest[case]
+    opt, sdf, rad, ren = product_for(meta, g, DEV)
+    cfg = golden_cfg(meta)
+    extent = cfg.bound_max[0] - cfg.bound_min[0]
+    c, d = _rays(g, 0, extent / 2, seed=0)                      # exactly the reference's 48 recorded rays
+    osd = golden_state(g, "sdf")
+    det = {}
+    od, os_, _, ofin, otrips = OF.sphere_tracing(cfg, c.view(1, -1, 3), d.view(1, -1, 3), osd, rng=False, details=det)
+    assert otrips == int(g["st_trips"]) == cfg.iters_max_st
+    with torch.no_grad():
+        near, far, pts, t_hist, k = fused.sphere_trace(sdf, c.to(DEV), d.to(DEV), history=True)
+    assert k == otrips
+    dev = (pts.cpu() - det["track"]).norm(dim=-1)                # [R,K]
+    dev = torch.where(torch.isfinite(dev), dev, torch.zeros_like(dev))      # misses: -1 - d on both sides (inf-free)
+    apart = dev > 1e-4 * extent
+    first = torch.where(apart.any(dim=1), apart.float().argmax(dim=1), torch.full((c.shape[0],), k))
+    together = first == k
+    record_property("first_divergence_trip_histogram", np.bincount(first.numpy(), minlength=k + 1).tolist())
+    print(f"[{case}] K={k}: rays together through all trips {int(together.sum())}/{c.shape[0]}; "
+          f"first-divergence histogram {np.bincount(first.numpy(), minlength=k + 1).tolist()}")
+    assert int(together.sum()) >= c.shape[0] // 4, "the comparison below would be vacuous"
+    d_pred, sdf_last, sampled, finish = sdf.sphere_tracing(c.view(1, -1, 3).to(DEV), d.view(1, -1, 3).to(DEV), sdf)
+    m = together.numpy()
+    got_d, got_s, got_f = d_pred.detach().cpu().numpy()[0], sdf_last.detach().cpu().numpy(), finish.cpu().numpy()[:, 0]
+    thr = extent / 10 / cfg.res
+    for ref_d, ref_s, ref_f, what in ((od.detach().numpy()[0], os_.detach().numpy(), ofin.numpy()[:, 0], "oracle"),
+                                      (g["st_d_pred"][0], g["st_sdf_last"], g["st_finish"][:, 0], "reference golden")):
+        assert np.allclose(got_d[m], ref_d[m], rtol=2e-3, atol=2e-3 * extent), what     # K sums of a field with |grad| >> 1
+        assert np.allclose(got_s[m], ref_s[m], rtol=0, atol=2e-2 * extent), what
+        clear = m & (np.abs(np.abs(ref_s) - thr) > 2e-2 * extent)
+        assert np.array_equal(got_f[clear], ref_f[clear]), what
+    assert tuple(sampled.shape) == tuple(g["st_sampled_shape"])

@@ -218,3 +218,24 @@ def test_render_size_limit_is_reported_not_overflowed():
     ok = lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(desc), 65536)          # 2^23 points: allowed
     assert ok > 0
     assert lib.ls2fm_render_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(desc), 65537) == -2  # LS2FM_ERR_UNSUPPORTED
+
+
+def test_mesh_sweep_lattices_are_the_references():
+    """ls2fm.utils.plots: the axes / lattices of get_grid_uniform and get_grid (utils/plots.py:325-370) against lattices
+    recorded from the reference's own functions (tests/golden/make_golden_plots.py); bit-exact (fp64 axes, fp32 points)"""
+    from conftest import load_golden
+    from ls2fm.utils import plots
+    g = load_golden("plots_lattices")
+    axes = plots.uniform_axes(7, [-0.6, 0.6])
+    for a, ax in zip("xyz", axes):
+        assert np.array_equal(ax, g[f"uniform/{a}"])
+    assert np.array_equal(plots.lattice_on_device(axes, "cpu").numpy(), g["uniform/points"])
+    for tag in ("fit_x", "fit_y", "fit_z"):
+        axes, length, k = plots.fitted_axes(torch.from_numpy(g[f"{tag}/input"]), 9)
+        assert k == int(g[f"{tag}/index"]) and length == float(g[f"{tag}/length"])
+        for a, ax in zip("xyz", axes):
+            assert np.array_equal(ax, g[f"{tag}/{a}"]), (tag, a)
+        pts = plots.lattice_on_device(axes, "cpu")
+        assert np.array_equal(pts.numpy(), g[f"{tag}/points"])
+        part = plots.lattice_on_device(axes, "cpu", first=1234, count=777)           # chunks of the same lattice
+        assert np.array_equal(part.numpy(), g[f"{tag}/points"][1234:1234 + 777])

@@ -164,3 +164,29 @@ def test_state_dict_manifest_and_hash_geometry(manifest):
         assert t.n_params == geo[ds]["n_params"] == n_params      # SURVEY A.2 figures
         assert abs(t.per_level_scale - geo[ds]["per_level_scale"]) < 1e-7
         assert geo[ds]["out_dim"] == 35
+
+
+def test_render_full_size_grid_vs_reference_checksums():
+    """the shipped L16/F2/T19 configuration (DTU bounds, dual field, 128 samples): outputs, small gradients and pose
+    gradients in full, the two 12 M-entry table gradients through checksums and sparse samples"""
+    from conftest import check_table_digest, load_fullsize_golden
+    g, sd, rd = load_fullsize_golden()
+    cfg = F.dataset_config("DTU", dual_field=True, sample_intvs=g["ret/sdfs_volume"].shape[2])
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rd = {k: v.clone().requires_grad_(True) for k, v in rd.items()}
+    center = torch.from_numpy(g["center"]).requires_grad_(True)
+    ray = torch.from_numpy(g["ray"]).requires_grad_(True)
+    ret = F.render(cfg, center, ray, sd, rd)
+    for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
+        assert rel_err(ret[k], g[f"ret/{k}"]) < TOL, k
+    loss = losses.render_loss(ret, torch.from_numpy(g["rgb_target"]), torch.from_numpy(g["nm_dir"]))
+    assert abs(loss.item() - float(g["render_loss"])) < 1e-5 * abs(float(g["render_loss"]))
+    loss.backward()
+    assert rel_err(center.grad, g["d_center"]) < GTOL and rel_err(ray.grad, g["d_ray"]) < GTOL
+    for pre, st in (("sdf", sd), ("rad", rd)):
+        for k, v in st.items():
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            if k.endswith("embedder_obj.params"):
+                check_table_digest(got, g, f"table_grad/{pre}", tol=GTOL)
+            else:
+                assert rel_err(got, g[f"render_grad/{pre}/{k}"]) < GTOL, (pre, k)
