@@ -294,14 +294,51 @@ def render(cfg: PathConfig, center: torch.Tensor, ray: torch.Tensor, sdf_sd: Sta
     else:
         geo = feats[..., 1:]
     rgbs = radiance_mlp(torch.cat([p, normals, ray_enc, geo], dim=-1), rad_sd)
+    return render_tail(cfg, ray, t, sdfs, normals, rgbs, alpha, beta)
+
+
+def render_tail(cfg: PathConfig, ray, t, sdfs, normals, rgbs, alpha, beta) -> Dict[str, torch.Tensor]:
+    """the part of Renderer.forward after the per-sample field evaluations: sigma, composite, background / depth / normal
+    epilogue (Renderer.py:80-107)"""
     sigma = sdf_to_sigma(sdfs, alpha, beta)
     rgb, prob = composite(ray, rgbs, sigma.squeeze(-1), t)
     opacity = prob.sum(dim=2)
-    bg = torch.tensor(cfg.bgcolor, dtype=dtype)
+    bg = torch.tensor(cfg.bgcolor, dtype=sdfs.dtype)
     rgb = rgb + (1 - opacity) * bg
     depth = (t[..., :-1, :] * prob).sum(dim=2) + (1 - opacity) * t[..., -1, :]
     normal = (normals[..., :-1, :] * prob).sum(dim=2) + (1 - opacity) * normals[..., -1, :]
     return {"rgb": rgb, "sdfs_volume": sdfs, "normals": normals, "depth_mlp": depth, "normal_mlp": normal}
+
+
+def beta_gradient_exact_sum(cfg: PathConfig, center, ray, sdf_sd: State, rad_sd: State, loss_fn) -> torch.Tensor:
+    """d loss / d beta of the FLOAT32 computation with the ill-conditioned part done exactly (test adjudication; no reference
+    counterpart).  d/d beta is one scalar summing terms of both signs over every sample (cancellation ~1e3), so an fp32
+    autograd value -- the reference's included -- carries summation noise of ~1e-4.  Running the whole oracle in fp64 does
+    not give "the true value" of what the fp32 path computes either: the hash-grid weights frac(scale * x + 0.5) lose up to
+    ~5e-4 absolute at the finest levels in fp32, so the fp64 FIELD is a slightly different field.  Here the per-sample field
+    outputs (sdf, normal, colour: what beta does not touch) are evaluated in fp32 exactly as the path does, and everything
+    beta enters -- sigma, composite, epilogue, loss -- is then carried out in fp64 on those values."""
+    table = cfg.table()
+    with torch.no_grad():
+        box_c, box_h = scene_box(cfg, torch.float32)
+        near, far = ray_aabb.near_far(center.reshape(-1, 3), ray.reshape(-1, 3), box_c, box_h)
+        near = near.view(*center.shape[:2], 1)
+        far = far.view(*center.shape[:2], 1)
+        t = sample_depth(cfg.sample_intvs, near, far)
+        p = center[:, :, None] + ray[:, :, None] * t
+        sdfs, feats = infer_sdf(p, sdf_sd, cfg, table, "ret_all")
+    normals = sdf_gradient(p.clone(), sdf_sd, cfg, table).detach()
+    with torch.no_grad():
+        ray_enc = fourier_embed(ray[..., None, :].expand_as(p))
+        geo = feats[..., 1:]
+        if cfg.dual_field:
+            geo = torch.cat([geo, geometry_feat(p, rad_sd, cfg, table)[..., 1:]], dim=-1)
+        rgbs = radiance_mlp(torch.cat([p, normals, ray_enc, geo], dim=-1), rad_sd)
+    b64 = sdf_sd["beta"].detach().double().clone().requires_grad_(True)
+    alpha, beta = forward_ab({"beta": b64}, cfg)
+    out = render_tail(cfg, ray.detach().double(), t.double(), sdfs.double(), normals.double(), rgbs.double(), alpha, beta)
+    loss_fn(out).backward()
+    return b64.grad
 
 
 # ----------------------------------------------------------------------------- sphere tracing

@@ -7,7 +7,7 @@
 Sizes the CPU oracle cannot render whole in test time, so each is checked through
   * a SPARSE ORACLE SAMPLE: a few rays per view rendered by the oracle; the fused outputs of those rays, and the
     gradients of a loss restricted to them (zero cotangent elsewhere -- the backward still processes the whole batch),
-    against the oracle to the path's bars (2e-5 outputs, 1e-4 every parameter gradient, d beta vs the fp64 oracle);
+    against the oracle to the path's bars (2e-5 outputs, 1e-4 every parameter gradient, d beta vs its exactly summed value);
   * SIZE-INDEPENDENT PROPERTIES: finite outputs, missed rays render the background exactly, depth within [near, far],
     and shard additivity -- the gradient of a sum-type loss over the whole [B,R] batch equals the sum over the B views
     rendered one by one (what the data-parallel path relies on, ls2fm/dist.py);
@@ -132,14 +132,14 @@ def test_full_shape_sparse_oracle_sample_and_properties(name):
     _loss(oret, t_s).backward()
     for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
         assert rel_err(ret[k][sel_d].cpu(), oret[k][0]) < 2e-5, k
-    o64s = {k: v.detach().cpu().double().requires_grad_(k == "beta") for k, v in sdf.state_dict().items()}
-    o64r = {k: v.detach().cpu().double() for k, v in rad.state_dict().items()}
-    _loss(OF.render(cfg, c_s.double(), r_s.double(), o64s, o64r), t_s.double()).backward()
+    exact_beta = OF.beta_gradient_exact_sum(cfg, c_s, r_s, {k: v.detach() for k, v in osd.items()},
+                                            {k: v.detach() for k, v in ord_.items()},
+                                            lambda out: _loss(out, t_s.double()))
     for pre, st in (("s.", osd), ("r.", ord_)):
         for k, v in st.items():
             ref = v.grad if v.grad is not None else torch.zeros_like(v)
             if pre + k == "s.beta":
-                _beta_ok(got[pre + k], ref, o64s["beta"].grad)
+                _beta_ok(got[pre + k], ref, exact_beta)
                 continue
             assert rel_err(got[pre + k], ref) < 1e-4, pre + k
 
