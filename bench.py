@@ -128,6 +128,7 @@ def main():
                          "wins by ~5 %% when the host keeps up, the graph wins when the host CPU is slow or busy)")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
+    ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
@@ -174,17 +175,19 @@ def main():
     head = RenderLossHead(dev, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0)           # same three terms and weights as loss_head()
     rgb_gt = torch.full((1, args.rays, 3), 0.5, device=dev)
     depth_ref = torch.zeros(1, args.rays, device=dev)
+    one = torch.ones((), device=dev)              # d loss / d loss (what loss.backward() would allocate and fill every step)
 
     def render_step():
         """Renderer.forward -> loss head -> backward: every parameter's .grad is (re)written"""
         for p in params:
             p.grad = None
-        ret = ren.forward(opt, center, ray, sdf, rad)
         if args.torch_loss:
-            loss = loss_head(ret)
-        else:
-            loss = head.terms(ret, rgb_gt, d_points=depth_ref)[1]
-        loss.backward()
+            loss = loss_head(ren.forward(opt, center, ray, sdf, rad))
+        elif args.split_loss:           # Renderer.forward, then the loss head as its own two kernels
+            loss = head.terms(ren.forward(opt, center, ray, sdf, rad), rgb_gt, d_points=depth_ref)[1]
+        else:                           # the loss head inside the render (forward epilogue / backward prologue)
+            loss = ren.forward_with_loss(opt, center, ray, sdf, rad, head, rgb_gt, d_points=depth_ref)[1]["all"]
+        loss.backward(gradient=one)
         return loss
 
     mode = "graph" if args.graph else args.launch

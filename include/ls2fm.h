@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 1
+#define LS2FM_ABI_VERSION 2
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -184,7 +184,8 @@ int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid,
  * center, ray [n_rays,3].  Outputs: rgb [n_rays,3], sdfs_volume [n_rays,N], normals [n_rays,N,3],
  * depth_mlp [n_rays], normal_mlp [n_rays,3].
  * workspace: ls2fm_render_workspace_bytes(...) bytes; its contents are consumed by ls2fm_render_bwd
- * for the same inputs, so it must be kept untouched between the two calls.
+ * for the same inputs, so it must be kept untouched between the two calls (ls2fm_render_bwd may run more than once on it).
+ * The hash-table gradient outputs of ls2fm_render_bwd must be 16-byte aligned (float4 stores).
  */
 #define LS2FM_MAX_RENDER_POINTS (1 << 23)   /* n_rays * n_samples per call (32-bit offsets and item counts inside);
                                                more: LS2FM_ERR_UNSUPPORTED -- split the rays over several calls */
@@ -195,10 +196,43 @@ int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_
  * buffer and refreshes it whenever either table changed (the host side keys it on the parameters' version counters). */
 int ls2fm_interleave_tables(const float* sdf_table, const float* rad_table, int64_t n_entries, float* dual_table,
                             void* stream);
+/* Optional extras of one render call (HOST struct; NULL = a plain render that a backward may follow).
+ *   inference_only  forward: non-zero = no ls2fm_render_bwd will follow on this workspace.  Otherwise the forward's gather
+ *                   pass also counts the items of the backward's table-gradient scatter (the corner cells are known there
+ *                   anyway) and scans them beside shade_fwd, so the backward starts its scatter without a counting pass.
+ *   loss            the loss head of the stage loops evaluated INSIDE the render (SURVEY.md section 8f row 1 "fuse as an
+ *                   epilogue of the render kernel"; replaces pipelines/Camera.py:515-537 + BA.py:206-218 exactly as
+ *                   ls2fm_loss_head_fwd/bwd below do, same tensors, same `terms` / `sums` layout): the forward's last kernel
+ *                   forms the per-ray partial sums while rgb / normals / depth are still in registers and a one-workgroup
+ *                   reduction writes `terms` and `sums`; the backward forms d rgb / d normals / d depth per sample from
+ *                   `sums` (the counts), `weights` and the scalar upstreams `d_terms` / `d_total` in its first kernel -- no
+ *                   [n_rays, N, 3] gradient tensor, no loss kernels between forward and backward.  Explicit upstreams
+ *                   (d_rgb ... of ls2fm_render_bwd) are added on top.  A sharded run may all-reduce `sums` between the two
+ *                   calls (and refresh `terms` with ls2fm_loss_terms_from_sums) for world-size-invariant means.
+ */
+typedef struct ls2fm_loss_spec {
+    const float* rgb_gt;          /* [n_rays,3] */
+    const float* depth_ref;       /* [n_rays] sphere-traced depth, or NULL = no depth-consistency term */
+    const uint8_t* mask_eik;      /* [n_rays] or NULL = every ray: rays whose samples enter the eikonal mean */
+    const uint8_t* mask_dc;       /* [n_rays] or NULL: mask_finish */
+    const uint8_t* mask_mse;      /* [n_rays] or NULL: mask_bg */
+    const float* weights;         /* DEVICE float[3] = 10^w of (rgb, eikonal, DC) */
+    float* terms;                 /* DEVICE float[6]: forward output (layout of ls2fm_loss_head_fwd) */
+    double* sums;                 /* DEVICE double[8]: forward output, backward input */
+    const float* d_terms;         /* backward: DEVICE float[5] upstream of terms[0..4], or NULL = zeros */
+    const float* d_total;         /* backward: DEVICE float[1] additional upstream of the weighted total, or NULL */
+    float* d_depth_ref;           /* backward output: [n_rays] gradient w.r.t. depth_ref (overwritten), or NULL */
+} ls2fm_loss_spec;
+
+typedef struct ls2fm_render_opts {
+    int32_t inference_only;
+    const ls2fm_loss_spec* loss;  /* NULL: no fused loss head */
+} ls2fm_render_opts;
+
 int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                      const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
                      const float* ray, int64_t n_rays, float* rgb, float* sdfs_volume, float* normals,
-                     float* depth_mlp, float* normal_mlp, void* workspace, void* stream);
+                     float* depth_mlp, float* normal_mlp, void* workspace, const ls2fm_render_opts* opts, void* stream);
 
 /* Fused backward of ls2fm_render_fwd, including the analytic double backward of the normal path
  * (normals feed the radiance decoder, normal_mlp and the eikonal loss).
@@ -213,7 +247,7 @@ int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_g
                      const float* ray, int64_t n_rays, const float* d_rgb, const float* d_sdfs_volume,
                      const float* d_normals, const float* d_depth_mlp, const float* d_normal_mlp,
                      const ls2fm_param_grads* grads, float* d_center, float* d_ray, void* workspace,
-                     void* stream);
+                     const ls2fm_render_opts* opts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bidirectional sphere tracing, the no-grad root-find loop.
@@ -260,6 +294,8 @@ int ls2fm_loss_head_bwd(const float* rgb, const float* rgb_gt, const float* norm
                         const float* depth_ref, const uint8_t* mask_eik, const uint8_t* mask_dc, const uint8_t* mask_mse,
                         int64_t n_rays, int32_t n_samples, const float* weights, const float* d_terms, const float* d_total,
                         float* d_rgb, float* d_normals, float* d_depth, float* d_depth_ref, const double* sums, void* stream);
+/* terms float[6] (DEVICE, overwritten) from sums double[8] (DEVICE) -- e.g. after a sharded run all-reduced the sums. */
+int ls2fm_loss_terms_from_sums(const double* sums, const float* weights, float* terms, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused Adam step over a list of fp32 tensors, one launch, one pass over memory.

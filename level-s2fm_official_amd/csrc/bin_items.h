@@ -1,0 +1,116 @@
+// Item classification of the table-gradient scatter, shared by the pass that COUNTS the items of every (tile, level, slab)
+// -- folded into the forward's gather pass (render_fwd.hip), which computes the corner indices anyway -- and the pass that
+// FILLS the sorted payload lists (bin_scatter.hip).  Both must classify identically: same functions, same arithmetic.
+#pragma once
+
+#include "render_common.h"
+
+namespace {
+
+constexpr int kAccSlots = 2 << kSlabShift;       // 16384 u64 accumulators = 128 KiB of LDS per workgroup
+constexpr int kSlabBins = 128;                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
+constexpr int kBins = kSlabBins;
+constexpr int kCountThreads = 512;
+constexpr int kFillThreads = 512;                // one sample point per thread
+constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
+constexpr int kAccThreads = 1024;
+constexpr int kMaxParts = 16;
+
+typedef unsigned long long u64;
+
+struct __attribute__((aligned(16))) Item {      // 32 bytes
+    uint32_t ij;           // local entry index of x-corner 0 (low 16 bits) and 1 (high 16 bits); 0xFFFF = not in this slab
+    float wx;              // x weight: px(0) = 1 - wx, px(1) = wx
+    float a0, a1, b0, b1;  // SDF grid, per feature: A = pyz de + qyz rr ; B = qd_x pyz rr
+    float c0, c1;          // second grid: C = pyz de2
+};
+
+struct BinMeta {           // device arrays inside the workspace
+    int* count;            // [L][kBins]  items per (level, slab)
+    int* start;            // [L][kBins]  absolute offsets into items
+    int* tile;             // [L][n_tiles][kBins]  per fill-workgroup counts, turned into absolute offsets by the scan: no
+                           //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
+                           //                      order is deterministic
+    Item* items;
+    float* level_bound;    // [32] max over rays of the per-ray contribution bounds (rows 0..15 SDF grid, 16..31 second grid)
+    int n_tiles;
+};
+
+struct LevelC {            // level constants
+    uint32_t size, res, hashed, mask;
+    bool pow2;
+    float scale;
+    int sshift;            // log2 of the slab size in entries on this level
+};
+
+__device__ __forceinline__ uint32_t wrap_index(uint32_t idx, uint32_t size) {
+    if (idx >= size) {                   // in-range points: at most one wrap (size >= res^3)
+        idx -= size;
+        if (idx >= size) idx %= size;    // only for positions far outside the unit cube
+    }
+    return idx;
+}
+
+__device__ __forceinline__ uint32_t level_index(const LevelC& L, uint32_t cx, uint32_t cy, uint32_t cz) {
+    if (L.hashed) {
+        const uint32_t h = cx ^ (cy * LS2FM_PRIME_Y) ^ (cz * LS2FM_PRIME_Z);
+        return L.pow2 ? (h & L.mask) : (h % L.size);
+    }
+    return wrap_index(cx + cy * L.res + cz * L.res * L.res, L.size);
+}
+
+// slabs of a level at the base slab size (8192 entries single grid / 4096 dual); a level with more than kSlabBins of them
+// (log2_hashmap_size > 19 single / > 19 dual) is refused by the launcher
+__host__ __device__ __forceinline__ int level_slabs(uint32_t size, int sshift) { return (int)((size + (1u << sshift) - 1u) >> sshift); }
+
+__device__ __forceinline__ LevelC make_level_c(const LevelSet& lv, int l, int sshift) {
+    LevelC L;
+    L.size = lv.size[l]; L.res = lv.res[l]; L.hashed = lv.hashed[l]; L.scale = lv.scale[l];
+    L.mask = L.size - 1u;
+    L.pow2 = (L.size & L.mask) == 0u;
+    L.sshift = sshift;
+    return L;
+}
+
+// The items of one (point, level): for each (y,z) corner pair c = by + 2 bz the two x-corner entries idx0, idx1; one item
+// when both lie in the same slab, else two half items.  f(slab, c, local idx0 or 0xFFFF, local idx1 or 0xFFFF).
+// Used identically by the count and the fill pass.
+template <typename F>
+__device__ __forceinline__ void for_each_item(const LevelC& L, const uint32_t g[3], F&& f) {
+    const uint32_t lmask = (1u << L.sshift) - 1u;
+#pragma unroll
+    for (unsigned c = 0; c < 4; ++c) {
+        const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
+        const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
+        const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
+        if (s0 == s1) {
+            f((int)s0, c, i0 & lmask, i1 & lmask);
+        } else {
+            f((int)s0, c, i0 & lmask, 0xFFFFu);
+            f((int)s1, c, 0xFFFFu, i1 & lmask);
+        }
+    }
+}
+
+
+constexpr int kFillTile = kFillThreads;          // sample points per count / fill workgroup (must agree)
+static_assert(kCountThreads == kFillThreads, "count and fill classify the same tiles");
+
+inline int64_t meta_ints(int64_t n_points) {
+    const int64_t n_tiles = (n_points + kFillTile - 1) / kFillTile;
+    return (2 * LS2FM_MAX_LEVELS * kBins + 64 + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
+}
+
+inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
+    BinMeta bm;
+    int* meta = reinterpret_cast<int*>(bins_ws);
+    bm.n_tiles = (int)((n_points + kFillTile - 1) / kFillTile);
+    bm.count = meta;
+    bm.start = meta + LS2FM_MAX_LEVELS * kBins;
+    bm.level_bound = reinterpret_cast<float*>(meta + 2 * LS2FM_MAX_LEVELS * kBins);
+    bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
+    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points));      // 256-byte aligned
+    return bm;
+}
+
+}  // namespace

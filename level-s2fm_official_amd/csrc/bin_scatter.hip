@@ -11,10 +11,10 @@
 //     two grids) -- so the records are turned into per-item payloads where they are still coalesced (by sample point)
 //     and delivered to the slabs sorted
 //
-//   scatter_count  thread = (point, level): which slab does each of the four (y,z) corner pairs fall into (the two
-//                  x-corners of a pair share a slab except when cx+1 carries across the slab bit or a dense row ends --
-//                  then the pair is split into two half items).  Needs the rays only: runs on the side stream under
-//                  shade_bwd.
+//   count          (in the forward's gather pass, render_fwd.hip: the corner cells are known there) per (512-point tile,
+//                  level): which slab does each of the four (y,z) corner pairs fall into (the two x-corners of a pair
+//                  share a slab except when cx+1 carries across the slab bit or a dense row ends -- then the pair is
+//                  split into two half items; bin_items.h)
 //   scatter_scan   per-(tile, slab) counts -> absolute offsets (two small kernels; no global atomics in any pass: 1 M of
 //                  them per pass cost ~50 us, and the item order is now deterministic)
 //   scatter_fill   same classification, now with shade_bwd's records (read once, coalesced): builds the 32-byte payload
@@ -31,94 +31,9 @@
 //                  stores (no zero fill); only point-split coarse levels are flushed with a few float atomics.
 #include <cstdlib>
 
-#include "render_common.h"
+#include "bin_items.h"
 
 namespace {
-
-constexpr int kAccSlots = 2 << kSlabShift;       // 16384 u64 accumulators = 128 KiB of LDS per workgroup
-constexpr int kSlabBins = 128;                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
-constexpr int kBins = kSlabBins;
-constexpr int kCountThreads = 512;
-constexpr int kFillThreads = 512;                // one sample point per thread
-constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
-constexpr int kAccThreads = 1024;
-constexpr int kMaxParts = 16;
-
-typedef unsigned long long u64;
-
-struct __attribute__((aligned(16))) Item {      // 32 bytes
-    uint32_t ij;           // local entry index of x-corner 0 (low 16 bits) and 1 (high 16 bits); 0xFFFF = not in this slab
-    float wx;              // x weight: px(0) = 1 - wx, px(1) = wx
-    float a0, a1, b0, b1;  // SDF grid, per feature: A = pyz de + qyz rr ; B = qd_x pyz rr
-    float c0, c1;          // second grid: C = pyz de2
-};
-
-struct BinMeta {           // device arrays inside the workspace
-    int* count;            // [L][kBins]  items per (level, slab)
-    int* start;            // [L][kBins]  absolute offsets into items
-    int* tile;             // [L][n_tiles][kBins]  per fill-workgroup counts, turned into absolute offsets by the scan: no
-                           //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
-                           //                      order is deterministic
-    Item* items;
-    float* level_bound;    // [32] max over rays of the per-ray contribution bounds (rows 0..15 SDF grid, 16..31 second grid)
-    int n_tiles;
-};
-
-struct LevelC {            // level constants
-    uint32_t size, res, hashed, mask;
-    bool pow2;
-    float scale;
-    int sshift;            // log2 of the slab size in entries on this level
-};
-
-__device__ __forceinline__ uint32_t wrap_index(uint32_t idx, uint32_t size) {
-    if (idx >= size) {                   // in-range points: at most one wrap (size >= res^3)
-        idx -= size;
-        if (idx >= size) idx %= size;    // only for positions far outside the unit cube
-    }
-    return idx;
-}
-
-__device__ __forceinline__ uint32_t level_index(const LevelC& L, uint32_t cx, uint32_t cy, uint32_t cz) {
-    if (L.hashed) {
-        const uint32_t h = cx ^ (cy * LS2FM_PRIME_Y) ^ (cz * LS2FM_PRIME_Z);
-        return L.pow2 ? (h & L.mask) : (h % L.size);
-    }
-    return wrap_index(cx + cy * L.res + cz * L.res * L.res, L.size);
-}
-
-// slabs of a level at the base slab size (8192 entries single grid / 4096 dual); a level with more than kSlabBins of them
-// (log2_hashmap_size > 19 single / > 19 dual) is refused by the launcher
-__host__ __device__ __forceinline__ int level_slabs(uint32_t size, int sshift) { return (int)((size + (1u << sshift) - 1u) >> sshift); }
-
-__device__ __forceinline__ LevelC make_level_c(const LevelSet& lv, int l, int sshift) {
-    LevelC L;
-    L.size = lv.size[l]; L.res = lv.res[l]; L.hashed = lv.hashed[l]; L.scale = lv.scale[l];
-    L.mask = L.size - 1u;
-    L.pow2 = (L.size & L.mask) == 0u;
-    L.sshift = sshift;
-    return L;
-}
-
-// The items of one (point, level): for each (y,z) corner pair c = by + 2 bz the two x-corner entries idx0, idx1; one item
-// when both lie in the same slab, else two half items.  f(slab, c, local idx0 or 0xFFFF, local idx1 or 0xFFFF).
-// Used identically by the count and the fill pass.
-template <typename F>
-__device__ __forceinline__ void for_each_item(const LevelC& L, const uint32_t g[3], F&& f) {
-    const uint32_t lmask = (1u << L.sshift) - 1u;
-#pragma unroll
-    for (unsigned c = 0; c < 4; ++c) {
-        const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
-        const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
-        const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
-        if (s0 == s1) {
-            f((int)s0, c, i0 & lmask, i1 & lmask);
-        } else {
-            f((int)s0, c, i0 & lmask, 0xFFFFu);
-            f((int)s1, c, 0xFFFFu, i1 & lmask);
-        }
-    }
-}
 
 // sample i -> grid-normalised position, exactly as every other kernel of the path computes it
 __device__ __forceinline__ void point_position(const FieldC& fc, const float* __restrict__ center, const float* __restrict__ ray,
@@ -128,30 +43,6 @@ __device__ __forceinline__ void point_position(const FieldC& fc, const float* __
     const RayGeom gm = load_ray(fc, center, ray, r);
     float p[3];
     sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
-}
-
-// ------------------------------------------------------------------------------------------------ count
-__global__ void __launch_bounds__(kCountThreads)
-scatter_count_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
-                     int sshift, BinMeta bm) {
-    __shared__ int hist[kBins];
-    const int tid = threadIdx.x, l = blockIdx.y;
-    for (int b = tid; b < kBins; b += kCountThreads) hist[b] = 0;
-    __syncthreads();
-    const LevelC L = make_level_c(lv, l, sshift);
-    const int64_t i = (int64_t)blockIdx.x * kCountThreads + tid;
-    if (i < n_points) {
-        float x[3];
-        point_position(fc, center, ray, i, x);
-        uint32_t g[3];
-        float w;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) pos_fract(x[a], L.scale, g[a], w);
-        for_each_item(L, g, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
-    }
-    __syncthreads();
-    int* row = bm.tile + ((int64_t)l * bm.n_tiles + blockIdx.x) * kBins;
-    for (int b = tid; b < kBins; b += kCountThreads) row[b] = hist[b];
 }
 
 // ------------------------------------------------------------------------------------------------ scan
@@ -443,26 +334,6 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
 #endif
 }
 
-constexpr int kFillTile = kFillThreads;          // sample points per count / fill workgroup (must agree)
-static_assert(kCountThreads == kFillThreads, "count and fill classify the same tiles");
-
-int64_t meta_ints(int64_t n_points) {
-    const int64_t n_tiles = (n_points + kFillTile - 1) / kFillTile;
-    return (2 * LS2FM_MAX_LEVELS * kBins + 64 + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
-}
-
-BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
-    BinMeta bm;
-    int* meta = reinterpret_cast<int*>(bins_ws);
-    bm.n_tiles = (int)((n_points + kFillTile - 1) / kFillTile);
-    bm.count = meta;
-    bm.start = meta + LS2FM_MAX_LEVELS * kBins;
-    bm.level_bound = reinterpret_cast<float*>(meta + 2 * LS2FM_MAX_LEVELS * kBins);
-    bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
-    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points));      // 256-byte aligned
-    return bm;
-}
-
 bool levels_fit(const ls2fm_grid_desc* grid, int sshift) {
     for (int l = 0; l < grid->n_levels; ++l)
         if (level_slabs(grid->size[l], sshift) > kSlabBins) return false;
@@ -479,15 +350,11 @@ int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points) {
 
 size_t ls2fm_bin_counts_bytes() { return 0; }      // nothing to zero: every count is written, not accumulated
 
-// count -> scan of the per-slab item lists: positions only (the rays), shared by both grids; counts zeroed by the caller
-int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, int64_t n_points,
-                           float* bins_ws, int dual, hipStream_t stream) {
-    const int sshift = ls2fm_slab_shift(dual);
-    if (!levels_fit(grid, sshift)) return LS2FM_ERR_UNSUPPORTED;
+bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual) { return levels_fit(grid, ls2fm_slab_shift(dual)); }
+
+// per-(tile, slab) item counts (written by the forward's gather pass, render_fwd.hip) -> absolute offsets of every run
+int ls2fm_launch_bin_scan(const ls2fm_grid_desc* grid, int64_t n_points, float* bins_ws, hipStream_t stream) {
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
-    const LevelSet lv = make_level_set(grid);
-    const dim3 g((unsigned)bm.n_tiles, (unsigned)grid->n_levels);
-    scatter_count_kernel<<<g, kCountThreads, 0, stream>>>(lv, fc, center, ray, n_points, sshift, bm);
     scatter_scan_tiles_kernel<<<grid->n_levels, kBins * kScanChunks, 0, stream>>>(bm);
     scatter_scan_kernel<<<1, 64 * LS2FM_MAX_LEVELS, 0, stream>>>(grid->n_levels, bm);
     return ls2fm_launch_status();

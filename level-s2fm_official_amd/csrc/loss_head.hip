@@ -151,7 +151,57 @@ loss_head_bwd_kernel(LossIn in, const float* __restrict__ weights, const double*
     }
 }
 
+// fused form (ls2fm_render_opts.loss): shade_fwd left four partial sums per ray; one workgroup adds them in fixed order in
+// fp64, derives the counts from the masks and finishes the terms.  lpart [4][r_pad]
+__global__ void __launch_bounds__(1024)
+loss_reduce_kernel(ls2fm_loss_spec loss, const float* __restrict__ lpart, int64_t n_rays, int64_t r_pad, int n_samples) {
+    __shared__ double red[16][kSums];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) s[k] = 0.0;
+    for (int64_t r = tid; r < n_rays; r += 1024) {
+        s[0] += (double)lpart[0 * r_pad + r];
+        s[1] += 3.0;
+        if (loss.mask_eik == nullptr || loss.mask_eik[r]) { s[2] += (double)lpart[1 * r_pad + r]; s[3] += (double)n_samples; }
+        if (loss.depth_ref != nullptr && (loss.mask_dc == nullptr || loss.mask_dc[r])) { s[4] += (double)lpart[2 * r_pad + r]; s[5] += 1.0; }
+        if (loss.mask_mse == nullptr || loss.mask_mse[r]) { s[6] += (double)lpart[3 * r_pad + r]; s[7] += 3.0; }
+    }
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) {
+        double v = s[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < kSums) {
+        double v = 0.0;
+        for (int q = 0; q < 16; ++q) v += red[q][tid];
+        red[0][tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) finish_terms(red[0], loss.weights, loss.terms, loss.sums);
+}
+
+__global__ void terms_from_sums_kernel(const double* __restrict__ sums, const float* __restrict__ weights, float* __restrict__ terms) {
+    double s[kSums], keep[kSums];
+    for (int k = 0; k < kSums; ++k) s[k] = sums[k];
+    finish_terms(s, weights, terms, keep);
+}
+
 }  // namespace
+
+int ls2fm_launch_loss_reduce(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples, hipStream_t stream) {
+    loss_reduce_kernel<<<1, 1024, 0, stream>>>(*loss, ray_part, n_rays, (n_rays + 63) / 64 * 64, n_samples);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_loss_terms_from_sums(const double* sums, const float* weights, float* terms, void* stream) {
+    LS2FM_CHECK_ARG(sums && weights && terms);
+    terms_from_sums_kernel<<<1, 1, 0, (hipStream_t)stream>>>(sums, weights, terms);
+    return ls2fm_launch_status();
+}
 
 extern "C" int64_t ls2fm_loss_head_workspace_bytes(void) {
     return (int64_t)sizeof(double) * kSums * kLossMaxBlocks + 64;

@@ -165,9 +165,6 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- C ABI
-int ls2fm_launch_bin_build(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, int64_t n_points,
-                           float* bins_ws, int dual, hipStream_t stream);
-size_t ls2fm_bin_counts_bytes();
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream);
@@ -180,7 +177,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
                                 const float* ray, int64_t n_rays, const float* d_rgb, const float* d_sdfs_volume,
                                 const float* d_normals, const float* d_depth_mlp, const float* d_normal_mlp,
                                 const ls2fm_param_grads* grads, float* d_center, float* d_ray, void* workspace,
-                                void* stream) {
+                                const ls2fm_render_opts* opts, void* stream) {
     LS2FM_CHECK_ARG(field && grid_desc_ok(sdf_grid) && params && grads && n_rays >= 0);
     LS2FM_CHECK_ARG(!field->dual_field || grid_desc_ok(rad_grid));
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;
@@ -188,6 +185,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (field->n_samples < 1 || field->n_samples > 512) return LS2FM_ERR_UNSUPPORTED;
     LS2FM_CHECK_ARG((d_center == nullptr) == (d_ray == nullptr));     // pose gradients: both or neither
     const int want_pose = d_center != nullptr;
+    const ls2fm_loss_spec* loss = opts ? opts->loss : nullptr;
+    LS2FM_CHECK_ARG(!loss || (loss->rgb_gt && loss->weights && loss->sums && (loss->d_terms || loss->d_total)));
     if (n_rays == 0) return LS2FM_OK;
     LS2FM_CHECK_ARG(center && ray && grads->sdf_table && grads->beta && (!field->dual_field || grads->rad_table));
     if (!workspace) return LS2FM_ERR_WORKSPACE;
@@ -204,38 +203,24 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
-    // fork 1: the per-slab item counts / offsets depend on the sample positions only.  They run beside shade_bwd on the
-    // HIGHEST-PRIORITY stream: at normal priority their few workgroups queue behind shade_bwd's and the chain (42 us alone)
-    // takes ~110 us -- longer than shade_bwd itself, i.e. scatter_fill ended up waiting for it.
-    // (Inside a stream capture the chain stays on the side stream: a captured graph maps a third concurrent branch onto the
-    // main branch's queue, which serialises it with shade_bwd -- measured 0.716 vs 0.700 ms/step.)
+    // fork 1: zero fills off the main chain.  (The per-slab item offsets of the scatter were built by the forward:
+    // counted inside its gather pass, scanned beside shade_fwd.)
     SideCtx sc;
-    bool forked = ls2fm_side_stream(&sc);
-    if (forked) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) sc.fast = sc.side;
-        forked = hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess &&
-                 (sc.fast == sc.side || hipStreamWaitEvent(sc.fast, sc.fork, 0) == hipSuccess);
-    }
+    bool forked = ls2fm_side_stream(&sc, s);
+    if (forked) forked = hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
-    hipStream_t fs = forked ? sc.fast : s;
-    // the reduced-weight-gradient accumulators are zeroed off the main chain (consumed by the wgrad kernels, which run on the
-    // side stream later)
-    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), gs) != hipSuccess) return LS2FM_ERR_LAUNCH;
-    {   // the point-split coarse levels of the gradient table(s) are zeroed up front (one small launch, off the main chain:
-        // only slab_accumulate, which waits for the `mid` event of this stream, needs it)
-        const int st = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, fs);
-        if (st != LS2FM_OK) return st;
-    }
-    ls2fm_prof_begin(LS2FM_PROF_BIN, fs);
-    {
-        const int st = ls2fm_launch_bin_build(sdf_grid, fc, center, ray, w.p, ws + w.bins, dual, fs);
-        if (st != LS2FM_OK) return st;
-    }
-    ls2fm_prof_end(LS2FM_PROF_BIN, fs);
-    if (forked && hipEventRecord(sc.mid, sc.fast) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    int status = LS2FM_OK;
+    // the reduced-weight-gradient accumulators (consumed by the wgrad kernels, which run on the side stream later) ...
+    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), gs) != hipSuccess) status = LS2FM_ERR_LAUNCH;
+    // ... and the point-split coarse levels of the gradient table(s) (one small launch; only slab_accumulate needs it)
+    if (status == LS2FM_OK) status = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, gs);
+    if (forked && hipEventRecord(sc.mid, sc.side) != hipSuccess) status = LS2FM_ERR_LAUNCH;
+    if (status != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, status);
 
-    const Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp};
+    Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp, LossUp{}};
+    if (loss)
+        up.loss = LossUp{loss->rgb_gt, loss->depth_ref, loss->mask_eik, loss->mask_dc, loss->mask_mse, loss->weights, loss->sums,
+                         loss->d_terms, loss->d_total, loss->d_depth_ref};
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
     ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
@@ -247,27 +232,27 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
 
     // fork 2: weight-gradient GEMM -> reduce -> finalize run on the side stream, concurrently with the table scatters
     if (forked && (hipEventRecord(sc.fork, s) != hipSuccess || hipStreamWaitEvent(sc.side, sc.fork, 0) != hipSuccess))
-        return LS2FM_ERR_LAUNCH;
+        return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
     ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     finalize_kernel<<<7, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
                                        ws + w.dbeta, n_rays);
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
-    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
 
     // hash-table gradients: LDS-owned slabs walking their binned item lists (bin_scatter.hip); tables overwritten in full
-    if (forked && hipStreamWaitEvent(s, sc.mid, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;         // item lists ready
+    if (forked && hipStreamWaitEvent(s, sc.mid, 0) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);   // zero fills done
     {
         // payloads sorted by slab, then one streaming pass per slab; dual field: both grids share geometry, hence items
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
         int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
                                            ws + w.rpt, ws + w.smax, n_rays, dual, s);
         ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
-        if (st != LS2FM_OK) return st;
+        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
         st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s);
         ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
-        if (st != LS2FM_OK) return st;
+        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();

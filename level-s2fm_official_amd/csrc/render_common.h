@@ -21,8 +21,9 @@ void ls2fm_prof_begin(int id, hipStream_t stream);      // bracket one kernel la
 void ls2fm_prof_end(int id, hipStream_t stream);
 
 // internal fork/join (streams.hip)
-struct SideCtx { hipStream_t side, fast; hipEvent_t fork, mid, join; };      // fast: highest-priority stream
-bool ls2fm_side_stream(SideCtx* out);
+struct SideCtx { hipStream_t side; hipEvent_t fork, mid, join; };
+bool ls2fm_side_stream(SideCtx* out, hipStream_t caller);       // side stream + events of this caller stream
+int ls2fm_join_on_error(bool forked, const SideCtx& sc, hipStream_t caller, int status);
 
 constexpr int kHidden = LS2FM_HIDDEN;     // 64
 constexpr int kOut = LS2FM_FEAT + 1;      // 17: sdf + 16 features
@@ -210,7 +211,7 @@ struct WsLayout {
     int64_t p, p_pad, r_pad;
     int l1, l2, dual;
     // forward -> backward
-    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2;
+    int64_t packed, e1, j1, e2, sdfv, nrm, rgbs, fe, fe2, rout, lpart;
     // backward scratch
     int64_t rec1, rec2, rpt, bins, v, p3, gf, dz, gf2, dzr, renc, dexyz, dlen, mpart, wg, dbeta, smax;
     int64_t total;
@@ -253,6 +254,8 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.rgbs = take(3 * P);
     w.fe = take(16 * P);
     w.fe2 = take(dual ? 16 * P : 0);
+    w.rout = take(4 * w.r_pad);      // per-ray outputs kept for a fused loss head's backward: rgb (3), depth_mlp  [4][r_pad]
+    w.lpart = take(4 * w.r_pad);     // fused loss head: per-ray partial sums  S|rgb-gt|, S| |n|-1 |, smooth_l1, S (rgb-gt)^2
     // scatter payload: per point {x y z | gn0 gn1 gn2 | - -} (32 B, 4 MB per 131072 points: L2-resident across all the
     // levels' slab workgroups) + per (level, point) {de0 de1 rr0 rr1} (SDF grid, 16 B) / {de0 de1} (second grid, 8 B)
     w.rpt = take(8 * P);
@@ -280,13 +283,28 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
 
 struct LevelScales { float s[LS2FM_MAX_LEVELS]; };
 
+// fused loss head, backward side (ls2fm_loss_spec + the per-ray outputs the forward kept): the upstream of rgb / normals /
+// depth is formed per sample from the counts in `sums`, the weights and the scalar upstreams
+struct LossUp {
+    const float* rgb_gt;           // null: no fused loss head
+    const float* depth_ref;
+    const uint8_t* mask_eik; const uint8_t* mask_dc; const uint8_t* mask_mse;
+    const float* weights; const double* sums; const float* d_terms; const float* d_total;
+    float* d_depth_ref;            // [R] output or null
+};
+
 struct Upstream {                  // dL/d(outputs of render_fwd); any pointer may be null (= zeros)
     const float* d_rgb;            // [R,3]
     const float* d_sdfs;           // [R,N]
     const float* d_normals;        // [R,N,3]
     const float* d_depth;          // [R]
     const float* d_nm;             // [R,3]
+    LossUp loss;
 };
+
+__device__ __forceinline__ float ls2fm_smooth_l1(float d) { const float a = fabsf(d); return a < 1.0f ? 0.5f * d * d : a - 0.5f; }
+__device__ __forceinline__ float ls2fm_smooth_l1_grad(float d) { return fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f); }
+__device__ __forceinline__ float ls2fm_sign(float d) { return d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f); }
 
 // shade_bwd.hip
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
@@ -305,4 +323,4 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
                            int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
-                           float* depth_mlp, float* normal_mlp, hipStream_t s);
+                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, hipStream_t s);

@@ -10,7 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 
-#include "render_common.h"
+#include "bin_items.h"
 
 namespace {
 
@@ -43,21 +43,20 @@ __device__ __forceinline__ int row_base(int li) {
     }
 }
 
-__global__ void __launch_bounds__(256)
-prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad,
-                    Packed* __restrict__ out) {
+// one workgroup of `nt` >= 256 threads (a multiple of 64) per task; callable from the stand-alone kernel below and from
+// the first workgroups of the gather pass (ray_encode_kernel)
+__device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad,
+                                  Packed* __restrict__ out, const int task, const int tid, const int nt) {
     // with_rad == 0: the no-graph SDF evaluation / sphere tracing -- scalar records of the SDF MLP only, no MFMA-ordered copies
     __shared__ float row_scale[296];
-    const int tid = threadIdx.x;
     // one workgroup per independent task (a single workgroup doing everything was a 72 us latency chain that gated
     // shade_fwd in single-field runs): 0 = SDF MLP, 1 = second field's MLP, 2 = radiance chain (+ beta)
-    const int task = blockIdx.x;
     if (task == 1 && !dual) return;
     const int row_lo = task == 0 ? row_base(0) : (task == 1 ? row_base(2) : row_base(4));
     const int row_hi = task == 0 ? row_base(2) : (task == 1 ? row_base(4) : row_base(7));
     // 1. weight-norm row scales  s = g / ||v||   (torch._weight_norm(v, g, 0) = v * (g / norm))
     //    (16 lanes per row: coalesced reads + a 16-wide shuffle reduction instead of a serial latency chain)
-    for (int row0 = row_lo; row0 < row_hi; row0 += 16) {
+    for (int row0 = row_lo; row0 < row_hi; row0 += nt / 16) {
         const int row = row0 + (tid >> 4), sub = tid & 15;
         int li = 0;
         while (li < 6 && row >= row_base(li + 1)) ++li;
@@ -80,7 +79,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
         const LayerRef L0 = layer_ref(P, which ? 2 : 0, ind, rad_in), L1 = layer_ref(P, which ? 3 : 1, ind, rad_in);
         const float* s0 = row_scale + row_base(which ? 2 : 0);
         const float* s1 = row_scale + row_base(which ? 3 : 1);
-        for (int idx = tid; idx < kHidden * kRecStride; idx += 256) {
+        for (int idx = tid; idx < kHidden * kRecStride; idx += nt) {
             const int j = idx / kRecStride, k = idx % kRecStride;
             float val = 0.f;
             if (k < ind) val = L0.v[j * ind + k] * s0[j];
@@ -88,7 +87,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             else if (k >= kRecW1 && k < kRecW1 + kOut) val = L1.v[(k - kRecW1) * kHidden + j] * s1[k - kRecW1];
             dst[idx] = val;
         }
-        for (int o = tid; o < 32; o += 256) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
+        for (int o = tid; o < 32; o += nt) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
         if (!with_rad) continue;
         // MFMA-operand-ordered copies (shade kernels): see MfmaW
         auto w0p = [&](int j, int kp) -> float {
@@ -97,11 +96,11 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
             return kp == 35 ? L0.b[j] : 0.f;
         };
         MfmaW& mw = out->mw;
-        for (int idx = tid; idx < 4 * 9 * 64; idx += 256) {
+        for (int idx = tid; idx < 4 * 9 * 64; idx += nt) {
             const int m = idx / (9 * 64), t = (idx / 64) % 9, ln = idx & 63;
             (which ? mw.geo : mw.sdf).w0a[m][t][ln] = w0p(16 * m + (ln & 15), 4 * t + (ln >> 4));
         }
-        for (int idx = tid; idx < 4 * 4 * 64; idx += 256) {
+        for (int idx = tid; idx < 4 * 4 * 64; idx += nt) {
             const int m = idx / 256, r = (idx / 64) & 3, ln = idx & 63;
             const int hid = 16 * m + 4 * (ln >> 4) + r;
             (which ? mw.geo : mw.sdf).w1a[m][r][ln] = L1.v[(1 + (ln & 15)) * kHidden + hid] * s1[1 + (ln & 15)];
@@ -114,17 +113,17 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
                 }
             }
         }
-        {
+        if (tid < 256) {
             const int r = tid >> 6, ln = tid & 63;
             mw.b1a[which][r][ln] = L1.b[1 + 4 * (ln >> 4) + r];
         }
         // backward copies
-        for (int idx = tid; idx < 4 * 9 * 64; idx += 256) {
+        for (int idx = tid; idx < 4 * 9 * 64; idx += nt) {
             const int m = idx / (9 * 64), t = (idx / 64) % 9, ln = idx & 63;
             const float v = w0p(16 * m + (ln & 15), 4 * t + (ln >> 4));
             if (which) out->bg.w0a[m][t][ln] = v; else out->bs.w0a[m][t][ln] = v;
         }
-        for (int idx = tid; idx < 4 * 5 * 64; idx += 256) {
+        for (int idx = tid; idx < 4 * 5 * 64; idx += nt) {
             const int m = idx / (5 * 64), t = (idx / 64) % 5, ln = idx & 63;
             const int hid = 16 * m + (ln & 15);
             if (which) {
@@ -134,7 +133,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
                 out->bs.w1ta[m][t][ln] = o < kOut ? L1.v[o * kHidden + hid] * s1[o] : 0.f;
             }
         }
-        for (int idx = tid; idx < 2 * 4 * 4 * 64; idx += 256) {
+        for (int idx = tid; idx < 2 * 4 * 4 * 64; idx += nt) {
             const int mk = idx / 1024, m = (idx / 256) & 3, r = (idx / 64) & 3, ln = idx & 63;
             const int hid = 16 * m + 4 * (ln >> 4) + r;
             const float v = w0p(hid, 16 * mk + (ln & 15));
@@ -156,18 +155,18 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
     {
         const LayerRef R0 = layer_ref(P, 4, in_dim, rad_in), R1 = layer_ref(P, 5, in_dim, rad_in),
                        R2 = layer_ref(P, 6, in_dim, rad_in);
-        for (int idx = tid; idx < 64 * 68; idx += 256) {
+        for (int idx = tid; idx < 64 * 68; idx += nt) {
             const int j = idx / 68, k = idx % 68;
             out->r0[j][k] = k < rad_in ? R0.v[j * rad_in + k] * row_scale[row_base(4) + j] : 0.f;
         }
-        for (int idx = tid; idx < 64 * 64; idx += 256)
+        for (int idx = tid; idx < 64 * 64; idx += nt)
             out->r1[idx / 64][idx % 64] = R1.v[idx] * row_scale[row_base(5) + idx / 64];
-        for (int idx = tid; idx < 3 * 64; idx += 256)
+        for (int idx = tid; idx < 3 * 64; idx += nt)
             out->r2[idx / 64][idx % 64] = R2.v[idx] * row_scale[row_base(6) + idx / 64];
     }
     __syncthreads();
     // 4. T1 = R2 R1
-    for (int idx = tid; idx < 3 * 64; idx += 256) {
+    for (int idx = tid; idx < 3 * 64; idx += nt) {
         const int c = idx / 64, j = idx % 64;
         float acc = 0.f;
         for (int m = 0; m < 64; ++m) acc = fmaf(out->r2[c][m], out->r1[m][j], acc);
@@ -175,7 +174,7 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
     }
     __syncthreads();
     // 5. Wc = T1 R0 ; bc = T1 b0 + R2 b1 + b2
-    for (int idx = tid; idx < 3 * 68; idx += 256) {
+    for (int idx = tid; idx < 3 * 68; idx += nt) {
         const int c = idx / 68, k = idx % 68;
         float acc = 0.f;
         if (k < rad_in)
@@ -190,6 +189,11 @@ prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dua
         out->bc[c] = acc;
     }
     if (tid == 3) out->bc[3] = 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad, Packed* __restrict__ out) {
+    prep_weights_task(P, in_dim, in_dim2, rad_in, dual, with_rad, out, (int)blockIdx.x, (int)threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------------------------------- ray_encode
@@ -208,56 +212,145 @@ __device__ unsigned long long g_enc_ticks[2 * LS2FM_MAX_LEVELS + 24];    // [0,3
                                                                           // (100 MHz); [32,40) last end per XCD; [40,48) first start
 #endif
 
-__global__ void __launch_bounds__(256)
+// What the gather pass does besides gathering, in the same launch (a launch boundary on the main chain costs 2-10 us, a
+// cross-stream join ~10 us, and a side stream's kernels take CUs from the main chain's):
+//   * its first 8 workgroups are reserved for the weight prep (3 tasks; the latency-bound 33 us chain hides under the gather)
+//   * when a backward will follow, every workgroup also COUNTS the items its 512 sample points will contribute to each slab
+//     of the table-gradient scatter on its level (bin_items.h): the corner cells are known here anyway, and the count /
+//     scan chain of the backward (16 us alone, 85 us beside shade_bwd, then 35 us of waiting before scatter_fill) is gone
+struct EncodeExtras {
+    ls2fm_params params;      // prep
+    int in_dim, in_dim2, rad_in, dual;
+    Packed* packed;           // null: no prep in this launch
+    int* tile_counts;         // [L][n_tiles][kBins] or null: no counting
+    int n_tiles, sshift;
+};
+
+constexpr int kEncThreads = kFillTile;       // 512: one workgroup = one (level, tile of the scatter's counting sort)
+constexpr int kEncReserved = 8;              // leading workgroups (a multiple of 8: block -> XCD mapping stays b % 8)
+
+// position of sample i, its cell on the level, the 8 corner entries (absolute) and fractions
+__device__ __forceinline__ void locate_sample(const FieldC& fc, const float* __restrict__ center, const float* __restrict__ ray,
+                                              int64_t i, const LevelSet& lv, int l, uint32_t g[3], Cell& c) {
+    const int64_t r = i / fc.n_samples;
+    const int n = (int)(i - r * fc.n_samples);
+    const RayGeom gm = load_ray(fc, center, ray, r);
+    float p[3], x[3];
+    sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos_fract(x[d], lv.scale[l], g[d], c.w[d]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        c.idx[k] = lv.offset[l] + corner_index(g[0] + (k & 1), g[1] + ((k >> 1) & 1), g[2] + ((k >> 2) & 1), lv.res[l],
+                                               lv.size[l], lv.hashed[l]);
+}
+
+// INTERLEAVED: dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner
+// serves both grids -- the gathers are bound by the L2 -> L1 line rate, not by bytes.
+template <bool INTERLEAVED>
+__global__ void __launch_bounds__(kEncThreads)
 ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
-                       const float* __restrict__ table1, const float* __restrict__ table2, int64_t n_points, int64_t p_pad,
-                       int n_chunks, XcdPlan plan, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+                  const float* __restrict__ table1, const float* __restrict__ table2, int64_t n_points, int64_t p_pad,
+                  int n_chunks, XcdPlan plan, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac,
+                  EncodeExtras ex) {
+    __shared__ int hist[kBins];
+    const int tid = threadIdx.x;
+    if (blockIdx.x < kEncReserved) {
+        if (ex.packed && blockIdx.x < 3)
+            prep_weights_task(ex.params, ex.in_dim, ex.in_dim2, ex.rad_in, ex.dual, 1, ex.packed, (int)blockIdx.x, tid, kEncThreads);
+        return;
+    }
+    const int bx = (int)blockIdx.x - kEncReserved;
+    const int xcd = bx & 7, j = bx >> 3;
     const int unit = plan.start[xcd] + j;
     if (unit >= plan.start[xcd + 1]) return;
     const int pl = unit / n_chunks;                      // pass-level: grid 1 levels, then grid 2 levels
-    const bool second = pl >= lv1.n_levels;
+    const int chunk = unit % n_chunks;
+    const bool second = !INTERLEAVED && pl >= lv1.n_levels;
     const int l = second ? pl - lv1.n_levels : pl;
     const LevelSet& lv = second ? lv2 : lv1;
-    const int64_t i = (int64_t)(unit % n_chunks) * 256 + threadIdx.x;
-    if (i >= n_points) return;
+    const bool counting = ex.tile_counts != nullptr && !second;          // workgroup-uniform
+    if (counting) {
+        for (int b = tid; b < kBins; b += kEncThreads) hist[b] = 0;
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)chunk * kEncThreads + tid;
 #ifdef LS2FM_STAMPS
     const long long t_begin = wall_clock64();
 #endif
-    const int64_t r = i / fc.n_samples;
-    const int n = (int)(i - r * fc.n_samples);
-    const RayGeom g = load_ray(fc, center, ray, r);
-    float p[3], x[3];
-    sample_position(fc, g, sample_depth(g, n, fc.n_samples), p, x);
-    Cell c;
-    locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
-    const float* __restrict__ table = second ? table2 : table1;
-    float2 v[8];
+    if (i < n_points) {
+        uint32_t g[3];
+        Cell c;
+        locate_sample(fc, center, ray, i, lv, l, g, c);
+        if (INTERLEAVED) {
+            const float4* __restrict__ table = reinterpret_cast<const float4*>(table1);
+            float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
-    float y0 = 0.f, y1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float wt = corner_weight(c.w, k);
-        y0 = fmaf(wt, v[k].x, y0);
-        y1 = fmaf(wt, v[k].y, y1);
-    }
-    float* __restrict__ enc = second ? enc2 : enc1;
-    __builtin_nontemporal_store(y0, enc + (2 * l + 0) * p_pad + i);
-    __builtin_nontemporal_store(y1, enc + (2 * l + 1) * p_pad + i);
-    if (!second) {
-#pragma unroll
-        for (int gd = 0; gd < 3; ++gd) {
-            float g0 = 0.f, g1 = 0.f;
+            for (int k = 0; k < 8; ++k) v[k] = table[c.idx[k]];
+            float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float dw = corner_dweight(c.w, k, gd);
-                g0 = fmaf(dw, v[k].x, g0);
-                g1 = fmaf(dw, v[k].y, g1);
+                const float wt = corner_weight(c.w, k);
+                y0 = fmaf(wt, v[k].x, y0);
+                y1 = fmaf(wt, v[k].y, y1);
+                y2 = fmaf(wt, v[k].z, y2);
+                y3 = fmaf(wt, v[k].w, y3);
             }
-            __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-            __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+            __builtin_nontemporal_store(y0, enc1 + (2 * l + 0) * p_pad + i);
+            __builtin_nontemporal_store(y1, enc1 + (2 * l + 1) * p_pad + i);
+            __builtin_nontemporal_store(y2, enc2 + (2 * l + 0) * p_pad + i);
+            __builtin_nontemporal_store(y3, enc2 + (2 * l + 1) * p_pad + i);
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) {
+                float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float dw = corner_dweight(c.w, k, gd);
+                    g0 = fmaf(dw, v[k].x, g0);
+                    g1 = fmaf(dw, v[k].y, g1);
+                }
+                __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+                __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+            }
+        } else {
+            const float* __restrict__ table = second ? table2 : table1;
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+            float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wt = corner_weight(c.w, k);
+                y0 = fmaf(wt, v[k].x, y0);
+                y1 = fmaf(wt, v[k].y, y1);
+            }
+            float* __restrict__ enc = second ? enc2 : enc1;
+            __builtin_nontemporal_store(y0, enc + (2 * l + 0) * p_pad + i);
+            __builtin_nontemporal_store(y1, enc + (2 * l + 1) * p_pad + i);
+            if (!second) {
+#pragma unroll
+                for (int gd = 0; gd < 3; ++gd) {
+                    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float dw = corner_dweight(c.w, k, gd);
+                        g0 = fmaf(dw, v[k].x, g0);
+                        g1 = fmaf(dw, v[k].y, g1);
+                    }
+                    __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+                    __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+                }
+            }
         }
+        if (counting) {        // the classification of scatter_fill, on the same cell
+            const LevelC L = make_level_c(lv, l, ex.sshift);
+            for_each_item(L, g, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
+        }
+    }
+    if (counting) {
+        __syncthreads();
+        int* row = ex.tile_counts + ((int64_t)l * ex.n_tiles + chunk) * kBins;
+        for (int b = tid; b < kBins; b += kEncThreads) row[b] = hist[b];
     }
 #ifdef LS2FM_STAMPS
     __syncthreads();
@@ -268,55 +361,6 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
         atomicMin(&g_enc_ticks[40 + xcd], (unsigned long long)t_begin);
     }
 #endif
-}
-
-// Dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner serves both
-// grids -- the gathers are bound by the L2->L1 request rate, not by bytes, so this halves the cost of the two encodes.
-__global__ void __launch_bounds__(256)
-ray_encode_dual_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
-                       const float4* __restrict__ table, int64_t n_points, int64_t p_pad, int n_chunks, XcdPlan plan,
-                       float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int unit = plan.start[xcd] + j;
-    if (unit >= plan.start[xcd + 1]) return;
-    const int l = unit / n_chunks;
-    const int64_t i = (int64_t)(unit % n_chunks) * 256 + threadIdx.x;
-    if (i >= n_points) return;
-    const int64_t r = i / fc.n_samples;
-    const int n = (int)(i - r * fc.n_samples);
-    const RayGeom g = load_ray(fc, center, ray, r);
-    float p[3], x[3];
-    sample_position(fc, g, sample_depth(g, n, fc.n_samples), p, x);
-    Cell c;
-    locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = table[c.idx[k]];
-    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float wt = corner_weight(c.w, k);
-        y0 = fmaf(wt, v[k].x, y0);
-        y1 = fmaf(wt, v[k].y, y1);
-        y2 = fmaf(wt, v[k].z, y2);
-        y3 = fmaf(wt, v[k].w, y3);
-    }
-    __builtin_nontemporal_store(y0, enc1 + (2 * l + 0) * p_pad + i);
-    __builtin_nontemporal_store(y1, enc1 + (2 * l + 1) * p_pad + i);
-    __builtin_nontemporal_store(y2, enc2 + (2 * l + 0) * p_pad + i);
-    __builtin_nontemporal_store(y3, enc2 + (2 * l + 1) * p_pad + i);
-#pragma unroll
-    for (int gd = 0; gd < 3; ++gd) {
-        float g0 = 0.f, g1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float dw = corner_dweight(c.w, k, gd);
-            g0 = fmaf(dw, v[k].x, g0);
-            g1 = fmaf(dw, v[k].y, g1);
-        }
-        __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-        __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
-    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -422,55 +466,86 @@ extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, c
     return w.total * (int64_t)sizeof(float);
 }
 
+bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
+int ls2fm_launch_bin_scan(const ls2fm_grid_desc* grid, int64_t n_points, float* bins_ws, hipStream_t stream);
+int ls2fm_launch_loss_reduce(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples, hipStream_t stream);
+
 extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
                                 const float* ray, int64_t n_rays, float* rgb, float* sdfs_volume, float* normals,
-                                float* depth_mlp, float* normal_mlp, void* workspace, void* stream) {
+                                float* depth_mlp, float* normal_mlp, void* workspace, const ls2fm_render_opts* opts,
+                                void* stream) {
     LS2FM_CHECK_ARG(render_config_ok(field, sdf_grid, rad_grid) && params && n_rays >= 0);
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;       // min(sdf, bg_rad-|p|): general (composed) form only
     if (field->dual_field && !same_grid_geometry(sdf_grid, rad_grid)) return LS2FM_ERR_UNSUPPORTED;
     if (n_rays * (int64_t)field->n_samples > LS2FM_MAX_RENDER_POINTS) return LS2FM_ERR_UNSUPPORTED;
+    const ls2fm_loss_spec* loss = opts ? opts->loss : nullptr;
+    LS2FM_CHECK_ARG(!loss || (loss->rgb_gt && loss->weights && loss->terms && loss->sums));
     if (n_rays == 0) return LS2FM_OK;
     LS2FM_CHECK_ARG(center && ray && rgb && sdfs_volume && normals && depth_mlp && normal_mlp);
     if (!workspace) return LS2FM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int dual = field->dual_field ? 1 : 0;
+    const bool prepare_bwd = !(opts && opts->inference_only);
+    if (prepare_bwd && !ls2fm_bins_levels_fit(sdf_grid, dual)) return LS2FM_ERR_UNSUPPORTED;
     const int L1 = sdf_grid->n_levels, L2 = dual ? rad_grid->n_levels : 0;
     const WsLayout w = make_ws_layout(n_rays, field->n_samples, L1, dual ? L2 : L1, dual);
     float* ws = (float*)workspace;
     Packed* pk = (Packed*)(ws + w.packed);
     const FieldC fc = make_field_c(field);
-    const int rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1);
 
-    // fork: the single-workgroup weight prep (latency bound) overlaps with the wide hash-grid gather
-    SideCtx sc;
-    const bool forked = ls2fm_side_stream(&sc) && hipEventRecord(sc.fork, s) == hipSuccess &&
-                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
-    hipStream_t ps = forked ? sc.side : s;
-    ls2fm_prof_begin(LS2FM_PROF_PREP, ps);
-    prep_weights_kernel<<<3, 256, 0, ps>>>(*params, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, 1, pk);
-    ls2fm_prof_end(LS2FM_PROF_PREP, ps);
-    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return LS2FM_ERR_LAUNCH;
-    const int n_chunks = (int)((w.p + 255) / 256);
+    // ---- gather pass (+ weight prep in its first workgroups, + the scatter's item counts when a backward follows)
+    const int n_chunks = (int)((w.p + kEncThreads - 1) / kEncThreads);
     const bool interleaved = dual && params->dual_table;
     const bool pair = dual && !interleaved;      // both grids, one launch
     const int enc_span = pair ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;
     int most = 0;
     const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, &most);
+    EncodeExtras ex;
+    ex.params = *params;
+    ex.in_dim = 3 + 2 * L1; ex.in_dim2 = 3 + 2 * L2; ex.rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1); ex.dual = dual;
+    ex.packed = pk;
+    ex.tile_counts = nullptr; ex.n_tiles = 0; ex.sshift = ls2fm_slab_shift(dual);
+    if (prepare_bwd) {
+        const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
+        ex.tile_counts = bm.tile;
+        ex.n_tiles = bm.n_tiles;
+    }
+    const unsigned enc_blocks = (unsigned)(kEncReserved + 8 * most);
     ls2fm_prof_begin(enc_span, s);
     if (interleaved)
-        ray_encode_dual_kernel<<<(unsigned)(8 * most), 256, 0, s>>>(make_level_set(sdf_grid), fc, center, ray,
-                                                                    reinterpret_cast<const float4*>(params->dual_table), w.p,
-                                                                    w.p_pad, n_chunks, plan, ws + w.e1, ws + w.e2, ws + w.j1);
+        ray_encode_kernel<true><<<enc_blocks, kEncThreads, 0, s>>>(
+            make_level_set(sdf_grid), make_level_set(sdf_grid), fc, center, ray, params->dual_table, nullptr, w.p, w.p_pad, n_chunks,
+            plan, ws + w.e1, ws + w.e2, ws + w.j1, ex);
     else
-        ray_encode_kernel<<<(unsigned)(8 * most), 256, 0, s>>>(
+        ray_encode_kernel<false><<<enc_blocks, kEncThreads, 0, s>>>(
             make_level_set(sdf_grid), make_level_set(pair ? rad_grid : sdf_grid), fc, center, ray, params->sdf_table,
-            pair ? params->rad_table : nullptr, w.p, w.p_pad, n_chunks, plan, ws + w.e1, pair ? ws + w.e2 : nullptr, ws + w.j1);
+            pair ? params->rad_table : nullptr, w.p, w.p_pad, n_chunks, plan, ws + w.e1, pair ? ws + w.e2 : nullptr, ws + w.j1, ex);
     ls2fm_prof_end(enc_span, s);
-    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
+
+    // ---- fork: the scans of the item counts (15 us, two small launches) run beside shade_fwd
+    SideCtx sc;
+    bool forked = false;
+    if (prepare_bwd) {
+        forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess &&
+                 hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+        hipStream_t bs = forked ? sc.side : s;
+        ls2fm_prof_begin(LS2FM_PROF_BIN, bs);
+        int st = ls2fm_launch_bin_scan(sdf_grid, w.p, ws + w.bins, bs);
+        ls2fm_prof_end(LS2FM_PROF_BIN, bs);
+        if (st == LS2FM_OK && forked && hipEventRecord(sc.join, sc.side) != hipSuccess) st = LS2FM_ERR_LAUNCH;
+        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+    }
     ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
     ls2fm_launch_shade_fwd(fc, dual, 2 * L1, 2 * L2, pk, center, ray, n_rays, w, ws, rgb, sdfs_volume, normals, depth_mlp,
-                           normal_mlp, s);
+                           normal_mlp, loss, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_FWD, s);
+    if (loss) {
+        ls2fm_prof_begin(LS2FM_PROF_LOSS_FWD, s);
+        const int st = ls2fm_launch_loss_reduce(loss, ws + w.lpart, n_rays, field->n_samples, s);
+        ls2fm_prof_end(LS2FM_PROF_LOSS_FWD, s);
+        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+    }
+    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();
 }

@@ -70,7 +70,37 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             g_rgb[c] = up.d_rgb ? up.d_rgb[r * 3 + c] : 0.f;
             g_nm[c] = up.d_nm ? up.d_nm[r * 3 + c] : 0.f;
         }
-        const float g_dep = up.d_depth ? up.d_depth[r] : 0.f;
+        float g_dep = up.d_depth ? up.d_depth[r] : 0.f;
+        // fused loss head (ls2fm_loss_spec): the upstream of rgb / depth / normals is formed here from the counts of the
+        // forward's reduction, the weights and the scalar upstreams -- exactly loss_head_bwd_kernel's arithmetic
+        float gl_eik = 0.f;
+        if (up.loss.rgb_gt != nullptr) {
+            const LossUp& lo = up.loss;
+            float gt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (lo.d_terms) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) gt[k] = lo.d_terms[k];
+            }
+            const float g_all = gt[4] + (lo.d_total ? lo.d_total[0] : 0.f);
+            const float gl_rgb = fmaf(lo.weights[0], g_all, gt[0]) / (float)lo.sums[1];
+            const float gl_dc = lo.sums[5] > 0.0 ? fmaf(lo.weights[2], g_all, gt[2]) / (float)lo.sums[5] : 0.f;
+            const float gl_mse = gt[3] / (float)lo.sums[7];
+            if (lo.mask_eik == nullptr || lo.mask_eik[r] != 0) gl_eik = fmaf(lo.weights[1], g_all, gt[1]) / (float)lo.sums[3];
+            const float* __restrict__ rout = fws + w.rout;
+            const bool in_mse = lo.mask_mse == nullptr || lo.mask_mse[r] != 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = rout[c * w.r_pad + r] - lo.rgb_gt[r * 3 + c];
+                float v = gl_rgb * ls2fm_sign(d);
+                if (in_mse) v = fmaf(gl_mse * 2.0f, d, v);
+                g_rgb[c] += v;
+            }
+            float gd = 0.f;
+            if (lo.depth_ref != nullptr && (lo.mask_dc == nullptr || lo.mask_dc[r] != 0))
+                gd = gl_dc * ls2fm_smooth_l1_grad(lo.depth_ref[r] - rout[3 * w.r_pad + r]);
+            g_dep -= gd;
+            if (n == 0 && lo.d_depth_ref != nullptr) lo.d_depth_ref[r] = gd;
+        }
         // forward per-sample values saved by shade_fwd
         const float sdf = fws[w.sdfv + i];
         float nrm[3], col[3], n_last[3];
@@ -132,6 +162,12 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             if (n == N - 1) v += rest * g_nm[a];
             if (live && up.d_normals) v += up.d_normals[i * 3 + a];
             gn[a] = live ? v : 0.f;
+        }
+        if (gl_eik != 0.f && live) {       // eikonal term: d | |n| - 1 | / d n   (d |n| at 0 := 0, as torch)
+            const float len = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+            const float k = len > 0.f ? gl_eik * ls2fm_sign(len - 1.0f) / len : 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gn[a] = fmaf(k, nrm[a], gn[a]);
         }
         float g_sdf = (live && up.d_sdfs) ? up.d_sdfs[i] : 0.f;
         {   // sigma backward (+ d beta)

@@ -38,7 +38,8 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
                  const float* __restrict__ J1, const float* __restrict__ E2, float* __restrict__ rgb_out,
                  float* __restrict__ sdfs_out, float* __restrict__ normals_out, float* __restrict__ depth_out,
                  float* __restrict__ nm_out, float* __restrict__ SDFV, float* __restrict__ NRM,
-                 float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2) {
+                 float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2, float* __restrict__ ROUT,
+                 float* __restrict__ LPART, int64_t r_pad, ls2fm_loss_spec loss) {
     __shared__ float s_part[MAXT / 64][10];     // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
     __shared__ float s_view[3];
     __shared__ float s_x[MAXT][8];              // per sample: sdf, normal(3), colour(3)
@@ -314,6 +315,14 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         const float s = wave_sum(sums[q]);
         if (lane == 0) s_part[wave][1 + q] = s;
     }
+    // fused loss head: this ray's eikonal partial  sum_n | |n_n| - 1 |  (Initialization.py:257-258, BA.py:193-194)
+    const bool want_eik = loss.rgb_gt != nullptr && (loss.mask_eik == nullptr || loss.mask_eik[r] != 0);
+    if (loss.rgb_gt != nullptr) {
+        float e = 0.f;
+        if (want_eik && live) e = fabsf(sqrtf(nrm_n[0] * nrm_n[0] + nrm_n[1] * nrm_n[1] + nrm_n[2] * nrm_n[2]) - 1.0f);
+        e = wave_sum(e);
+        if (lane == 0) s_part[wave][9] = e;
+    }
     __syncthreads();
     if (n == N - 1) {         // the last sample's thread owns t_last / n_last and writes the ray outputs
         float tot[8];
@@ -323,11 +332,33 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             for (int w = 0; w < n_waves; ++w) tot[q] += s_part[w][1 + q];
         }
         const float rest = 1.0f - tot[7];
+        float rgb_r[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb_out[r * 3 + c] = tot[c] + rest * fc.bg[c];
-        depth_out[r] = tot[3] + rest * t;
+        for (int c = 0; c < 3; ++c) { rgb_r[c] = tot[c] + rest * fc.bg[c]; rgb_out[r * 3 + c] = rgb_r[c]; }
+        const float depth_r = tot[3] + rest * t;
+        depth_out[r] = depth_r;
 #pragma unroll
         for (int a = 0; a < 3; ++a) nm_out[r * 3 + a] = tot[4 + a] + rest * nrm_n[a];
+        if (loss.rgb_gt != nullptr) {
+            // per-ray partial sums of the loss head (pipelines/Camera.py:520-535): reduced in fixed order by loss_reduce; the
+            // ray's rgb / depth are kept for the backward, which forms the upstream of the outputs itself
+            float l1 = 0.f, sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = rgb_r[c] - loss.rgb_gt[r * 3 + c];
+                l1 += fabsf(d);
+                sq = fmaf(d, d, sq);
+                ROUT[c * r_pad + r] = rgb_r[c];
+            }
+            ROUT[3 * r_pad + r] = depth_r;
+            float eik = 0.f;
+            for (int w = 0; w < n_waves; ++w) eik += s_part[w][9];
+            const bool dc = loss.depth_ref != nullptr && (loss.mask_dc == nullptr || loss.mask_dc[r] != 0);
+            LPART[0 * r_pad + r] = l1;
+            LPART[1 * r_pad + r] = eik;
+            LPART[2 * r_pad + r] = dc ? ls2fm_smooth_l1(loss.depth_ref[r] - depth_r) : 0.f;
+            LPART[3 * r_pad + r] = (loss.mask_mse == nullptr || loss.mask_mse[r] != 0) ? sq : 0.f;
+        }
     }
 }
 
@@ -335,12 +366,15 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
                            int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
-                           float* depth_mlp, float* normal_mlp, hipStream_t s) {
+                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, hipStream_t s) {
     const int threads = (fc.n_samples + 63) / 64 * 64;
+    ls2fm_loss_spec ls{};            // rgb_gt == null: plain render
+    if (loss) ls = *loss;
 #define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                                \
     shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                              \
         fc, ch1, ch2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb, sdfs_volume, \
-        normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe, DUAL ? ws + w.fe2 : nullptr)
+        normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe, DUAL ? ws + w.fe2 : nullptr,        \
+        ws + w.rout, ws + w.lpart, w.r_pad, ls)
     if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 512); }
 #undef LS2FM_SHADE_FWD

@@ -1,40 +1,52 @@
-// Internal fork/join helper: a cached non-blocking side stream + events per device, so that latency-bound
-// single-workgroup kernels (prep_weights, wgrad_reduce, finalize) and the MFMA weight-gradient GEMM overlap with the
-// wide kernels of the same call.  Everything forked is joined back into the caller's stream before the C-ABI call
-// returns, so the caller-visible contract ("asynchronous on `stream`") is unchanged.  LS2FM_SERIAL=1 disables it, and so does the opt-in per-kernel
-// profiler (overlapped kernels would time each other).
+// Internal fork/join helper: a non-blocking side stream + events PER CALLER STREAM (per device), so that latency-bound
+// small kernels (the scatter's scans, finalize) and the MFMA weight-gradient chain overlap with the wide kernels of the
+// same call.  Everything forked is joined back into the caller's stream before the C-ABI call returns -- on error paths
+// too (ls2fm_join_on_error) -- so the caller-visible contract ("asynchronous on `stream`") is unchanged and an active stream
+// capture is never left with an unjoined branch.  Calls on DIFFERENT caller streams (two host threads, autograd on two
+// streams) get different side streams and events, so they cannot order against each other's forks; concurrent calls on the
+// SAME stream from two threads are as undefined as any other concurrent use of one stream.
+// LS2FM_SERIAL=1 disables the fork, and so does the opt-in per-kernel profiler (overlapped kernels would time each other).
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "render_common.h"
 
 namespace {
-struct DeviceCtx { bool init = false; hipStream_t side = nullptr, fast = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; };
+struct StreamCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; };
 std::mutex g_mu;
-DeviceCtx g_ctx[64];
+std::map<std::pair<int, hipStream_t>, StreamCtx> g_ctx;
+constexpr size_t kMaxContexts = 64;          // streams come and go: beyond this, calls run unforked instead of leaking
 }  // namespace
 
-bool ls2fm_side_stream(SideCtx* out) {
+bool ls2fm_side_stream(SideCtx* out, hipStream_t caller) {
     static const bool serial = [] { const char* e = getenv("LS2FM_SERIAL"); return e && e[0] == '1'; }();
     if (serial || ls2fm_prof_enabled()) return false;      // per-kernel profiling: serial launches, so that the
                                                            // event-bracketed durations are those of the kernel alone
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(g_mu);
-    DeviceCtx& c = g_ctx[dev];
-    if (!c.init) {
+    auto it = g_ctx.find({dev, caller});
+    if (it == g_ctx.end()) {
+        if (g_ctx.size() >= kMaxContexts) return false;
+        StreamCtx c;
         if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return false;
-        {   // small latency-critical chains (the scatter's count / scan) go to a stream of the highest priority, so that their
-            // few workgroups are dispatched ahead of the wide kernel they run beside
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
-            if (hipStreamCreateWithPriority(&c.fast, hipStreamNonBlocking, hi) != hipSuccess) return false;
-        }
-        if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&c.mid, hipEventDisableTiming) != hipSuccess) return false;
-        c.init = true;
+        if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.mid, hipEventDisableTiming) != hipSuccess)
+            return false;
+        it = g_ctx.emplace(std::make_pair(dev, caller), c).first;
     }
-    out->side = c.side; out->fast = c.fast; out->fork = c.fork; out->mid = c.mid; out->join = c.join;
+    out->side = it->second.side; out->fork = it->second.fork; out->mid = it->second.mid; out->join = it->second.join;
     return true;
+}
+
+// an error after a fork: whatever was enqueued on the side stream is still joined into the caller's stream
+int ls2fm_join_on_error(bool forked, const SideCtx& sc, hipStream_t caller, int status) {
+    if (forked) {
+        (void)hipEventRecord(sc.join, sc.side);
+        (void)hipStreamWaitEvent(caller, sc.join, 0);
+    }
+    return status;
 }

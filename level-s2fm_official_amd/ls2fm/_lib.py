@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +77,17 @@ class ParamGrads(Structure):
     ]
 
 
+class LossSpec(Structure):
+    """ls2fm_loss_spec: the loss head evaluated inside the render (forward epilogue / backward prologue)"""
+    _fields_ = [("rgb_gt", c_void_p), ("depth_ref", c_void_p), ("mask_eik", c_void_p), ("mask_dc", c_void_p),
+                ("mask_mse", c_void_p), ("weights", c_void_p), ("terms", c_void_p), ("sums", c_void_p),
+                ("d_terms", c_void_p), ("d_total", c_void_p), ("d_depth_ref", c_void_p)]
+
+
+class RenderOpts(Structure):
+    _fields_ = [("inference_only", c_int32), ("loss", POINTER(LossSpec))]
+
+
 _P = c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)        -- must list every symbol include/ls2fm.h declares
@@ -95,9 +106,10 @@ _SIGNATURES = {
     "ls2fm_render_workspace_bytes": (c_int64, [POINTER(FieldDesc), POINTER(GridDesc), c_int64]),
     "ls2fm_interleave_tables": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ls2fm_render_fwd": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(GridDesc), POINTER(Params), _P, _P,
-                                   c_int64, _P, _P, _P, _P, _P, _P, _P]),
+                                   c_int64, _P, _P, _P, _P, _P, _P, POINTER(RenderOpts), _P]),
     "ls2fm_render_bwd": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(GridDesc), POINTER(Params), _P, _P,
-                                   c_int64, _P, _P, _P, _P, _P, POINTER(ParamGrads), _P, _P, _P, _P]),
+                                   c_int64, _P, _P, _P, _P, _P, POINTER(ParamGrads), _P, _P, _P, POINTER(RenderOpts), _P]),
+    "ls2fm_loss_terms_from_sums": (c_int32, [_P, _P, _P, _P]),
     "ls2fm_sphere_trace": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
                                      c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ls2fm_loss_head_workspace_bytes": (c_int64, []),

@@ -51,6 +51,22 @@ def global_mean(local_sum: torch.Tensor, local_count: torch.Tensor) -> torch.Ten
     return pair[0] / pair[1].clamp_min(1)
 
 
+def globalize_loss_sums(sums: torch.Tensor, mode: str = "allreduce") -> None:
+    """fp64 [8] = (sum, count) x (rgb L1, eikonal, DC, mse) of this rank's rays -> what the loss head's backward must divide by
+    so that the all-reduced gradients are those of the GLOBAL means (the reference's losses are means over all rays /
+    masked subsets: Camera.py:515-537).  In place.  "allreduce": sums and counts summed over the ranks (one 64-byte
+    collective between forward and backward); "uniform": every rank holds the same number of rays and no masks -- the counts
+    are multiplied by the world size, nothing is exchanged, a rank's loss terms are then its share of the global means."""
+    if not is_distributed():
+        return
+    if mode == "allreduce":
+        dist.all_reduce(sums)
+    elif mode == "uniform":
+        sums[1::2] *= dist.get_world_size()
+    else:
+        raise ValueError(f"global_counts={mode!r}: expected 'allreduce' or 'uniform'")
+
+
 def global_max_int(value: int, device) -> int:
     """e.g. the sphere-tracing trip count K (SDF.py:167 tests a mask over ALL rays)"""
     if not is_distributed():

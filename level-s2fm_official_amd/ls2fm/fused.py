@@ -261,9 +261,31 @@ def _refresh_dual_table(lib, plan, sdf_table, rad_table):
     plan.dual_key = key
 
 
+class FusedLoss:
+    """What the fused loss head of one render needs (ls2fm_loss_spec): built by ls2fm.losses.RenderLossHead.spec()."""
+    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts")
+
+    def __init__(self, weights, rgb_gt, mask_eik=None, mask_dc=None, mask_mse=None, global_counts="allreduce"):
+        self.weights, self.rgb_gt = weights, rgb_gt
+        self.mask_eik, self.mask_dc, self.mask_mse = mask_eik, mask_dc, mask_mse
+        self.global_counts = global_counts
+
+
+def _loss_struct(fl, depth_ref, terms, sums, d_terms=None, d_total=None, d_depth_ref=None):
+    s = _lib.LossSpec()
+    s.rgb_gt, s.depth_ref = ptr(fl.rgb_gt), ptr(depth_ref)
+    s.mask_eik, s.mask_dc, s.mask_mse = ptr(fl.mask_eik), ptr(fl.mask_dc), ptr(fl.mask_mse)
+    s.weights, s.terms, s.sums = ptr(fl.weights), ptr(terms), ptr(sums)
+    s.d_terms, s.d_total, s.d_depth_ref = ptr(d_terms), ptr(d_total), ptr(d_depth_ref)
+    return s
+
+
 class _Render(torch.autograd.Function):
+    """Renderer.forward (and, with a FusedLoss, the loss head of the stage loops inside it) as ONE autograd node.
+    outputs: rgb, sdfs_volume, normals, depth_mlp, normal_mlp [, terms (5), total]"""
+
     @staticmethod
-    def forward(ctx, center, ray, cfg, *params):
+    def forward(ctx, center, ray, depth_ref, cfg, fl, want_bwd, *params):
         fdesc, g1, g2, dual, beta_speed, plan = cfg
         lib = _lib.load()
         ctx.set_materialize_grads(False)        # unused outputs reach backward as None -> NULL upstream, no zero fills
@@ -302,26 +324,47 @@ class _Render(torch.autograd.Function):
         depth = torch.empty(*shape2, 1, device=dev)
         nmlp = torch.empty(*shape2, 3, device=dev)
         pstruct = plan.pstruct
+        opts = _lib.RenderOpts()
+        opts.inference_only = 0 if want_bwd else 1
+        terms = sums = dref = None
+        if fl is not None:
+            dref = None if depth_ref is None else depth_ref.detach().reshape(-1).float().contiguous()
+            if fl.rgb_gt.numel() != 3 * n_rays or (dref is not None and dref.numel() != n_rays):
+                raise RuntimeError("ls2fm: fused loss head: rgb_gt / d_points do not match the rays")
+            terms = torch.empty(6, device=dev, dtype=torch.float32)
+            sums = torch.empty(8, device=dev, dtype=torch.float64)
+            lspec = _loss_struct(fl, dref, terms, sums)
+            opts.loss = ctypes.pointer(lspec)
         check(lib.ls2fm_render_fwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), n_rays, ptr(rgb), ptr(sdfs), ptr(normals),
-                                   ptr(depth), ptr(nmlp), ptr(ws), stream_ptr()), "ls2fm_render_fwd")
+                                   ptr(depth), ptr(nmlp), ptr(ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_fwd")
+        if fl is not None:
+            from . import dist as _dist
+            if _dist.is_distributed():        # world-size-invariant means: global counts (and sums) before the backward
+                _dist.globalize_loss_sums(sums, fl.global_counts)
+                check(lib.ls2fm_loss_terms_from_sums(ptr(sums), ptr(fl.weights), ptr(terms), stream_ptr()),
+                      "ls2fm_loss_terms_from_sums")
         ctx.cfg = cfg
         ctx.ws = ws
         ctx.n_rays = n_rays
         ctx.pstruct = pstruct
         ctx.pose_shape = tuple(center.shape)
+        ctx.loss = (fl, dref, sums, None if depth_ref is None else tuple(depth_ref.shape))
         ctx.save_for_backward(c, d, *ps)
-        return rgb, sdfs, normals, depth, nmlp
+        if fl is None:
+            return rgb, sdfs, normals, depth, nmlp
+        return rgb, sdfs, normals, depth, nmlp, terms[:5], terms[5]
 
     @staticmethod
-    def backward(ctx, d_rgb, d_sdfs, d_normals, d_depth, d_nmlp):
+    def backward(ctx, d_rgb, d_sdfs, d_normals, d_depth, d_nmlp, d_terms=None, d_total=None):
         fdesc, g1, g2, dual, beta_speed, _ = ctx.cfg
         lib = _lib.load()
         c, d, *ps = ctx.saved_tensors
 
         def prep(t):
             return None if t is None else t.float().contiguous()
-        d_rgb, d_sdfs, d_normals, d_depth, d_nmlp = map(prep, (d_rgb, d_sdfs, d_normals, d_depth, d_nmlp))
+        d_rgb, d_sdfs, d_normals, d_depth, d_nmlp, d_terms, d_total = map(
+            prep, (d_rgb, d_sdfs, d_normals, d_depth, d_nmlp, d_terms, d_total))
         # every gradient -- both tables (overwritten in full by the slab scatter) and the small tensors -- is a view of ONE
         # flat buffer: a multi-GPU run all-reduces it as a single message without packing kernels (ls2fm.dist)
         flat, grads = flat_gradient_views(ps)
@@ -330,20 +373,36 @@ class _Render(torch.autograd.Function):
         want_pose = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         d_center = torch.empty_like(c) if want_pose else None
         d_ray = torch.empty_like(d) if want_pose else None
+        fl, dref, sums, dref_shape = ctx.loss
+        opts = _lib.RenderOpts()
+        d_dref = None
+        if fl is not None and (d_terms is not None or d_total is not None):
+            if dref is not None and ctx.needs_input_grad[2]:
+                d_dref = torch.empty_like(dref)
+            lspec = _loss_struct(fl, dref, None, sums, d_terms, d_total, d_dref)
+            opts.loss = ctypes.pointer(lspec)
         check(lib.ls2fm_render_bwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), ctx.n_rays, ptr(d_rgb), ptr(d_sdfs),
                                    ptr(d_normals), ptr(d_depth), ptr(d_nmlp), ctypes.byref(gstruct), ptr(d_center), ptr(d_ray),
-                                   ptr(ctx.ws), stream_ptr()), "ls2fm_render_bwd")
+                                   ptr(ctx.ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_bwd")
         if want_pose:
             d_center, d_ray = d_center.view(ctx.pose_shape), d_ray.view(ctx.pose_shape)
-        return (d_center, d_ray, None, *grads)  # ctx.ws is kept: backward may run again (retain_graph)
+        if d_dref is not None:
+            d_dref = d_dref.view(dref_shape)
+        return (d_center, d_ray, d_dref, None, None, None, *grads)  # ctx.ws is kept: backward may run again (retain_graph)
 
 
-def render(renderer, opt, center, ray, sdf_field, rad_field):
-    """Renderer.forward through the fused kernels -> the reference's result dict."""
+def render(renderer, opt, center, ray, sdf_field, rad_field, loss=None, d_points=None):
+    """Renderer.forward through the fused kernels -> the reference's result dict.  With `loss` (a FusedLoss) the loss head
+    runs inside the render and the dict also holds 'loss_terms' ([5]: rgb, eikonal, DC, mse, all) and 'loss_total'."""
     pl = _plan(renderer, opt, sdf_field, rad_field)
-    rgb, sdfs, normals, depth, nmlp = _Render.apply(center, ray, pl.cfg, *pl.ts)
-    return {"rgb": rgb, "sdfs_volume": sdfs, "normals": normals, "depth_mlp": depth, "normal_mlp": nmlp}
+    want_bwd = torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad or any(p.requires_grad for p in pl.ts)
+                                            or (d_points is not None and d_points.requires_grad))
+    out = _Render.apply(center, ray, d_points if loss is not None else None, pl.cfg, loss, want_bwd, *pl.ts)
+    ret = {"rgb": out[0], "sdfs_volume": out[1], "normals": out[2], "depth_mlp": out[3], "normal_mlp": out[4]}
+    if loss is not None:
+        ret["loss_terms"], ret["loss_total"] = out[5], out[6]
+    return ret
 
 
 # ------------------------------------------------------------------------------------------------ sdf eval / tracing

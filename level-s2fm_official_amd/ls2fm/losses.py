@@ -40,7 +40,7 @@ def _mask(m, n_rays):
 
 class _LossHead(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb, normals, depth, depth_ref, rgb_gt, mask_eik, mask_dc, mask_mse, weights, ws):
+    def forward(ctx, rgb, normals, depth, depth_ref, rgb_gt, mask_eik, mask_dc, mask_mse, weights, ws, global_counts):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         _lib.require_device(rgb, normals, depth, depth_ref, rgb_gt, weights)
@@ -55,6 +55,11 @@ class _LossHead(torch.autograd.Function):
                                            _lib.ptr(mask_eik), _lib.ptr(mask_dc), _lib.ptr(mask_mse), n_rays, n_samples,
                                            _lib.ptr(weights), _lib.ptr(terms), _lib.ptr(sums), _lib.ptr(ws), _lib.stream_ptr()),
                    "ls2fm_loss_head_fwd")
+        from . import dist as _dist
+        if _dist.is_distributed():       # sharded rays: the backward must divide by the GLOBAL counts (means over all ranks' rays)
+            _dist.globalize_loss_sums(sums, global_counts)
+            _lib.check(lib.ls2fm_loss_terms_from_sums(_lib.ptr(sums), _lib.ptr(weights), _lib.ptr(terms), _lib.stream_ptr()),
+                       "ls2fm_loss_terms_from_sums")
         ctx.saved = (rgb_c, nrm_c, dep_c, ref_c, gt_c, mask_eik, mask_dc, mask_mse, weights, sums)
         _LAST_SUMS[rgb.device.index] = sums
         ctx.shapes = (rgb.shape, normals.shape, depth.shape, None if depth_ref is None else depth_ref.shape)
@@ -65,7 +70,7 @@ class _LossHead(torch.autograd.Function):
     def backward(ctx, g, g_total):
         lib = _lib.load()
         if g is None and g_total is None:
-            return (None,) * 10
+            return (None,) * 11
         rgb_c, nrm_c, dep_c, ref_c, gt_c, mask_eik, mask_dc, mask_mse, weights, sums = ctx.saved
         n_rays, n_samples = ctx.n
         g = None if g is None else _lib.cf(g)
@@ -78,7 +83,7 @@ class _LossHead(torch.autograd.Function):
                                            _lib.ptr(d_ref), _lib.ptr(sums), _lib.stream_ptr()), "ls2fm_loss_head_bwd")
         s_rgb, s_nrm, s_dep, s_ref = ctx.shapes
         return (d_rgb.view(s_rgb), d_nrm.view(s_nrm), d_dep.view(s_dep), None if d_ref is None else d_ref.view(s_ref),
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class RenderLossHead:
@@ -87,9 +92,10 @@ class RenderLossHead:
     dict with the reference's keys ``rgb_loss, eikonal_loss, DC_loss, mse, all`` (0-dim tensors; ``all`` carries the
     gradient to ``ret['rgb'], ret['normals'], ret['depth_mlp']`` and ``d_points``)."""
 
-    def __init__(self, device, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0):
+    def __init__(self, device, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0, global_counts="allreduce"):
         w = [0.0 if x is None else 10.0 ** float(x) for x in (w_rgb, w_eikonal, w_dc)]
         self.weights = torch.tensor(w, device=device, dtype=torch.float32)
+        self.global_counts = global_counts      # multi-GPU runs: see spec()
 
     def terms(self, ret, rgbs_gt, d_points=None, mask_finish=None, mask_eik=None, mask_bg=None):
         """-> (terms [5] = rgb, eikonal, DC, mse, all ; all as its own 0-dim tensor: backward through it costs no
@@ -98,11 +104,27 @@ class RenderLossHead:
         n_rays = normals.numel() // (3 * normals.shape[-2])
         return _LossHead.apply(ret["rgb"], normals, ret["depth_mlp"], d_points, rgbs_gt, _mask(mask_eik, n_rays),
                                _mask(mask_finish, n_rays), _mask(mask_bg, n_rays), self.weights,
-                               _workspace(normals.device))
+                               _workspace(normals.device), self.global_counts)
 
     def __call__(self, ret, rgbs_gt, **kw):
         t, total = self.terms(ret, rgbs_gt, **kw)
+        return self.as_dict(t, total)
+
+    @staticmethod
+    def as_dict(t, total):
         return {"rgb_loss": t[0], "eikonal_loss": t[1], "DC_loss": t[2], "mse": t[3], "all": total}
+
+    def spec(self, rgbs_gt, mask_finish=None, mask_eik=None, mask_bg=None, n_rays=None, global_counts=None):
+        """the same loss head as a FusedLoss for `Renderer.forward_with_loss` / `ls2fm.fused.render(loss=...)`.
+        global_counts (multi-GPU runs only): "allreduce" = the (sum, count) pairs are all-reduced between forward and backward,
+        every rank sees the global means; "uniform" = no collective: every rank holds the same number of rays and no masks, the
+        counts are scaled by the world size and a rank's terms are its SHARE of the global means (they add up over the ranks)."""
+        from .fused import FusedLoss
+        n_rays = rgbs_gt.numel() // 3 if n_rays is None else n_rays
+        gt = _lib.cf(rgbs_gt.detach()).reshape(-1)
+        _lib.require_device(gt)
+        return FusedLoss(self.weights, gt, _mask(mask_eik, n_rays), _mask(mask_finish, n_rays), _mask(mask_bg, n_rays),
+                         self.global_counts if global_counts is None else global_counts)
 
     @staticmethod
     def sums(device):

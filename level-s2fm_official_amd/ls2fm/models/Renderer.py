@@ -75,6 +75,21 @@ class Renderer(nn.Module):
             return fused.render(self, opt, center, ray, SDF_Field, Rad_Field)
         return self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
 
+    def forward_with_loss(self, opt, center, ray, SDF_Field, Rad_Field, head, rgbs_gt, d_points=None, mask_finish=None,
+                          mask_eik=None, mask_bg=None):
+        """`Renderer.forward` followed by the stage loops' loss head (ls2fm.losses.RenderLossHead: pipelines/Camera.py:
+        515-537, BA.py:206-218) -> (ret, losses).  On the fused path the loss head runs INSIDE the render: partial sums in
+        the forward's last kernel, the upstream of rgb / normals / depth formed in the backward's first -- no loss kernels and
+        no [B,R,N,3] gradient tensor between forward and backward.  Same values and gradients as `head(self.forward(...),
+        rgbs_gt, ...)`, which is what runs when the configuration is served by the composed form."""
+        if fused.can_render(self, opt, center, ray, SDF_Field, Rad_Field):
+            spec = head.spec(rgbs_gt, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg,
+                             n_rays=center.shape[0] * center.shape[1])
+            ret = fused.render(self, opt, center, ray, SDF_Field, Rad_Field, loss=spec, d_points=d_points)
+            return ret, head.as_dict(ret.pop("loss_terms"), ret.pop("loss_total"))
+        ret = self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
+        return ret, head(ret, rgbs_gt, d_points=d_points, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg)
+
     def forward_composed(self, opt, center, ray, SDF_Field, Rad_Field):
         """General autograd composition (pose gradients, arbitrary layer sizes, second-order use)."""
         t, _, _ = self.volsdf_sampling(opt, center, ray, SDF_Field=SDF_Field)
