@@ -172,7 +172,10 @@ def main():
 
     from ls2fm.losses import RenderLossHead
     from ls2fm.graph import CapturedStep
-    head = RenderLossHead(dev, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0)           # same three terms and weights as loss_head()
+    # same three terms and weights as loss_head().  N > 1: every rank holds the same number of rays and no masks, so the global
+    # counts are the local ones times the world size ("uniform": no collective between forward and backward); the summed
+    # (all-reduced) gradients are then those of the global means
+    head = RenderLossHead(dev, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0, global_counts="uniform")
     rgb_gt = torch.full((1, args.rays, 3), 0.5, device=dev)
     depth_ref = torch.zeros(1, args.rays, device=dev)
     one = torch.ones((), device=dev)              # d loss / d loss (what loss.backward() would allocate and fill every step)

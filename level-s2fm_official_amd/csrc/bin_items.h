@@ -113,4 +113,96 @@ inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     return bm;
 }
 
+// ---- scans of the per-(tile, slab) counts, run by EXTRA WORKGROUPS of the shade_fwd launch (no launch, no stream fork: a
+// cross-queue edge on the main chain costs ~10 us in a graph replay).  Job = (level, group of 16 slabs): per-slab totals
+// and, inside a slab, the exclusive prefix of the tile counts; the last job to finish (ticket) turns the (level, slab)
+// totals into absolute starts.  The fill adds the two.  The ticket word is zeroed by the gather pass's launch.
+constexpr int kScanGroup = 16;
+constexpr int kScanJobsPerLevel = kBins / kScanGroup;
+struct ScanJob { BinMeta bm; int n_levels; };          // bm.tile == nullptr: no job
+
+inline int* scan_ticket(const BinMeta& bm) { return reinterpret_cast<int*>(bm.level_bound) + 48; }
+__device__ __forceinline__ int* scan_ticket_dev(const BinMeta& bm) { return reinterpret_cast<int*>(bm.level_bound) + 48; }
+
+__device__ __forceinline__ int wave_scan_incl_i32(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// nt = workgroup size: a multiple of 64, 64 <= nt <= 512
+[[maybe_unused]] __device__ void scan_job_run(const ScanJob& sj, const int job, const int tid, const int nt) {
+    __shared__ int chunk_sum[512 / kScanGroup][kScanGroup];
+    __shared__ int level_total[LS2FM_MAX_LEVELS];
+    __shared__ int s_last;
+    const BinMeta& bm = sj.bm;
+    const int l = job / kScanJobsPerLevel;
+    const int sub = tid % kScanGroup, ch = tid / kScanGroup, n_ch = nt / kScanGroup;
+    const int b = (job % kScanJobsPerLevel) * kScanGroup + sub;
+    const int per = (bm.n_tiles + n_ch - 1) / n_ch;
+    const int t0 = ch * per, t1 = t0 + per < bm.n_tiles ? t0 + per : bm.n_tiles;
+    int* col = bm.tile + (int64_t)l * bm.n_tiles * kBins + b;
+    int sum = 0;
+    for (int t = t0; t < t1; ++t) sum += col[(int64_t)t * kBins];
+    chunk_sum[ch][sub] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int q = 0; q < ch; ++q) run += chunk_sum[q][sub];
+    for (int t = t0; t < t1; ++t) {
+        const int c = col[(int64_t)t * kBins];
+        col[(int64_t)t * kBins] = run;
+        run += c;
+    }
+    if (ch == n_ch - 1) bm.count[l * kBins + b] = run;
+    // ---- ticket: the last job scans the (level, slab) totals
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(scan_ticket_dev(bm), 1) == sj.n_levels * kScanJobsPerLevel - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+    constexpr int kChunks = (kBins + 63) / 64;
+    for (int lv = wave; lv < LS2FM_MAX_LEVELS; lv += n_waves) {
+        int tot = 0;
+        if (lv < sj.n_levels)
+            for (int c = 0; c < kChunks; ++c) {
+                const int bb = 64 * c + lane;
+                tot += bb < kBins ? __builtin_nontemporal_load(&bm.count[lv * kBins + bb]) : 0;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+        if (lane == 0) level_total[lv] = tot;
+    }
+    __syncthreads();
+    for (int lv = wave; lv < sj.n_levels; lv += n_waves) {
+        int before = 0;
+        for (int q = 0; q < lv; ++q) before += level_total[q];
+        int run2 = 0;
+        for (int c = 0; c < kChunks; ++c) {
+            const int bb = 64 * c + lane;
+            const int cnt = bb < kBins ? __builtin_nontemporal_load(&bm.count[lv * kBins + bb]) : 0;
+            const int incl = wave_scan_incl_i32(cnt, lane);
+            if (bb < kBins) bm.start[lv * kBins + bb] = before + run2 + incl - cnt;
+            run2 += __shfl(incl, 63, 64);
+        }
+    }
+    if (tid == 0) *scan_ticket_dev(bm) = 0;
+}
+
+// ---- zero fills the backward needs, run by EXTRA WORKGROUPS of the shade_bwd launch: the weight-gradient accumulators and
+// the point-split coarse levels of the gradient table(s)
+struct ZeroJob { float4* a; int64_t na; float4* b; int64_t nb; float4* c; int64_t nc; int blocks; };
+
+__device__ __forceinline__ void zero_job_run(const ZeroJob& z, const int job, const int tid, const int nt) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t stride = (int64_t)z.blocks * nt;
+    for (int64_t i = (int64_t)job * nt + tid; i < z.na; i += stride) z.a[i] = zero;
+    for (int64_t i = (int64_t)job * nt + tid; i < z.nb; i += stride) z.b[i] = zero;
+    for (int64_t i = (int64_t)job * nt + tid; i < z.nc; i += stride) z.c[i] = zero;
+}
+
 }  // namespace

@@ -15,8 +15,8 @@
 //                  level): which slab does each of the four (y,z) corner pairs fall into (the two x-corners of a pair
 //                  share a slab except when cx+1 carries across the slab bit or a dense row ends -- then the pair is
 //                  split into two half items; bin_items.h)
-//   scatter_scan   per-(tile, slab) counts -> absolute offsets (two small kernels; no global atomics in any pass: 1 M of
-//                  them per pass cost ~50 us, and the item order is now deterministic)
+//   scan           (leading workgroups of the shade_fwd launch, bin_items.h) per-(tile, slab) counts -> absolute offsets;
+//                  no global atomics in any pass (1 M of them per pass cost ~50 us), and the item order is deterministic
 //   scatter_fill   same classification, now with shade_bwd's records (read once, coalesced): builds the 32-byte payload
 //                  {local idx0 | idx1, wx, A0 A1 B0 B1 (SDF grid), C0 C1 (second grid)} of every item, sorts the workgroup's
 //                  items by slab in LDS and writes each (workgroup, slab) run with full cache lines
@@ -43,68 +43,6 @@ __device__ __forceinline__ void point_position(const FieldC& fc, const float* __
     const RayGeom gm = load_ray(fc, center, ray, r);
     float p[3];
     sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
-}
-
-// ------------------------------------------------------------------------------------------------ scan
-__device__ __forceinline__ int wave_scan_incl_int(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
-// Offsets.  Pass 1 (workgroup = level, thread = (slab, chunk of tiles)): per-slab totals and, inside a slab, the
-// exclusive prefix of the tile counts.  Pass 2 (one workgroup): exclusive prefix of the (level, slab) totals into absolute
-// starts.  The fill adds the two.
-constexpr int kScanChunks = 8;
-__global__ void __launch_bounds__(kBins * kScanChunks)
-scatter_scan_tiles_kernel(BinMeta bm) {
-    __shared__ int chunk_sum[kScanChunks][kBins];
-    const int b = threadIdx.x % kBins, ch = threadIdx.x / kBins, l = blockIdx.x;
-    const int per = (bm.n_tiles + kScanChunks - 1) / kScanChunks;
-    const int t0 = ch * per, t1 = t0 + per < bm.n_tiles ? t0 + per : bm.n_tiles;
-    int* col = bm.tile + (int64_t)l * bm.n_tiles * kBins + b;
-    int sum = 0;
-    for (int t = t0; t < t1; ++t) sum += col[(int64_t)t * kBins];
-    chunk_sum[ch][b] = sum;
-    __syncthreads();
-    int run = 0;
-    for (int q = 0; q < ch; ++q) run += chunk_sum[q][b];
-    for (int t = t0; t < t1; ++t) {
-        const int c = col[(int64_t)t * kBins];
-        col[(int64_t)t * kBins] = run;
-        run += c;
-    }
-    if (ch == kScanChunks - 1) bm.count[l * kBins + b] = run;
-}
-
-__global__ void __launch_bounds__(64 * LS2FM_MAX_LEVELS)
-scatter_scan_kernel(int n_levels, BinMeta bm) {
-    __shared__ int level_total[LS2FM_MAX_LEVELS];
-    constexpr int kChunks = (kBins + 63) / 64;
-    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const bool on = l < n_levels;
-    int excl[kChunks], run = 0;
-#pragma unroll
-    for (int c = 0; c < kChunks; ++c) {
-        const int b = 64 * c + lane;
-        const int cnt = (on && b < kBins) ? bm.count[l * kBins + b] : 0;
-        const int incl = wave_scan_incl_int(cnt, lane);
-        excl[c] = run + incl - cnt;
-        run += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) level_total[l] = run;
-    __syncthreads();
-    if (!on) return;
-    int before = 0;
-    for (int q = 0; q < l; ++q) before += level_total[q];
-#pragma unroll
-    for (int c = 0; c < kChunks; ++c) {
-        const int b = 64 * c + lane;
-        if (b < kBins) bm.start[l * kBins + b] = before + excl[c];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ fill
@@ -154,7 +92,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         for (int c = 0; c < (kBins + 63) / 64; ++c) {
             const int b = 64 * c + lane;
             const int cnt = b < kBins ? hist[b] : 0;
-            const int incl = wave_scan_incl_int(cnt, lane);
+            const int incl = wave_scan_incl_i32(cnt, lane);
             if (b < kBins) lds_off[b] = run + incl - cnt;
             run += __shfl(incl, 63, 64);
         }
@@ -352,14 +290,6 @@ size_t ls2fm_bin_counts_bytes() { return 0; }      // nothing to zero: every cou
 
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual) { return levels_fit(grid, ls2fm_slab_shift(dual)); }
 
-// per-(tile, slab) item counts (written by the forward's gather pass, render_fwd.hip) -> absolute offsets of every run
-int ls2fm_launch_bin_scan(const ls2fm_grid_desc* grid, int64_t n_points, float* bins_ws, hipStream_t stream) {
-    const BinMeta bm = make_bin_meta(bins_ws, n_points);
-    scatter_scan_tiles_kernel<<<grid->n_levels, kBins * kScanChunks, 0, stream>>>(bm);
-    scatter_scan_kernel<<<1, 64 * LS2FM_MAX_LEVELS, 0, stream>>>(grid->n_levels, bm);
-    return ls2fm_launch_status();
-}
-
 // payloads from shade_bwd's records, sorted by slab
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
@@ -375,13 +305,6 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
 }
 
 namespace {
-// one launch for both tables (a hipMemsetAsync per table and range is several launches on the critical path)
-__global__ void __launch_bounds__(256)
-zero_ranges_kernel(float4* __restrict__ a, float4* __restrict__ b, int64_t n4) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) (blockIdx.y ? b : a)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 struct HostPlan { SlabPlan plan; int total, zero_lo, zero_hi; };
 
 HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift) {
@@ -414,17 +337,14 @@ HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift) {
 }
 }  // namespace
 
-// the point-split coarse levels are flushed with float atomics: their range of the gradient table(s) is zeroed first --
-// one small kernel, enqueued at the start of the backward
-int ls2fm_launch_scatter_zero(const ls2fm_grid_desc* grid, int64_t n_points, float* dtable1, float* dtable2, hipStream_t stream) {
-    const bool dual = dtable2 != nullptr;
+// the point-split coarse levels are flushed with float atomics: their range of the gradient table(s) is zeroed first (by
+// leading workgroups of the shade_bwd launch)
+void ls2fm_scatter_zero_range(const ls2fm_grid_desc* grid, int64_t n_points, bool dual, int64_t* first, int64_t* count) {
     const HostPlan h = make_plan(grid, n_points, ls2fm_slab_shift(dual ? 1 : 0));
-    if (h.zero_lo < 0) return LS2FM_OK;      // levels in between that have a sole owner are overwritten afterwards anyway
-    const size_t first = grid->offset[h.zero_lo], last = (size_t)grid->offset[h.zero_hi] + grid->size[h.zero_hi];
-    const int64_t n4 = (int64_t)(last - first) / 2;          // float4s per table (level offsets are multiples of 8 entries)
-    zero_ranges_kernel<<<dim3((unsigned)((n4 + 255) / 256), dual ? 2 : 1), 256, 0, stream>>>(
-        reinterpret_cast<float4*>(dtable1 + 2ull * first), dual ? reinterpret_cast<float4*>(dtable2 + 2ull * first) : nullptr, n4);
-    return ls2fm_launch_status();
+    *first = 0; *count = 0;
+    if (h.zero_lo < 0) return;               // levels in between that have a sole owner are overwritten afterwards anyway
+    *first = grid->offset[h.zero_lo];
+    *count = (int64_t)grid->offset[h.zero_hi] + grid->size[h.zero_hi] - *first;
 }
 
 #ifdef LS2FM_STAMPS

@@ -170,7 +170,6 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
                                  hipStream_t stream);
-int ls2fm_launch_scatter_zero(const ls2fm_grid_desc* grid, int64_t n_points, float* dtable1, float* dtable2, hipStream_t stream);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -203,26 +202,18 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
-    // fork 1: zero fills off the main chain.  (The per-slab item offsets of the scatter were built by the forward:
-    // counted inside its gather pass, scanned beside shade_fwd.)
     SideCtx sc;
-    bool forked = ls2fm_side_stream(&sc, s);
-    if (forked) forked = hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
-    hipStream_t gs = forked ? sc.side : s;
-    int status = LS2FM_OK;
-    // the reduced-weight-gradient accumulators (consumed by the wgrad kernels, which run on the side stream later) ...
-    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), gs) != hipSuccess) status = LS2FM_ERR_LAUNCH;
-    // ... and the point-split coarse levels of the gradient table(s) (one small launch; only slab_accumulate needs it)
-    if (status == LS2FM_OK) status = ls2fm_launch_scatter_zero(sdf_grid, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, gs);
-    if (forked && hipEventRecord(sc.mid, sc.side) != hipSuccess) status = LS2FM_ERR_LAUNCH;
-    if (status != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, status);
+    bool forked = false;
+    LS2FM_CHECK_ARG(((reinterpret_cast<uintptr_t>(grads->sdf_table) | (dual ? reinterpret_cast<uintptr_t>(grads->rad_table) : 0)) & 15u) == 0);
 
     Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp, LossUp{}};
     if (loss)
         up.loss = LossUp{loss->rgb_gt, loss->depth_ref, loss->mask_eik, loss->mask_dc, loss->mask_mse, loss->weights, loss->sums,
                          loss->d_terms, loss->d_total, loss->d_depth_ref};
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, s);
+    // (leading workgroups of this launch zero the weight-gradient accumulators and the atomically flushed table ranges)
+    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,
+                           dual ? grads->rad_table : nullptr, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
     if (want_pose) {
         ls2fm_prof_begin(LS2FM_PROF_POSE, s);
@@ -230,9 +221,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         ls2fm_prof_end(LS2FM_PROF_POSE, s);
     }
 
-    // fork 2: weight-gradient GEMM -> reduce -> finalize run on the side stream, concurrently with the table scatters
-    if (forked && (hipEventRecord(sc.fork, s) != hipSuccess || hipStreamWaitEvent(sc.side, sc.fork, 0) != hipSuccess))
-        return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
+    // the one fork of the backward: weight-gradient GEMMs -> reduce -> finalize run on the side stream, beside the table scatters
+    forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+    hipStream_t gs = forked ? sc.side : s;
     ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     finalize_kernel<<<7, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
@@ -241,7 +232,6 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
 
     // hash-table gradients: LDS-owned slabs walking their binned item lists (bin_scatter.hip); tables overwritten in full
-    if (forked && hipStreamWaitEvent(s, sc.mid, 0) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);   // zero fills done
     {
         // payloads sorted by slab, then one streaming pass per slab; dual field: both grids share geometry, hence items
         ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);

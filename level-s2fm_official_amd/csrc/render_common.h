@@ -306,10 +306,14 @@ __device__ __forceinline__ float ls2fm_smooth_l1(float d) { const float a = fabs
 __device__ __forceinline__ float ls2fm_smooth_l1_grad(float d) { return fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f); }
 __device__ __forceinline__ float ls2fm_sign(float d) { return d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f); }
 
+// bin_scatter.hip: the entry range [first, first + count) of the gradient table(s) that slab_accumulate flushes with atomics
+void ls2fm_scatter_zero_range(const ls2fm_grid_desc* grid, int64_t n_points, bool dual, int64_t* first, int64_t* count);
+
 // shade_bwd.hip
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
-                           const Upstream& up, int want_pose, hipStream_t s);
+                           const Upstream& up, int want_pose, const ls2fm_grid_desc* zero_grid, float* dtable1, float* dtable2,
+                           hipStream_t s);
 
 // pose_grad.hip
 int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, const ls2fm_grid_desc* rad_grid, int dual,
@@ -323,4 +327,5 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
                            int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
-                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, hipStream_t s);
+                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, const ls2fm_grid_desc* scan_grid,
+                           hipStream_t s);

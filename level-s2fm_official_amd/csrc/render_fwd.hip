@@ -223,6 +223,7 @@ struct EncodeExtras {
     int in_dim, in_dim2, rad_in, dual;
     Packed* packed;           // null: no prep in this launch
     int* tile_counts;         // [L][n_tiles][kBins] or null: no counting
+    int* scan_ticket;
     int n_tiles, sshift;
 };
 
@@ -230,19 +231,21 @@ constexpr int kEncThreads = kFillTile;       // 512: one workgroup = one (level,
 constexpr int kEncReserved = 8;              // leading workgroups (a multiple of 8: block -> XCD mapping stays b % 8)
 
 // position of sample i, its cell on the level, the 8 corner entries (absolute) and fractions
+struct LevelOne { float scale; uint32_t res, size, offset, hashed; };      // one level's constants (scalar registers)
+
 __device__ __forceinline__ void locate_sample(const FieldC& fc, const float* __restrict__ center, const float* __restrict__ ray,
-                                              int64_t i, const LevelSet& lv, int l, uint32_t g[3], Cell& c) {
+                                              int64_t i, const LevelOne& lv, uint32_t g[3], Cell& c) {
     const int64_t r = i / fc.n_samples;
     const int n = (int)(i - r * fc.n_samples);
     const RayGeom gm = load_ray(fc, center, ray, r);
     float p[3], x[3];
     sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) pos_fract(x[d], lv.scale[l], g[d], c.w[d]);
+    for (int d = 0; d < 3; ++d) pos_fract(x[d], lv.scale, g[d], c.w[d]);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-        c.idx[k] = lv.offset[l] + corner_index(g[0] + (k & 1), g[1] + ((k >> 1) & 1), g[2] + ((k >> 2) & 1), lv.res[l],
-                                               lv.size[l], lv.hashed[l]);
+        c.idx[k] = lv.offset + corner_index(g[0] + (k & 1), g[1] + ((k >> 1) & 1), g[2] + ((k >> 2) & 1), lv.res, lv.size,
+                                            lv.hashed);
 }
 
 // INTERLEAVED: dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner
@@ -258,6 +261,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     if (blockIdx.x < kEncReserved) {
         if (ex.packed && blockIdx.x < 3)
             prep_weights_task(ex.params, ex.in_dim, ex.in_dim2, ex.rad_in, ex.dual, 1, ex.packed, (int)blockIdx.x, tid, kEncThreads);
+        if (blockIdx.x == 3 && tid == 0 && ex.scan_ticket) *ex.scan_ticket = 0;      // armed for the scans in the shade_fwd launch
         return;
     }
     const int bx = (int)blockIdx.x - kEncReserved;
@@ -268,7 +272,14 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     const int chunk = unit % n_chunks;
     const bool second = !INTERLEAVED && pl >= lv1.n_levels;
     const int l = second ? pl - lv1.n_levels : pl;
-    const LevelSet& lv = second ? lv2 : lv1;
+    // the level's constants straight from the kernel-argument segment (a reference selecting between the two structs makes
+    // the compiler copy both to scratch: 652 bytes per lane and an 8x slower kernel)
+    LevelOne lv;
+    lv.scale = second ? lv2.scale[l] : lv1.scale[l];
+    lv.res = second ? lv2.res[l] : lv1.res[l];
+    lv.size = second ? lv2.size[l] : lv1.size[l];
+    lv.offset = second ? lv2.offset[l] : lv1.offset[l];
+    lv.hashed = second ? lv2.hashed[l] : lv1.hashed[l];
     const bool counting = ex.tile_counts != nullptr && !second;          // workgroup-uniform
     if (counting) {
         for (int b = tid; b < kBins; b += kEncThreads) hist[b] = 0;
@@ -281,7 +292,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     if (i < n_points) {
         uint32_t g[3];
         Cell c;
-        locate_sample(fc, center, ray, i, lv, l, g, c);
+        locate_sample(fc, center, ray, i, lv, g, c);
         if (INTERLEAVED) {
             const float4* __restrict__ table = reinterpret_cast<const float4*>(table1);
             float4 v[8];
@@ -309,8 +320,8 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                     g0 = fmaf(dw, v[k].x, g0);
                     g1 = fmaf(dw, v[k].y, g1);
                 }
-                __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-                __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+                __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+                __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
             }
         } else {
             const float* __restrict__ table = second ? table2 : table1;
@@ -337,14 +348,20 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                         g0 = fmaf(dw, v[k].x, g0);
                         g1 = fmaf(dw, v[k].y, g1);
                     }
-                    __builtin_nontemporal_store(lv.scale[l] * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-                    __builtin_nontemporal_store(lv.scale[l] * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+                    __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
+                    __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
                 }
             }
         }
-        if (counting) {        // the classification of scatter_fill, on the same cell
-            const LevelC L = make_level_c(lv, l, ex.sshift);
-            for_each_item(L, g, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
+        if (counting) {        // the classification of scatter_fill (for_each_item, bin_items.h) from the corner entries
+                               // already at hand: pair c = (by, bz) -> x-corners k = 2 by + 4 bz and k + 1
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+                const uint32_t i0 = c.idx[2 * cp] - lv.offset, i1 = c.idx[2 * cp + 1] - lv.offset;
+                const uint32_t s0 = i0 >> ex.sshift, s1 = i1 >> ex.sshift;
+                atomicAdd(&hist[s0], 1);
+                if (s1 != s0) atomicAdd(&hist[s1], 1);       // split pair: two half items
+            }
         }
     }
     if (counting) {
@@ -467,7 +484,6 @@ extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, c
 }
 
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
-int ls2fm_launch_bin_scan(const ls2fm_grid_desc* grid, int64_t n_points, float* bins_ws, hipStream_t stream);
 int ls2fm_launch_loss_reduce(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples, hipStream_t stream);
 
 extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
@@ -505,10 +521,11 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ex.params = *params;
     ex.in_dim = 3 + 2 * L1; ex.in_dim2 = 3 + 2 * L2; ex.rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1); ex.dual = dual;
     ex.packed = pk;
-    ex.tile_counts = nullptr; ex.n_tiles = 0; ex.sshift = ls2fm_slab_shift(dual);
+    ex.tile_counts = nullptr; ex.scan_ticket = nullptr; ex.n_tiles = 0; ex.sshift = ls2fm_slab_shift(dual);
     if (prepare_bwd) {
         const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
         ex.tile_counts = bm.tile;
+        ex.scan_ticket = scan_ticket(bm);
         ex.n_tiles = bm.n_tiles;
     }
     const unsigned enc_blocks = (unsigned)(kEncReserved + 8 * most);
@@ -523,29 +540,16 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
             pair ? params->rad_table : nullptr, w.p, w.p_pad, n_chunks, plan, ws + w.e1, pair ? ws + w.e2 : nullptr, ws + w.j1, ex);
     ls2fm_prof_end(enc_span, s);
 
-    // ---- fork: the scans of the item counts (15 us, two small launches) run beside shade_fwd
-    SideCtx sc;
-    bool forked = false;
-    if (prepare_bwd) {
-        forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess &&
-                 hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
-        hipStream_t bs = forked ? sc.side : s;
-        ls2fm_prof_begin(LS2FM_PROF_BIN, bs);
-        int st = ls2fm_launch_bin_scan(sdf_grid, w.p, ws + w.bins, bs);
-        ls2fm_prof_end(LS2FM_PROF_BIN, bs);
-        if (st == LS2FM_OK && forked && hipEventRecord(sc.join, sc.side) != hipSuccess) st = LS2FM_ERR_LAUNCH;
-        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
-    }
+    // ---- shading; its leading workgroups scan the item counts (no launch, no fork: the main chain stays on one queue)
     ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
     ls2fm_launch_shade_fwd(fc, dual, 2 * L1, 2 * L2, pk, center, ray, n_rays, w, ws, rgb, sdfs_volume, normals, depth_mlp,
-                           normal_mlp, loss, s);
+                           normal_mlp, loss, prepare_bwd ? sdf_grid : nullptr, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_FWD, s);
     if (loss) {
         ls2fm_prof_begin(LS2FM_PROF_LOSS_FWD, s);
         const int st = ls2fm_launch_loss_reduce(loss, ws + w.lpart, n_rays, field->n_samples, s);
         ls2fm_prof_end(LS2FM_PROF_LOSS_FWD, s);
-        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+        if (st != LS2FM_OK) return st;
     }
-    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();
 }

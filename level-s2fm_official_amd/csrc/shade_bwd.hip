@@ -13,7 +13,7 @@
 //      Only the small per-sample upstream vectors (v, gf, gf2, dz, p) are stored for the weight-gradient kernels
 //      (wgrad_mlp.hip re-derives the hidden-layer operands instead of reading them back from HBM).
 // MFMA-ordered weights are staged into LDS once per workgroup.  fp32 MFMA: exact fp32 products / sums.
-#include "render_common.h"
+#include "bin_items.h"
 
 namespace {
 
@@ -29,14 +29,20 @@ template <bool DUAL, int MAXT>
 __global__ void __launch_bounds__(MAXT, 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
-                 Upstream up, float* __restrict__ out, int want_pose) {
+                 Upstream up, float* __restrict__ out, int want_pose, ZeroJob zero) {
+    // leading workgroups: the zero fills the rest of the backward needs (weight-gradient accumulators, point-split coarse
+    // levels of the gradient tables) -- no memset / kernel launches and no cross-stream edge in front of the scatter
+    if ((int)blockIdx.x < zero.blocks) {
+        zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+        return;
+    }
     __shared__ float s_part[MAXT / 64][8];
     __shared__ double s_db[MAXT / 64];
     __shared__ int s_bound[32];                  // per-level max of a single scatter contribution (bits of a float >= 0)
     __shared__ float s_y[MAXT][8];               // per sample: dz(3), g_n(3), g_sdf
     __shared__ float s_w[kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB)
     const int N = fc.n_samples;
-    const int64_t r = blockIdx.x;
+    const int64_t r = (int64_t)blockIdx.x - zero.blocks;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
     const int jl = lane & 15, g = lane >> 4;
     const int64_t P = w.p_pad;
@@ -528,10 +534,22 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
-                           const Upstream& up, int want_pose, hipStream_t s) {
+                           const Upstream& up, int want_pose, const ls2fm_grid_desc* zero_grid, float* dtable1, float* dtable2,
+                           hipStream_t s) {
     const int threads = (fc.n_samples + 63) / 64 * 64;
+    ZeroJob zero{};
+    zero.blocks = 64;
+    zero.a = reinterpret_cast<float4*>(ws + w.wg);                       // w.wg .. w.dbeta: multiples of 64 floats
+    zero.na = (w.dbeta - w.wg) / 4;
+    int64_t first = 0, count = 0;
+    ls2fm_scatter_zero_range(zero_grid, w.p, dtable2 != nullptr, &first, &count);      // entries (level offsets: multiples of 8)
+    if (count > 0) {
+        zero.b = reinterpret_cast<float4*>(dtable1 + 2 * first);
+        zero.nb = count / 2;
+        if (dtable2) { zero.c = reinterpret_cast<float4*>(dtable2 + 2 * first); zero.nc = count / 2; }
+    }
 #define LS2FM_SHADE_BWD(DUAL, MAXT) \
-    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, want_pose)
+    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)(n_rays + zero.blocks), threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, want_pose, zero)
     if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """print the kernel timeline of the last full step in a rocprofv3 (rocpd sqlite) kernel trace:
-   start offset, duration, queue/stream and name of every dispatch between two consecutive prep_weights launches"""
+   start offset, duration, queue/stream and name of every dispatch between two consecutive gather-pass launches"""
 import glob, sqlite3, sys
 db = glob.glob(sys.argv[1] + '/*/*.db')[0]
 con = sqlite3.connect(db)
@@ -11,7 +11,7 @@ ks = [t for t in tables if t.startswith('rocpd_info_kernel_symbol')][0]
 cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
 q = f"select d.start, d.end, d.queue_id, d.stream_id, s.kernel_name from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"
 rows = list(cur.execute(q))
-marks = [i for i, r in enumerate(rows) if 'prep_weights' in r[4]]
+marks = [i for i, r in enumerate(rows) if 'ray_encode' in r[4]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 3
 a, b = marks[k], marks[k + 1]
 t0 = rows[a][0]
