@@ -133,37 +133,61 @@ __device__ __forceinline__ int wave_scan_incl_i32(int v, int lane) {
     return v;
 }
 
-// nt = workgroup size: a multiple of 64, 64 <= nt <= 512
-[[maybe_unused]] __device__ void scan_job_run(const ScanJob& sj, const int job, const int tid, const int nt) {
-    __shared__ int chunk_sum[512 / kScanGroup][kScanGroup];
-    __shared__ int level_total[LS2FM_MAX_LEVELS];
-    __shared__ int s_last;
+// nt = workgroup size: a multiple of 64, 64 <= nt <= 512.  The job's [n_tiles][16] block of counts goes through LDS in
+// pieces of 256 tiles (coalesced, independent loads in flight together: a thread walking its column in global memory pays one
+// dependent ~1 us access per tile, 20+ us per job -- and these jobs share a launch with shade_fwd).
+constexpr int kScanTiles = 256;
+constexpr int kScanArenaInts = kScanTiles * kScanGroup + (512 / kScanGroup) * kScanGroup + LS2FM_MAX_LEVELS + 1;
+// `arena`: kScanArenaInts ints of the caller's LDS (the host kernel lends one of its own arrays: its LDS budget decides how
+// many of its workgroups fit a CU)
+[[maybe_unused]] __device__ void scan_job_run(const ScanJob& sj, const int job, const int tid, const int nt, int* arena) {
+    int* stage = arena;
+    int (*chunk_sum)[kScanGroup] = reinterpret_cast<int (*)[kScanGroup]>(arena + kScanTiles * kScanGroup);
+    int* level_total = arena + kScanTiles * kScanGroup + (512 / kScanGroup) * kScanGroup;
+    int& s_last = level_total[LS2FM_MAX_LEVELS];
     const BinMeta& bm = sj.bm;
     const int l = job / kScanJobsPerLevel;
     const int sub = tid % kScanGroup, ch = tid / kScanGroup, n_ch = nt / kScanGroup;
-    const int b = (job % kScanJobsPerLevel) * kScanGroup + sub;
-    const int per = (bm.n_tiles + n_ch - 1) / n_ch;
-    const int t0 = ch * per, t1 = t0 + per < bm.n_tiles ? t0 + per : bm.n_tiles;
-    int* col = bm.tile + (int64_t)l * bm.n_tiles * kBins + b;
-    int sum = 0;
-    for (int t = t0; t < t1; ++t) sum += col[(int64_t)t * kBins];
-    chunk_sum[ch][sub] = sum;
-    __syncthreads();
-    int run = 0;
-    for (int q = 0; q < ch; ++q) run += chunk_sum[q][sub];
-    for (int t = t0; t < t1; ++t) {
-        const int c = col[(int64_t)t * kBins];
-        col[(int64_t)t * kBins] = run;
-        run += c;
+    const int b0 = (job % kScanJobsPerLevel) * kScanGroup;
+    int* blk = bm.tile + (int64_t)l * bm.n_tiles * kBins + b0;       // element (t, s) at blk[t * kBins + s]
+    int carry = 0;                                                  // column `sub`: items of the tiles before this piece
+    for (int base = 0; base < bm.n_tiles; base += kScanTiles) {
+        const int nt_here = bm.n_tiles - base < kScanTiles ? bm.n_tiles - base : kScanTiles;
+        for (int e = tid; e < nt_here * kScanGroup; e += nt)
+            stage[e] = blk[(int64_t)(base + e / kScanGroup) * kBins + e % kScanGroup];
+        __syncthreads();
+        const int per = (nt_here + n_ch - 1) / n_ch;
+        const int t0 = ch * per, t1 = t0 + per < nt_here ? t0 + per : nt_here;
+        int sum = 0;
+        for (int t = t0; t < t1; ++t) sum += stage[t * kScanGroup + sub];
+        chunk_sum[ch][sub] = sum;
+        __syncthreads();
+        int run = carry, total = carry;
+        for (int q = 0; q < n_ch; ++q) {
+            const int v = chunk_sum[q][sub];
+            if (q < ch) run += v;
+            total += v;
+        }
+        for (int t = t0; t < t1; ++t) {
+            const int c = stage[t * kScanGroup + sub];
+            stage[t * kScanGroup + sub] = run;
+            run += c;
+        }
+        carry = total;
+        __syncthreads();
+        for (int e = tid; e < nt_here * kScanGroup; e += nt)
+            blk[(int64_t)(base + e / kScanGroup) * kBins + e % kScanGroup] = stage[e];
+        __syncthreads();
     }
-    if (ch == n_ch - 1) bm.count[l * kBins + b] = run;
-    // ---- ticket: the last job scans the (level, slab) totals
-    __threadfence();
+    // ---- hand-off of the per-slab totals to the last job: write-through (sc1) stores, drained, then the ticket; the reader
+    // uses sc1 loads.  (Two __threadfence() per job -- L2 write-back + invalidate, several us each with 4 jobs per CU --
+    // made this launch 27 us; only these 16 words per job cross workgroups, everything else is read by a later kernel.)
+    if (ch == 0) __hip_atomic_store(&bm.count[l * kBins + b0 + sub], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) s_last = atomicAdd(scan_ticket_dev(bm), 1) == sj.n_levels * kScanJobsPerLevel - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
     constexpr int kChunks = (kBins + 63) / 64;
     for (int lv = wave; lv < LS2FM_MAX_LEVELS; lv += n_waves) {
@@ -171,7 +195,7 @@ __device__ __forceinline__ int wave_scan_incl_i32(int v, int lane) {
         if (lv < sj.n_levels)
             for (int c = 0; c < kChunks; ++c) {
                 const int bb = 64 * c + lane;
-                tot += bb < kBins ? __builtin_nontemporal_load(&bm.count[lv * kBins + bb]) : 0;
+                tot += bb < kBins ? __hip_atomic_load(&bm.count[lv * kBins + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
@@ -184,7 +208,7 @@ __device__ __forceinline__ int wave_scan_incl_i32(int v, int lane) {
         int run2 = 0;
         for (int c = 0; c < kChunks; ++c) {
             const int bb = 64 * c + lane;
-            const int cnt = bb < kBins ? __builtin_nontemporal_load(&bm.count[lv * kBins + bb]) : 0;
+            const int cnt = bb < kBins ? __hip_atomic_load(&bm.count[lv * kBins + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             const int incl = wave_scan_incl_i32(cnt, lane);
             if (bb < kBins) bm.start[lv * kBins + bb] = before + run2 + incl - cnt;
             run2 += __shfl(incl, 63, 64);

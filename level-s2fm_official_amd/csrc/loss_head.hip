@@ -5,7 +5,7 @@
 // the fused forward and the fused backward; here it is one kernel each way.
 //
 // Deterministic: every workgroup writes fp64 partial sums, the last one to finish (ticket) adds them in index order.
-#include "render_common.h"
+#include "bin_items.h"
 
 namespace {
 
@@ -151,16 +151,26 @@ loss_head_bwd_kernel(LossIn in, const float* __restrict__ weights, const double*
     }
 }
 
-// fused form (ls2fm_render_opts.loss): shade_fwd left four partial sums per ray; one workgroup adds them in fixed order in
-// fp64, derives the counts from the masks and finishes the terms.  lpart [4][r_pad]
-__global__ void __launch_bounds__(1024)
-loss_reduce_kernel(ls2fm_loss_spec loss, const float* __restrict__ lpart, int64_t n_rays, int64_t r_pad, int n_samples) {
-    __shared__ double red[16][kSums];
+// The launch after shade_fwd: workgroup 0 finishes the fused loss head (ls2fm_render_opts.loss) -- shade_fwd left four partial
+// sums per ray (lpart [4][r_pad]); they are added in fixed order in fp64, the counts come from the masks -- and the other
+// workgroups scan the item counts of the backward's scatter (bin_items.h).  (Inside the shade_fwd launch those 128 short
+// jobs cost 27 us: its 1024 ray workgroups fill the chip's 1024 slots exactly once, anything extra starts a second round.)
+constexpr int kPostThreads = 512;
+__global__ void __launch_bounds__(kPostThreads)
+post_shade_kernel(ls2fm_loss_spec loss, const float* __restrict__ lpart, int64_t n_rays, int64_t r_pad, int n_samples, ScanJob scan) {
+    __shared__ int arena[kScanArenaInts];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x > 0) {
+        scan_job_run(scan, (int)blockIdx.x - 1, tid, kPostThreads, arena);
+        return;
+    }
+    if (loss.rgb_gt == nullptr) return;
+    double (*red)[kSums] = reinterpret_cast<double (*)[kSums]>(arena);         // [kPostThreads / 64][kSums]
+    static_assert(sizeof(double) * (kPostThreads / 64) * kSums <= sizeof(int) * kScanArenaInts, "reduction buffer fits");
     double s[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) s[k] = 0.0;
-    for (int64_t r = tid; r < n_rays; r += 1024) {
+    for (int64_t r = tid; r < n_rays; r += kPostThreads) {
         s[0] += (double)lpart[0 * r_pad + r];
         s[1] += 3.0;
         if (loss.mask_eik == nullptr || loss.mask_eik[r]) { s[2] += (double)lpart[1 * r_pad + r]; s[3] += (double)n_samples; }
@@ -177,7 +187,7 @@ loss_reduce_kernel(ls2fm_loss_spec loss, const float* __restrict__ lpart, int64_
     __syncthreads();
     if (tid < kSums) {
         double v = 0.0;
-        for (int q = 0; q < 16; ++q) v += red[q][tid];
+        for (int q = 0; q < kPostThreads / 64; ++q) v += red[q][tid];
         red[0][tid] = v;
     }
     __syncthreads();
@@ -192,8 +202,20 @@ __global__ void terms_from_sums_kernel(const double* __restrict__ sums, const fl
 
 }  // namespace
 
-int ls2fm_launch_loss_reduce(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples, hipStream_t stream) {
-    loss_reduce_kernel<<<1, 1024, 0, stream>>>(*loss, ray_part, n_rays, (n_rays + 63) / 64 * 64, n_samples);
+// loss: null = no fused loss head; scan_grid: null = no backward follows (nothing to scan)
+int ls2fm_launch_post_shade(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples,
+                            const ls2fm_grid_desc* scan_grid, int64_t n_points, float* bins_ws, hipStream_t stream) {
+    if (!loss && !scan_grid) return LS2FM_OK;
+    ls2fm_loss_spec ls{};
+    if (loss) ls = *loss;
+    ScanJob scan{};
+    int blocks = 1;
+    if (scan_grid) {
+        scan.bm = make_bin_meta(bins_ws, n_points);
+        scan.n_levels = scan_grid->n_levels;
+        blocks += scan_grid->n_levels * kScanJobsPerLevel;
+    }
+    post_shade_kernel<<<blocks, kPostThreads, 0, stream>>>(ls, ray_part, n_rays, (n_rays + 63) / 64 * 64, n_samples, scan);
     return ls2fm_launch_status();
 }
 

@@ -327,5 +327,4 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
                            int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
-                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, const ls2fm_grid_desc* scan_grid,
-                           hipStream_t s);
+                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, hipStream_t s);

@@ -484,7 +484,8 @@ extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, c
 }
 
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
-int ls2fm_launch_loss_reduce(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples, hipStream_t stream);
+int ls2fm_launch_post_shade(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples,
+                            const ls2fm_grid_desc* scan_grid, int64_t n_points, float* bins_ws, hipStream_t stream);
 
 extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -540,16 +541,16 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
             pair ? params->rad_table : nullptr, w.p, w.p_pad, n_chunks, plan, ws + w.e1, pair ? ws + w.e2 : nullptr, ws + w.j1, ex);
     ls2fm_prof_end(enc_span, s);
 
-    // ---- shading; its leading workgroups scan the item counts (no launch, no fork: the main chain stays on one queue)
+    // ---- shading, then ONE small launch: the fused loss head's reduction and the scans of the item counts side by side (no
+    // stream fork anywhere in the forward: the main chain stays on one queue)
     ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
     ls2fm_launch_shade_fwd(fc, dual, 2 * L1, 2 * L2, pk, center, ray, n_rays, w, ws, rgb, sdfs_volume, normals, depth_mlp,
-                           normal_mlp, loss, prepare_bwd ? sdf_grid : nullptr, s);
+                           normal_mlp, loss, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_FWD, s);
-    if (loss) {
-        ls2fm_prof_begin(LS2FM_PROF_LOSS_FWD, s);
-        const int st = ls2fm_launch_loss_reduce(loss, ws + w.lpart, n_rays, field->n_samples, s);
-        ls2fm_prof_end(LS2FM_PROF_LOSS_FWD, s);
-        if (st != LS2FM_OK) return st;
-    }
+    ls2fm_prof_begin(LS2FM_PROF_BIN, s);
+    const int st = ls2fm_launch_post_shade(loss, ws + w.lpart, n_rays, field->n_samples, prepare_bwd ? sdf_grid : nullptr, w.p,
+                                           ws + w.bins, s);
+    ls2fm_prof_end(LS2FM_PROF_BIN, s);
+    if (st != LS2FM_OK) return st;
     return ls2fm_launch_status();
 }

@@ -14,7 +14,7 @@
 //   one-thread-per-sample order for the transmittance scan (Renderer.py:33-49).
 // fp32 MFMA = exact fp32 products and sums (no reduced-precision path); only the summation order differs from the
 // scalar-FMA oracle.
-#include "bin_items.h"
+#include "render_common.h"
 
 namespace {
 
@@ -39,19 +39,13 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
                  float* __restrict__ sdfs_out, float* __restrict__ normals_out, float* __restrict__ depth_out,
                  float* __restrict__ nm_out, float* __restrict__ SDFV, float* __restrict__ NRM,
                  float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2, float* __restrict__ ROUT,
-                 float* __restrict__ LPART, int64_t r_pad, ls2fm_loss_spec loss, int64_t n_rays, ScanJob scan) {
-    // leading workgroups (dispatched first, finished long before the rays'): the scans of the scatter's item counts
-    const int scan_blocks = scan.bm.tile ? scan.n_levels * kScanJobsPerLevel : 0;
-    if ((int)blockIdx.x < scan_blocks) {
-        scan_job_run(scan, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
-        return;
-    }
+                 float* __restrict__ LPART, int64_t r_pad, ls2fm_loss_spec loss) {
     __shared__ float s_part[MAXT / 64][10];     // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
     __shared__ float s_view[3];
     __shared__ float s_x[MAXT][8];              // per sample: sdf, normal(3), colour(3)
     __shared__ float s_w[kMfmaSdfFloats];       // MFMA-ordered weights of the field being evaluated (29 KB)
     const int N = fc.n_samples;
-    const int64_t r = (int64_t)blockIdx.x - scan_blocks;
+    const int64_t r = blockIdx.x;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
     const int jl = lane & 15, g = lane >> 4;
     const RayGeom gm = load_ray(fc, center, ray, r);
@@ -372,23 +366,15 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
                            int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
-                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, const ls2fm_grid_desc* scan_grid,
-                           hipStream_t s) {
+                           float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, hipStream_t s) {
     const int threads = (fc.n_samples + 63) / 64 * 64;
-    ScanJob scan{};                  // scan_grid: a backward follows -- the scatter's item counts are scanned in this launch
-    int scan_blocks = 0;
-    if (scan_grid) {
-        scan.bm = make_bin_meta(ws + w.bins, w.p);
-        scan.n_levels = scan_grid->n_levels;
-        scan_blocks = scan_grid->n_levels * kScanJobsPerLevel;
-    }
     ls2fm_loss_spec ls{};            // rgb_gt == null: plain render
     if (loss) ls = *loss;
 #define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                                \
-    shade_fwd_kernel<DUAL, MAXT><<<(unsigned)(n_rays + scan_blocks), threads, 0, s>>>(                                              \
+    shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                              \
         fc, ch1, ch2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb, sdfs_volume, \
         normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe, DUAL ? ws + w.fe2 : nullptr,        \
-        ws + w.rout, ws + w.lpart, w.r_pad, ls, n_rays, scan)
+        ws + w.rout, ws + w.lpart, w.r_pad, ls)
     if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 512); }
 #undef LS2FM_SHADE_FWD

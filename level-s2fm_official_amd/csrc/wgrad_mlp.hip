@@ -78,12 +78,12 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
 #pragma unroll
     for (int t = 0; t < 5; ++t) gsum[t] = 0.f;
 
-#pragma unroll 1
-    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles; tile += gridDim.x * kWmWaves) {
+    // B-layout operands of this lane's sample of one tile: rows k' = 4t + g / o = 4t + g.  The NEXT tile's operands are
+    // loaded while the current tile is being contracted: a wave is alone on its SIMD here (one workgroup per CU beside the
+    // scatter kernels), so nothing else hides the ~2 us of a dependent global load
+    auto load_tile = [&](int tile, float (&ub)[9], float (&vb)[9], float (&gfb)[5], float& gf0) {
         const uint32_t i = (uint32_t)tile * 16u + (uint32_t)jl;
-        const bool live = (int64_t)i < w.p;
-        // ---- B-layout operands of this lane's sample: rows k' = 4t + g / o = 4t + g
-        float ub[9], vb[9], gfb[5];
+        const bool live = tile < n_tiles && (int64_t)i < w.p;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int c = 4 * t + g;
@@ -108,9 +108,21 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
         for (int t = 0; t < 5; ++t) {
             const int o = GEO ? 1 + 4 * t + g : 4 * t + g;
             gfb[t] = (live && t < NT && o < kOut) ? f_gf[(uint32_t)o * P32 + i] : 0.f;
-            gsum[t] += gfb[t];
         }
-        const float gf0 = (!GEO && live) ? f_gf[i] : 0.f;
+        gf0 = (!GEO && live) ? f_gf[i] : 0.f;
+    };
+    const int tile_step = gridDim.x * kWmWaves;
+    float ub_n[9], vb_n[9], gfb_n[5], gf0_n;
+    load_tile(blockIdx.x * kWmWaves + wave, ub_n, vb_n, gfb_n, gf0_n);
+#pragma unroll 1
+    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles; tile += tile_step) {
+        float ub[9], vb[9], gfb[5];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { ub[t] = ub_n[t]; vb[t] = vb_n[t]; }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { gfb[t] = gfb_n[t]; gsum[t] += gfb[t]; }
+        const float gf0 = gf0_n;
+        load_tile(tile + tile_step, ub_n, vb_n, gfb_n, gf0_n);         // in flight during this tile's MFMA chain
         // transposed copies: [feature row][sample jl]
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
