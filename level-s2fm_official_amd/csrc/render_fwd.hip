@@ -268,10 +268,11 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     const int xcd = bx & 7, j = bx >> 3;
     const int unit = plan.start[xcd] + j;
     if (unit >= plan.start[xcd + 1]) return;
-    const int pl = unit / n_chunks;                      // pass-level: grid 1 levels, then grid 2 levels
+    const int pl = unit / n_chunks;                      // pass-level; two grids: (level 0, grid 1), (level 0, grid 2), (level 1, ..
     const int chunk = unit % n_chunks;
-    const bool second = !INTERLEAVED && pl >= lv1.n_levels;
-    const int l = second ? pl - lv1.n_levels : pl;
+    const bool two = !INTERLEAVED && table2 != nullptr;
+    const bool second = two && (pl & 1);
+    const int l = two ? pl >> 1 : pl;
     // the level's constants straight from the kernel-argument segment (a reference selecting between the two structs makes
     // the compiler copy both to scratch: 652 bytes per lane and an 8x slower kernel)
     LevelOne lv;
@@ -419,13 +420,19 @@ extern "C" int ls2fm_interleave_tables(const float* sdf_table, const float* rad_
 
 // cost-balanced cut of the walking order [grid 1 levels .., grid 2 levels ..] x chunks into 8 XCD pieces
 static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid_desc* g2, int l2, int n_samples, int n_chunks,
-                             int* most) {
+                             bool counting, int* most) {
     static const double dense_w = [] { const char* e = getenv("LS2FM_DENSE_W"); return e ? atof(e) : -1.0; }();   // experiments
     double cost[2 * LS2FM_MAX_LEVELS], total = 0.0;
+    // two grids (same geometry): the walking order alternates them level by level, so every XCD's piece holds both kinds of
+    // pass-levels -- the first grid's are dearer (Jacobian channels, and the scatter's item counting when a backward follows:
+    // with "all of grid 1, then all of grid 2" the four XCDs owning grid 1 finished 20 us after the others)
+    static const double g1_env = [] { const char* e = getenv("LS2FM_G1_W"); return e ? atof(e) : -1.0; }();
+    const double g1_w = g1_env > 0.0 ? g1_env : (counting ? 1.5 : 1.1);          // measured (tools/enc_probe.py)
     const int n_pl = l1 + l2;
     for (int pl = 0; pl < n_pl; ++pl) {
-        const ls2fm_grid_desc* gd = pl < l1 ? g1 : g2;
-        const int l = pl < l1 ? pl : pl - l1;
+        const bool second = l2 > 0 && (pl & 1);
+        const ls2fm_grid_desc* gd = second ? g2 : g1;
+        const int l = l2 > 0 ? pl >> 1 : pl;
         if (dense_w >= 0.0) {
             cost[pl] = gd->hashed[l] ? 1.0 : dense_w;
         } else {        // measured (tools/enc_ticks.py): dense levels ~0.28 of a fine hashed level; hashed levels grow with the
@@ -434,6 +441,7 @@ static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid
             const double h = 0.45 + 0.25 * log2(1.0 + rho);
             cost[pl] = gd->hashed[l] ? (h > 0.95 ? 0.95 : h) : 0.28;
         }
+        if (l2 > 0 && !second) cost[pl] *= g1_w;
         total += cost[pl];
     }
     XcdPlan plan;
@@ -517,7 +525,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const bool pair = dual && !interleaved;      // both grids, one launch
     const int enc_span = pair ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;
     int most = 0;
-    const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, &most);
+    const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, prepare_bwd, &most);
     EncodeExtras ex;
     ex.params = *params;
     ex.in_dim = 3 + 2 * L1; ex.in_dim2 = 3 + 2 * L2; ex.rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1); ex.dual = dual;

@@ -24,14 +24,15 @@ for log2_t in (17, 18, 19):
         sdf, rad, ren = SDF(opt).to(dev), RadF(opt).to(dev), Renderer(opt)
         randomize([sdf, rad], seed=0)
         center, ray = synthetic_rays(rays, 5.0, dev, seed=0)
-        with torch.no_grad():
-            for _ in range(5):
-                ren.forward(opt, center, ray, sdf, rad)
-            torch.cuda.synchronize()
-            lib.ls2fm_profile_reset(); lib.ls2fm_profile_enable(1)
-            for _ in range(30):
-                ren.forward(opt, center, ray, sdf, rad)
-            torch.cuda.synchronize()
-            lib.ls2fm_profile_enable(0)
-        t = kernel_times(lib)
-        print(f"T=2^{log2_t} dual_table={mode:8s}", {k: round(v[0], 1) for k, v in t.items() if "encode" in k or "shade" in k}, flush=True)
+        for grad in (False, True):           # grad enabled: the gather pass also counts the scatter's items
+            with torch.set_grad_enabled(grad):
+                for _ in range(5):
+                    ren.forward(opt, center, ray, sdf, rad)
+                torch.cuda.synchronize()
+                lib.ls2fm_profile_reset(); lib.ls2fm_profile_enable(1)
+                for _ in range(30):
+                    ren.forward(opt, center, ray, sdf, rad)
+                torch.cuda.synchronize()
+                lib.ls2fm_profile_enable(0)
+            t = kernel_times(lib)
+            print(f"T=2^{log2_t} dual_table={mode:8s} counting={grad}", {k: round(v[0], 1) for k, v in t.items() if "encode" in k or "shade" in k}, flush=True)
