@@ -74,12 +74,14 @@ def host_threads(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(dataset, dual, n_samples, budget_s=20.0):
-    """The CPU oracle (a torch restatement of the reference's op sequence, pinned against the reference's golden
-    vectors) timed on the host cores of this box on a bounded sample of the same workload."""
+def cpu_baseline(dataset, dual, n_samples, n_rays=1024, budget_s=25.0):
+    """The CPU oracle (a torch restatement of the reference's op sequence, pinned against the reference's golden vectors)
+    timed on the host cores of this box on a bounded sample of the SAME workload: whole fwd+bwd steps of the benchmark's
+    own batch (1024 rays x 128 samples, full-size grids) on all granted cores, plus one single-thread step of a quarter
+    batch (SURVEY 8d asks for both figures).  The step cost has a large batch-independent part (gradients of the two
+    12 M-entry tables), so small samples understate the CPU: 128 rays run at ~35 rays/s, 1024 rays at ~110."""
     from oracle import fields as OF
     threads = host_threads()
-    torch.set_num_threads(threads)
     cfg = OF.dataset_config(dataset, dual_field=dual, sample_intvs=n_samples)
     gen = torch.Generator().manual_seed(0)
     sd, rd = OF.init_sdf_state(cfg, gen), OF.init_rad_state(cfg, gen)
@@ -87,26 +89,46 @@ def cpu_baseline(dataset, dual, n_samples, budget_s=20.0):
     OF.randomize_state(rd, gen)
     sd = OF.to_dtype(sd, torch.float32, True)
     rd = OF.to_dtype(rd, torch.float32, True)
-    n_rays = 128
     s = cfg.bound_max[0]
-    center, ray = synthetic_rays(n_rays, s, "cpu")
     table = cfg.table()
 
-    def step():
+    def step(rays):
+        center, ray = synthetic_rays(rays, s, "cpu")
         for st in (sd, rd):
             for v in st.values():
                 v.grad = None
+        t = time.perf_counter()
         loss_head(OF.render(cfg, center, ray, sd, rd, table, table)).backward()
+        return time.perf_counter() - t
 
-    step()                                    # warm-up (allocators, thread pool)
-    t0, n = time.perf_counter(), 0
-    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 50):
-        step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
+    torch.set_num_threads(threads)
+    step(64)                                  # warm-up (allocators, thread pool)
+    times = []
+    while len(times) < 1 or (sum(times) + times[-1] < budget_s and len(times) < 10):
+        times.append(step(n_rays))
+    dt = sorted(times)[len(times) // 2]
+    torch.set_num_threads(1)
+    n1 = max(32, n_rays // 4)
+    dt1 = step(n1)
+    torch.set_num_threads(threads)
     return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{n} fwd+bwd steps of {n_rays} rays x {n_samples} samples (same field config, torch CPU, "
-                      f"{threads} threads), {dt * 1e3:.0f} ms/step"}
+            "sample": f"{len(times)} fwd+bwd step(s) of {n_rays} rays x {n_samples} samples (the benchmark's own batch and field "
+                      f"config, torch CPU, {threads} threads), median {dt * 1e3:.0f} ms/step",
+            "single_thread": {"value": n1 / dt1, "unit": "rays/s", "cores": 1,
+                              "sample": f"1 fwd+bwd step of {n1} rays x {n_samples} samples, 1 thread, {dt1 * 1e3:.0f} ms"}}
+
+
+# per-GPU workloads of BASELINE.json's configurations; weak scaling: every rank renders `rays` rays
+CONFIGS = {
+    "C2": dict(dataset="ETH3D", rays=1024, samples=128, dual=True,
+               note="configs[1]: ETH3D two-view init, 1024 rays x 128 samples, hash-grid SDF + radiance"),
+    "C3": dict(dataset="DTU", rays=8192, samples=128, dual=True,
+               note="configs[2]: DTU, dual field, the pipeline's 8192 rays per step (split over the views of a stage)"),
+    "C4": dict(dataset="BlendedMVS", rays=1024, samples=128, dual=False,
+               note="configs[3]: BlendedMVS Neural-BA step, one registered view (1024 rays) per GPU"),
+    "C5": dict(dataset="scannet", rays=4096, samples=256, dual=False,
+               note="configs[4]: ScanNet stress, 4096 rays x 256 samples with eikonal loss"),
+}
 
 
 def main():
@@ -114,10 +136,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=1024)
-    ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--dataset", default="ETH3D")
-    ap.add_argument("--single-field", action="store_true")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2",
+                    help="BASELINE.json workload (SURVEY 8d): C2 = the metric's configuration (default); C3-C5 per-GPU shapes of "
+                         "configs[2..4]; --rays / --samples / --dataset / --single-field override single values")
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU")
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--dataset", default=None)
+    ap.add_argument("--single-field", action="store_true", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
     ap.add_argument("--force-dist", action="store_true",
@@ -130,9 +155,14 @@ def main():
     ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
     ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
     args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    args.rays = preset["rays"] if args.rays is None else args.rays
+    args.samples = preset["samples"] if args.samples is None else args.samples
+    args.dataset = preset["dataset"] if args.dataset is None else args.dataset
+    args.single_field = (not preset["dual"]) if args.single_field is None else args.single_field
 
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.dataset, not args.single_field, args.samples)))
+        print(json.dumps(cpu_baseline(args.dataset, not args.single_field, args.samples, args.rays)))
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,12 +272,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    # timed region: EXACTLY K steps between barrier + synchronize on both sides.  That block is repeated until ~1 s of device
+    # time has been sampled (a driver run with --steps 20 would otherwise time 12 ms) and the MEDIAN block is reported; every
+    # block is a complete measurement under the contract, min / max are in the line.
+    def timed_block():
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        return time.perf_counter() - t_start
+    blocks = [timed_block()]
+    n_blocks = max(1, min(100, int(1.0 / max(blocks[0], 1e-4) + 0.999)))
+    if multi:                                # every rank must run the same number of blocks
+        nb = torch.tensor([n_blocks], device=dev)
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+        n_blocks = int(nb.item())
+    while len(blocks) < n_blocks:
+        blocks.append(timed_block())
+    if multi:                                # max over ranks, block by block
+        tb = torch.tensor(blocks, device=dev, dtype=torch.float64)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        blocks = tb.tolist()
+    dt = sorted(blocks)[len(blocks) // 2]
     # per-kernel device times (roofline): the same K steps launched eagerly with the library's HIP-event profiler on
     # (events cannot be read back from inside a graph replay); also gives the eager step time
     lib.ls2fm_profile_reset()
@@ -260,10 +307,6 @@ def main():
     dt_eager = time.perf_counter() - t1
     lib.ls2fm_profile_enable(0)
     has_prof = True
-    if multi:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
     value = args.rays * world * args.steps / dt
@@ -272,22 +315,37 @@ def main():
         from ls2fm.profile import dominant_kernel_roofline
         roofline = dominant_kernel_roofline(lib, n_points=args.rays * args.samples, dual=dual,
                                             hbm_peak_gbs=HBM_PEAK_GBS, f32_peak_tflops=F32_PEAK_TFLOPS)
-        # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter
-        # summary of this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is quoted
-        # when the workload is the default one
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter summary of
+        # this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is QUOTED when the workload
+        # is the default one -- with the commit it was measured at, so a stale figure is recognisable
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
-            rec = json.load(open(pmc)).get(roofline["kernel"])
+            doc = json.load(open(pmc))
+            rec = doc.get(roofline["kernel"])
             if rec:
                 roofline["traffic"] = rec["fetch"] + rec["write"]
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; raw)"
+                roofline["traffic_source"] = (f"quoted from profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                              f"passes at commit {doc.get('_commit', '?')}; FETCH_SIZE doubled per the guide)")
+        if roofline:
+            # SURVEY 8d's whole-step figures: algorithmic table bytes (gather + scatter, both grids) and dense FLOPs of one step
+            # over the measured step time
+            n_pts = args.rays * args.samples
+            bytes_per_pt = (4 if dual else 2) * 1024 + 16
+            flops_per_pt = 115e3 if dual else 75e3
+            step_s = dt / args.steps
+            roofline["whole_step"] = {
+                "hbm": {"bytes_per_ray": bytes_per_pt * args.samples, "achieved": n_pts * bytes_per_pt / step_s / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": n_pts * bytes_per_pt / step_s / 1e9 / HBM_PEAK_GBS},
+                "mfma": {"flops_per_ray": flops_per_pt * args.samples, "achieved": n_pts * flops_per_pt / step_s / 1e12,
+                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": n_pts * flops_per_pt / step_s / 1e12 / F32_PEAK_TFLOPS}}
     out = {
         "metric": "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "timed_blocks": len(blocks), "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launch": ("hipGraph replay of the whole step" if use_graph else "eager") + (" (auto)" if mode == "auto" else ""),
         "eager_profiled_ms_per_step": dt_eager / args.steps * 1e3,
-        "config": {"workload": f"{args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
+        "config": {"workload": f"{args.config}: {args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
                                f"{'dual' if dual else 'single'} field, L16/F2/T19 hash grid, fwd+loss+bwd"
                                + (", RCCL grad all-reduce" if multi else ""),
                    "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "dual_field": dual,
@@ -301,7 +359,7 @@ def main():
             # misbehaving host can never hang the benchmark
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--dataset", args.dataset,
-                   "--samples", str(args.samples)] + (["--single-field"] if args.single_field else [])
+                   "--samples", str(args.samples), "--rays", str(args.rays)] + (["--single-field"] if args.single_field else [])
             try:
                 res = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
                 out["cpu_baseline"] = json.loads(res.stdout.strip().splitlines()[-1])

@@ -4,7 +4,9 @@ timing") and the roofline bookkeeping of bench.py.
 Algorithmic work per launch (P = sample points of one batch, L = hash levels, 8 corners x 2 features
 x 4 B = 64 B per level per point):
   ray_encode_*    : P * L * 64 B  gathered from the table (ray_encode_pair: both grids)  -> HBM roofline
-  slab_scatter_*  : P * L * 64 B  accumulated into the table gradient          -> HBM roofline
+  scatter (fill + accumulate) : P * L * 64 B per grid accumulated into the table gradient -> HBM roofline.  The two kernels
+                    are two passes over ONE algorithmic transfer, so they are credited as a pair ("scatter_pair": bytes over
+                    the SUM of their durations); neither is listed with a fraction of its own.
   shade_fwd       : P * 2 * MACs  (SDF MLP 35*64 + 64*17, normal W0^T 35*64 + 96, second field 35*64 + 64*17,
                     collapsed radiance 3*38)                                    -> f32 MFMA/VALU roofline
   shade_bwd       : P * 2 * MACs  (a, q, dE, r: 4 * 35*64; W1^T g 17*64; second field 2 * 35*64 + 16*64)
@@ -40,9 +42,8 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
     return {
         "ray_encode_sdf": ("hbm", table_bytes), "ray_encode_rad": ("hbm", table_bytes),
         "ray_encode_pair": ("hbm", 2 * table_bytes),             # dual field: both grids gathered by one launch
-        # table-gradient scatter = scatter_fill (payload sort) + slab_accumulate; dual field: both grids in one pass
-        "slab_accumulate": ("hbm", table_bytes * (2 if dual else 1)),
-        "scatter_fill": ("hbm", table_bytes * (2 if dual else 1)),
+        # table-gradient scatter = scatter_fill (payload sort) + slab_accumulate, credited ONCE for the pair (_fractions)
+        "scatter_pair": ("hbm", table_bytes * (2 if dual else 1)),
         "shade_fwd": ("mfma", 2 * fwd_macs * n_points), "shade_bwd": ("mfma", 2 * bwd_macs * n_points),
         "wgrad_mlp_sdf": ("mfma", 2 * (64 * 36 + 64 * 35 + 17 * 65 + 64) * n_points),
         "wgrad_mlp_geo": ("mfma", 2 * (64 * 36 + 17 * 65) * n_points),
@@ -52,6 +53,10 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
 def _fractions(times, work, hbm_peak_gbs, f32_peak_tflops):
     """algorithmic bytes (or FLOPs) / measured duration / peak, for every kernel with an algorithmic figure"""
     out = {}
+    if "scatter_fill" in times and "slab_accumulate" in times:
+        times = dict(times)
+        pair_us = times["scatter_fill"][0] + times["slab_accumulate"][0]
+        times["scatter_pair"] = (pair_us, times["scatter_fill"][1], times["scatter_fill"][2] + times["slab_accumulate"][2])
     for name, (avg_us, _, _) in times.items():
         if name not in work:
             continue
@@ -67,10 +72,12 @@ def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float
     if not times:
         return None
     work = algorithmic_work(n_points, dual)
-    name = max(times, key=lambda k: times[k][2])
+    name = max(times, key=lambda k: times[k][2])          # a single kernel (the scatter's two passes are separate launches)
     avg_us, launches, total_ms = times[name]
     grand = sum(t[2] for t in times.values())
     bound, amount = work.get(name, ("hbm", 0))
+    if name in ("scatter_fill", "slab_accumulate"):       # half of a two-pass transfer: priced against the pair's bytes
+        bound, amount = work["scatter_pair"]
     if bound == "hbm":
         achieved, peak, unit = amount / (avg_us * 1e-6) / 1e9, hbm_peak_gbs, "GB/s"
     else:
