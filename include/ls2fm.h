@@ -175,6 +175,23 @@ int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid,
                      const double* origin, float* sdf, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Point queries WITH a graph: backward of  p -> (sdf, the 17 MLP outputs, the analytic normal d sdf / d p)  for n free points.
+ * Replaces: what loss.backward() traverses for SDF.infer_sdf with parameters requiring grad (models/SDF.py:55-78),
+ * SDF.gradient (SDF.py:102-114: autograd.grad(create_graph=True) -- callers take norms of it inside losses:
+ * pipelines/Registration.py:202,259-261, BA.py:123-125) and SDF.get_surface_pts (SDF.py:95-100): tcnn's backward and
+ * double-backward kernels plus the torch Linear / Softplus / weight_norm backward nodes and their double backward.
+ * The forward is ls2fm_sdf_eval (same values; nothing is kept from it).  Upstreams (any may be NULL = zeros, not all):
+ * d_sdf [n], d_feat [n,17] (raw MLP outputs; column 0 is f0, sdf = +-f0 / scale_mlp), d_normal [n,3].
+ * grads: sdf_table (overwritten in full), sdf_mlp[0..1] (weight_v / weight_g / bias, overwritten); other members ignored.
+ * d_p [n,3] (overwritten) or NULL.  No background-sphere min (LS2FM_ERR_UNSUPPORTED: general composed form).
+ * workspace: ls2fm_sdf_points_workspace_bytes(...) bytes, scratch for this call only.
+ */
+int64_t ls2fm_sdf_points_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n_points);
+int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                         const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
+                         const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused volumetric rendering, forward.
  * Replaces: Renderer.forward (models/Renderer.py:51-116) and everything it calls: ray/AABB near-far
  * (Renderer.py:178), uniform mid-point sampling (Renderer.py:118-127), p = c + d t (utils/camera.py:

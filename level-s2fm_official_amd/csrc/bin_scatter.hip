@@ -35,16 +35,6 @@
 
 namespace {
 
-// sample i -> grid-normalised position, exactly as every other kernel of the path computes it
-__device__ __forceinline__ void point_position(const FieldC& fc, const float* __restrict__ center, const float* __restrict__ ray,
-                                               int64_t i, float x[3]) {
-    const int64_t r = i / fc.n_samples;
-    const int n = (int)(i - r * fc.n_samples);
-    const RayGeom gm = load_ray(fc, center, ray, r);
-    float p[3];
-    sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
-}
-
 // ------------------------------------------------------------------------------------------------ fill
 // rpt[point] = {x y z gn0 | gn1 gn2 - -}; rec1[level][point] = {de0 de1 rr0 rr1}; rec2[level][point] = {de0 de1}
 template <bool DUAL>
@@ -72,8 +62,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         const float4 a = reinterpret_cast<const float4*>(rpt)[2 * i];
         const float4 c = reinterpret_cast<const float4*>(rpt)[2 * i + 1];
         const float4 b = reinterpret_cast<const float4*>(rec1)[(int64_t)l * p_pad + i];
-        float x[3];
-        point_position(fc, center, ray, i, x);              // the very code path of the count pass: same cells, same slabs
+        const float x[3] = {a.x, a.y, a.z};                 // the grid-normalised position the forward classified (same bits)
 #pragma unroll
         for (int q = 0; q < 3; ++q) pos_fract(x[q], L.scale, g[q], w[q]);
         d0 = b.x; d1 = b.y; r0 = b.z; r1 = b.w;

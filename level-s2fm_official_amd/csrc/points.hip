@@ -1,0 +1,272 @@
+// Point queries of the SDF field WITH a graph: the backward of  p -> (sdf, 17 MLP outputs, analytic normal d sdf / d p)
+// for M free points (M ~ 1e3 .. 1e5), to the hash table, the SDF MLP (in the reference's weight_v / weight_g / bias
+// parametrisation) and the points themselves -- including the double-backward terms of the normal.
+//
+// Replaces what loss.backward() traverses for SDF.infer_sdf with parameters requiring grad, SDF.gradient (create_graph=True:
+// callers put ||gradient|| inside losses) and SDF.get_surface_pts (models/SDF.py:55-114; callers pipelines/BA.py:123-125
+// "sfm" mode, pipelines/Registration.py:202,259-261, 500-iteration loops): tcnn's backward and double-backward kernels, the
+// torch Linear / Softplus / weight_norm backward nodes and autograd's double backward of them -- ~60 launch-bound kernels per
+// call in the composed form.
+//
+// The forward is ls2fm_sdf_eval (sdf_eval.hip).  The backward keeps nothing from it: it re-encodes the points and then runs
+// the render backward's own machinery on them (a point is a "ray" of one sample):
+//   gather pass      ray_encode_kernel over free points: E, J channels, SDF-MLP weight prep, the scatter's item counts
+//   points_bwd       thread per point: hidden layer, Softplus derivatives, DA = S1.T + S2.w1_0.Q, GJ = S1.w1_0, the encoding
+//                    rows of W0^T DA / W0^T GJ (the scatter's records), the upstream vectors v / gf for the weight gradients
+//   post             scans of the item counts
+//   wgrad_mlp + reduce + finalize (side stream)    weight gradients on the matrix cores, weight-norm backward
+//   scatter_fill + slab_accumulate                 table gradient, exact fixed-point sums, written in full
+//   points_dx        (only when d p is wanted) first derivatives of the encodings contracted with DE and the mixed second
+//                    partials contracted with RR and the normal's upstream (8 gathers per level again)
+#include "bin_items.h"
+
+int ls2fm_launch_points_encode(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                               const float* pts, const WsLayout& w, float* ws, hipStream_t s);
+int ls2fm_launch_post_shade(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples,
+                            const ls2fm_grid_desc* scan_grid, int64_t n_points, float* bins_ws, hipStream_t stream);
+int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
+                              int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream);
+int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
+                                 hipStream_t stream);
+int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
+                              const float* wg, hipStream_t stream);
+bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
+
+namespace {
+
+// thread per point.  Weights as wave-uniform scalar loads from the packed records (Packed::sdf: [j][0..34] W0 row in the
+// reference's column order (p, e), [35] b0, [36..52] W1[o][j]).
+__global__ void __launch_bounds__(256)
+points_bwd_kernel(FieldC fc, LevelScales lsc, int n_levels, WsLayout w, const Packed* __restrict__ pk, const float* __restrict__ pts,
+                  const float* __restrict__ d_sdf, const float* __restrict__ d_feat, const float* __restrict__ d_normal,
+                  float* __restrict__ ws, int want_dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= w.p) return;
+    const int64_t P = w.p_pad;
+    float p[3], x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        p[a] = pts[i * 3 + a];
+        x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+    }
+    // upstream of the 17 MLP outputs and of the normal
+    float gf[kOut];
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) gf[o] = d_feat ? d_feat[i * kOut + o] : 0.f;
+    if (d_sdf) gf[0] = fmaf(fc.kappa, d_sdf[i], gf[0]);               // sdf = kappa f0
+    float gnk[3], gns[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        gnk[a] = d_normal ? fc.kappa * d_normal[i * 3 + a] : 0.f;
+        gns[a] = gnk[a] * fc.inv_ext[a];
+    }
+    // u = [p / rescale ; e(x)],  v = d u / d p contracted with kappa g_n   (reference column order)
+    float u[kInMax], v[kInMax];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { u[a] = p[a] / fc.rescale; v[a] = gnk[a] / fc.rescale; }
+#pragma unroll
+    for (int c = 0; c < 2 * LS2FM_MAX_LEVELS; ++c) {
+        float e = 0.f, acc = 0.f;
+        if (c < 2 * n_levels) {
+            e = ws[w.e1 + (int64_t)c * P + i];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc = fmaf(ws[w.j1 + (int64_t)(c * 3 + a) * P + i], gns[a], acc);
+        }
+        u[3 + c] = e;
+        v[3 + c] = acc;
+    }
+    float de[kInMax], rr[kInMax];
+#pragma unroll
+    for (int k = 0; k < kInMax; ++k) { de[k] = 0.f; rr[k] = 0.f; }
+    const float* __restrict__ rec = pk->sdf;
+#pragma unroll 1
+    for (int j = 0; j < kHidden; ++j) {
+        const float* __restrict__ wr = rec + j * kRecStride;
+        float a0 = wr[kRecB0], a1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int k = 0; k + 1 < kInMax; k += 2) {
+            a0 = fmaf(wr[k], u[k], a0);
+            a1 = fmaf(wr[k + 1], u[k + 1], a1);
+            q0 = fmaf(wr[k], v[k], q0);
+            q1 = fmaf(wr[k + 1], v[k + 1], q1);
+        }
+        a0 = fmaf(wr[kInMax - 1], u[kInMax - 1], a0);
+        q0 = fmaf(wr[kInMax - 1], v[kInMax - 1], q0);
+        float h, s1, s2;
+        softplus100(a0 + a1, h, s1, s2);
+        const float q = q0 + q1;
+        float t = 0.f;
+#pragma unroll
+        for (int o = 0; o < kOut; ++o) t = fmaf(wr[kRecW1 + o], gf[o], t);
+        const float w10 = wr[kRecW1];
+        const float da = fmaf(s1, t, s2 * w10 * q);
+        const float gj = s1 * w10;
+#pragma unroll
+        for (int k = 0; k < kInMax; ++k) {
+            de[k] = fmaf(wr[k], da, de[k]);
+            rr[k] = fmaf(wr[k], gj, rr[k]);
+        }
+    }
+    // ---- hand-over to the weight-gradient and scatter kernels of the render backward
+#pragma unroll
+    for (int k = 0; k < kInMax; ++k) ws[w.v + (int64_t)k * P + i] = v[k];
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) ws[w.gf + (int64_t)o * P + i] = gf[o];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ws[w.p3 + (int64_t)a * P + i] = p[a];
+    float4* rpt = reinterpret_cast<float4*>(ws + w.rpt + i * 8);
+    rpt[0] = make_float4(x[0], x[1], x[2], gns[0]);
+    rpt[1] = make_float4(gns[1], gns[2], 0.f, 0.f);
+    const float g1 = fabsf(gns[0]) + fabsf(gns[1]) + fabsf(gns[2]);
+#pragma unroll
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+        float b = 0.f;
+        if (l < n_levels) {
+            const float d0 = de[3 + 2 * l], d1 = de[4 + 2 * l], r0 = rr[3 + 2 * l], r1 = rr[4 + 2 * l];
+            *reinterpret_cast<float4*>(ws + w.rec1 + ((int64_t)l * P + i) * 4) = make_float4(d0, d1, r0, r1);
+            b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[l] * g1 * fmaxf(fabsf(r0), fabsf(r1));
+        }
+        ws[w.smax + (int64_t)l * w.r_pad + i] = b;            // a point is its own "ray" (n_samples = 1)
+    }
+    if (want_dx) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ws[w.dexyz + (int64_t)a * P + i] = de[a];
+    }
+}
+
+// d L / d p  =  (1 / rescale) (W0^T DA)_p  +  inv_ext . sum_l sum_f [ de_f  d e_f / d x  +  rr_f (d^2 e_f / d x d x) gns ]
+// (pose_grad.hip's per-sample expression, SDF grid only)
+__global__ void __launch_bounds__(256)
+points_dx_kernel(FieldC fc, LevelSet lv, WsLayout w, const float* __restrict__ table, const float* __restrict__ ws,
+                 float* __restrict__ d_p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= w.p) return;
+    const int64_t P = w.p_pad;
+    const float4 pa = reinterpret_cast<const float4*>(ws + w.rpt)[2 * i];
+    const float4 pb = reinterpret_cast<const float4*>(ws + w.rpt)[2 * i + 1];
+    const float x[3] = {pa.x, pa.y, pa.z};
+    const float gns[3] = {pa.w, pb.x, pb.y};
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < lv.n_levels; ++l) {
+        Cell c;
+        locate(x, lv.scale[l], lv.res[l], lv.size[l], lv.offset[l], lv.hashed[l], c);
+        float2 tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tv[k] = reinterpret_cast<const float2*>(table)[c.idx[k]];
+        const float4 rec = reinterpret_cast<const float4*>(ws + w.rec1)[(int64_t)l * P + i];
+        const float de[2] = {rec.x, rec.y}, rr[2] = {rec.z, rec.w};
+        const float sc = lv.scale[l];
+        float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f}, h0[3] = {0.f, 0.f, 0.f}, h1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float dw = corner_dweight(c.w, k, a);
+                j0[a] = fmaf(tv[k].x, dw, j0[a]);
+                j1[a] = fmaf(tv[k].y, dw, j1[a]);
+            }
+            const float d01 = corner_d2weight(c.w, k, 0, 1), d02 = corner_d2weight(c.w, k, 0, 2), d12 = corner_d2weight(c.w, k, 1, 2);
+            h0[0] = fmaf(tv[k].x, d01, h0[0]); h0[1] = fmaf(tv[k].x, d02, h0[1]); h0[2] = fmaf(tv[k].x, d12, h0[2]);
+            h1[0] = fmaf(tv[k].y, d01, h1[0]); h1[1] = fmaf(tv[k].y, d02, h1[1]); h1[2] = fmaf(tv[k].y, d12, h1[2]);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] = fmaf(sc, de[0] * j0[a] + de[1] * j1[a], acc[a]);
+        const float s2 = sc * sc;
+        const float hg0[3] = {h0[0] * gns[1] + h0[1] * gns[2], h0[0] * gns[0] + h0[2] * gns[2], h0[1] * gns[0] + h0[2] * gns[1]};
+        const float hg1[3] = {h1[0] * gns[1] + h1[1] * gns[2], h1[0] * gns[0] + h1[2] * gns[2], h1[1] * gns[0] + h1[2] * gns[1]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] = fmaf(s2, rr[0] * hg0[a] + rr[1] * hg1[a], acc[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d_p[i * 3 + a] = fmaf(acc[a], fc.inv_ext[a], ws[w.dexyz + (int64_t)a * P + i] / fc.rescale);
+}
+
+ls2fm_field_desc one_sample_field(const ls2fm_field_desc* field) {
+    ls2fm_field_desc f = *field;
+    f.n_samples = 1;
+    f.dual_field = 0;
+    return f;
+}
+
+}  // namespace
+
+extern "C" int64_t ls2fm_sdf_points_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n_points) {
+    if (!field || !grid_desc_ok(grid) || n_points < 0) return LS2FM_ERR_INVALID_ARGUMENT;
+    if (n_points > LS2FM_MAX_RENDER_POINTS) return LS2FM_ERR_UNSUPPORTED;
+    const WsLayout w = make_ws_layout(n_points, 1, grid->n_levels, grid->n_levels, 0);
+    return w.total * (int64_t)sizeof(float);
+}
+
+extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                    const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
+                                    const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream) {
+    LS2FM_CHECK_ARG(field && grid_desc_ok(grid) && params && grads && n >= 0);
+    LS2FM_CHECK_ARG(params->sdf_table && params->sdf_mlp[0].weight_v && params->sdf_mlp[1].weight_v);
+    LS2FM_CHECK_ARG(d_sdf || d_feat || d_normal);
+    if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;            // min(sdf, bg_rad - |p|): general (composed) form only
+    if (n > LS2FM_MAX_RENDER_POINTS || !ls2fm_bins_levels_fit(grid, 0)) return LS2FM_ERR_UNSUPPORTED;
+    if (n == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(p && grads->sdf_table && grads->sdf_mlp[0].weight_v && grads->sdf_mlp[1].weight_v);
+    LS2FM_CHECK_ARG((reinterpret_cast<uintptr_t>(grads->sdf_table) & 15u) == 0);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const ls2fm_field_desc f1 = one_sample_field(field);
+    const FieldC fc = make_field_c(&f1);
+    const int L = grid->n_levels;
+    const WsLayout w = make_ws_layout(n, 1, L, L, 0);
+    float* ws = (float*)workspace;
+    const Packed* pk = (const Packed*)(ws + w.packed);
+    LevelScales lsc;
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L ? grid->scale[l] : 0.f;
+
+    // zero fills: reduced weight-gradient accumulators; the atomically flushed (point-split coarse) levels of the table gradient
+    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    {
+        int64_t first = 0, count = 0;
+        ls2fm_scatter_zero_range(grid, w.p, false, &first, &count);
+        if (count > 0 && hipMemsetAsync(grads->sdf_table + 2 * first, 0, sizeof(float) * 2 * (size_t)count, s) != hipSuccess)
+            return LS2FM_ERR_LAUNCH;
+    }
+    ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
+    int st = ls2fm_launch_points_encode(&f1, grid, params, p, w, ws, s);
+    ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
+    if (st != LS2FM_OK) return st;
+    ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
+    points_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws, d_p != nullptr);
+    ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
+    ls2fm_prof_begin(LS2FM_PROF_BIN, s);
+    st = ls2fm_launch_post_shade(nullptr, nullptr, n, 1, grid, w.p, ws + w.bins, s);
+    ls2fm_prof_end(LS2FM_PROF_BIN, s);
+    if (st != LS2FM_OK) return st;
+
+    // fork: weight gradients (matrix cores) + weight-norm backward beside the table scatter
+    SideCtx sc;
+    const bool forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess &&
+                        hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+    hipStream_t gs = forked ? sc.side : s;
+    ls2fm_launch_wgrad_mlp(fc, 0, 2 * L, 0, w, pk, nullptr, nullptr, n, ws, gs, /*sdf_only=*/true);
+    ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
+    st = ls2fm_launch_finalize_sdf(params, grads, 3 + 2 * L, pk, ws + w.wg, gs);
+    ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
+    if (st == LS2FM_OK && forked && hipEventRecord(sc.join, sc.side) != hipSuccess) st = LS2FM_ERR_LAUNCH;
+    if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+
+    ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
+    st = ls2fm_launch_scatter_fill(grid, fc, nullptr, nullptr, ws + w.bins, w.p, w.p_pad, ws + w.rec1, nullptr, ws + w.rpt, ws + w.smax,
+                                   n, 0, s);
+    ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
+    if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+    ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
+    st = ls2fm_launch_slab_accumulate(grid, ws + w.bins, w.p, grads->sdf_table, nullptr, s);
+    ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
+    if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+    if (d_p) {
+        ls2fm_prof_begin(LS2FM_PROF_POSE, s);
+        points_dx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(fc, make_level_set(grid), w, params->sdf_table, ws, d_p);
+        ls2fm_prof_end(LS2FM_PROF_POSE, s);
+    }
+    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
+    return ls2fm_launch_status();
+}

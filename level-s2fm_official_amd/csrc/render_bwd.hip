@@ -164,6 +164,13 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 
 }  // namespace
 
+// weight-norm backward of the SDF MLP alone (point queries, points.hip): tasks 0 and 1 of finalize_kernel
+int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
+                              const float* wg, hipStream_t stream) {
+    finalize_kernel<<<2, 256, 0, stream>>>(*params, *grads, in_dim, 0, 0, 0, pk, wg, nullptr, 0);
+    return ls2fm_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------- C ABI
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,

@@ -322,7 +322,7 @@ int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, co
 
 // wgrad_mlp.hip
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
-                           const float* ray, int64_t n_rays, float* ws, hipStream_t s);
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only = false);
 
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,

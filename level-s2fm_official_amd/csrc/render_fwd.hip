@@ -225,6 +225,8 @@ struct EncodeExtras {
     int* tile_counts;         // [L][n_tiles][kBins] or null: no counting
     int* scan_ticket;
     int n_tiles, sshift;
+    int n_prep_tasks;         // 3: both MLPs + the radiance chain (render); 1: the SDF MLP only (point queries)
+    const float* pts;         // [n,3] free points instead of ray samples (point queries), or null
 };
 
 constexpr int kEncThreads = kFillTile;       // 512: one workgroup = one (level, tile of the scatter's counting sort)
@@ -234,12 +236,20 @@ constexpr int kEncReserved = 8;              // leading workgroups (a multiple o
 struct LevelOne { float scale; uint32_t res, size, offset, hashed; };      // one level's constants (scalar registers)
 
 __device__ __forceinline__ void locate_sample(const FieldC& fc, const float* __restrict__ center, const float* __restrict__ ray,
-                                              int64_t i, const LevelOne& lv, uint32_t g[3], Cell& c) {
-    const int64_t r = i / fc.n_samples;
-    const int n = (int)(i - r * fc.n_samples);
-    const RayGeom gm = load_ray(fc, center, ray, r);
+                                              const float* __restrict__ pts, int64_t i, const LevelOne& lv, uint32_t g[3], Cell& c) {
     float p[3], x[3];
-    sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
+    if (pts) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            p[a] = pts[i * 3 + a];
+            x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+        }
+    } else {
+        const int64_t r = i / fc.n_samples;
+        const int n = (int)(i - r * fc.n_samples);
+        const RayGeom gm = load_ray(fc, center, ray, r);
+        sample_position(fc, gm, sample_depth(gm, n, fc.n_samples), p, x);
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d) pos_fract(x[d], lv.scale, g[d], c.w[d]);
 #pragma unroll
@@ -259,7 +269,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     __shared__ int hist[kBins];
     const int tid = threadIdx.x;
     if (blockIdx.x < kEncReserved) {
-        if (ex.packed && blockIdx.x < 3)
+        if (ex.packed && (int)blockIdx.x < ex.n_prep_tasks)
             prep_weights_task(ex.params, ex.in_dim, ex.in_dim2, ex.rad_in, ex.dual, 1, ex.packed, (int)blockIdx.x, tid, kEncThreads);
         if (blockIdx.x == 3 && tid == 0 && ex.scan_ticket) *ex.scan_ticket = 0;      // armed for the scans in the shade_fwd launch
         return;
@@ -293,7 +303,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     if (i < n_points) {
         uint32_t g[3];
         Cell c;
-        locate_sample(fc, center, ray, i, lv, g, c);
+        locate_sample(fc, center, ray, ex.pts, i, lv, g, c);
         if (INTERLEAVED) {
             const float4* __restrict__ table = reinterpret_cast<const float4*>(table1);
             float4 v[8];
@@ -492,6 +502,32 @@ extern "C" int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, c
 }
 
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
+
+// Gather pass over FREE POINTS (the point-query backward, points.hip): value + Jacobian channels of the SDF grid, the SDF MLP's
+// weight prep in the leading workgroups and the scatter's item counts -- the same kernel as the render's
+int ls2fm_launch_points_encode(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                               const float* pts, const WsLayout& w, float* ws, hipStream_t s) {
+    const FieldC fc = make_field_c(field);
+    const int L = grid->n_levels;
+    const int n_chunks = (int)((w.p + kEncThreads - 1) / kEncThreads);
+    int most = 0;
+    const XcdPlan plan = make_xcd_plan(grid, L, nullptr, 0, 1, n_chunks, true, &most);
+    EncodeExtras ex;
+    ex.params = *params;
+    ex.in_dim = 3 + 2 * L; ex.in_dim2 = 0; ex.rad_in = 0; ex.dual = 0;
+    ex.packed = (Packed*)(ws + w.packed);
+    const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
+    ex.tile_counts = bm.tile;
+    ex.scan_ticket = scan_ticket(bm);
+    ex.n_tiles = bm.n_tiles;
+    ex.sshift = ls2fm_slab_shift(0);
+    ex.n_prep_tasks = 1;
+    ex.pts = pts;
+    ray_encode_kernel<false><<<(unsigned)(kEncReserved + 8 * most), kEncThreads, 0, s>>>(
+        make_level_set(grid), make_level_set(grid), fc, nullptr, nullptr, params->sdf_table, nullptr, w.p, w.p_pad, n_chunks, plan,
+        ws + w.e1, nullptr, ws + w.j1, ex);
+    return ls2fm_launch_status();
+}
 int ls2fm_launch_post_shade(const ls2fm_loss_spec* loss, const float* ray_part, int64_t n_rays, int n_samples,
                             const ls2fm_grid_desc* scan_grid, int64_t n_points, float* bins_ws, hipStream_t stream);
 
@@ -531,6 +567,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ex.in_dim = 3 + 2 * L1; ex.in_dim2 = 3 + 2 * L2; ex.rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1); ex.dual = dual;
     ex.packed = pk;
     ex.tile_counts = nullptr; ex.scan_ticket = nullptr; ex.n_tiles = 0; ex.sshift = ls2fm_slab_shift(dual);
+    ex.n_prep_tasks = 3; ex.pts = nullptr;
     if (prepare_bwd) {
         const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
         ex.tile_counts = bm.tile;

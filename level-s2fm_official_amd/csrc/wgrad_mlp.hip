@@ -41,11 +41,11 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
     __shared__ __attribute__((aligned(16))) float s_x[kWmWaves][kXRows * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jl = lane & 15, g = lane >> 4;
-    const int N = fc.n_samples;
     const uint32_t P32 = (uint32_t)w.p_pad;
     const float* __restrict__ f_e = ws + (GEO ? w.e2 : w.e1);
     const float* __restrict__ f_v = ws + w.v;
     const float* __restrict__ f_gf = ws + (GEO ? w.gf2 : w.gf);
+    const float* __restrict__ f_p3 = ws + w.p3;
     {
         const float* src = GEO ? &pk->bg.w0a[0][0][0] : &pk->bs.w0a[0][0][0];      // w0a then w1ta are contiguous
         constexpr int n01 = 4 * 9 * 64 + 4 * NT * 64;
@@ -92,15 +92,9 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
             vb[t] = (!GEO && on) ? f_v[(uint32_t)(3 + c) * P32 + i] : 0.f;
         }
         {
-            float pg = 0.f;
-            if (live && g < 3) {
-                const int64_t r = i / (uint32_t)N;
-                const int n = (int)(i - (uint32_t)r * (uint32_t)N);
-                const RayGeom gm = load_ray(fc, center, ray, r);
-                float p[3], x[3];
-                sample_position(fc, gm, sample_depth(gm, n, N), p, x);
-                pg = g == 0 ? p[0] : (g == 1 ? p[1] : p[2]);
-            }
+            // world position rows: written per sample by shade_bwd / the point-query backward (no ray arithmetic here: the
+            // kernel serves ray samples and free points alike)
+            const float pg = (live && g < 3) ? f_p3[(uint32_t)g * P32 + i] : 0.f;
             ub[8] = live ? (g < 3 ? pg / fc.rescale : 1.0f) : 0.f;
             vb[8] = (!GEO && live && g < 3) ? f_v[(uint32_t)g * P32 + i] : 0.f;
         }
@@ -366,7 +360,7 @@ int64_t ls2fm_wgrad_mlp_part_floats(int dual) {
 
 // enqueue every weight-gradient kernel of the backward (+ the reduction of their partials) on `s`
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
-                           const float* ray, int64_t n_rays, float* ws, hipStream_t s) {
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only) {
     const int n_tiles = (int)((w.p + 15) / 16);
     int blocks = (n_tiles + kWmWaves - 1) / kWmWaves;
     if (blocks > kWgradMlpBlocks) blocks = kWgradMlpBlocks;
@@ -383,9 +377,13 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
         ls2fm_prof_end(LS2FM_PROF_WGRAD_GEO, s);
     }
     ls2fm_prof_begin(LS2FM_PROF_WGRAD_TAIL, s);
-    wgrad_dec_kernel<<<dec_blocks, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3);
-    wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(part1, part2, part3, blocks,
-                                                                                             dec_blocks, dual, ws + w.wg);
+    if (sdf_only) {          // point queries: no decoder columns, the SDF MLP's partials only (blocks [0, kRegsSdf) of the reduction)
+        wgrad_reduce_all_kernel<<<kRegsSdf, kWmThreads, 0, s>>>(part1, part2, part3, blocks, 0, 0, ws + w.wg);
+    } else {
+        wgrad_dec_kernel<<<dec_blocks, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3);
+        wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(part1, part2, part3, blocks,
+                                                                                                 dec_blocks, dual, ws + w.wg);
+    }
     ls2fm_prof_end(LS2FM_PROF_WGRAD_TAIL, s);
     return LS2FM_OK;
 }

@@ -436,6 +436,83 @@ def sdf_eval(sdf_field, xyz, want_feat=False, want_normal=False):
     return out + (normal.view(*shape, 3),) if want_normal else out
 
 
+# ------------------------------------------------------------------------------------------------ point queries with a graph
+def can_query_points(sdf_field, xyz) -> bool:
+    """grad-enabled SDF.infer_sdf / SDF.gradient / get_surface_pts through ONE fused node (ls2fm_sdf_eval forward,
+    ls2fm_sdf_points_bwd backward); the background-sphere min and non-reference layer sizes take the composed form"""
+    if not (xyz.is_cuda and supported(sdf_field.opt, sdf_field)):
+        return False
+    opt = sdf_field.opt
+    if opt.data.inside == True and opt.data.bg_sdf == True:  # noqa: E712
+        return False
+    n = xyz.numel() // 3
+    return 0 < n <= _lib.MAX_RENDER_POINTS
+
+
+class _SdfPoints(torch.autograd.Function):
+    """xyz [...,3] -> sdf [...,1], feat [...,17], normal [...,3] (the analytic d sdf / d xyz).  All three are differentiable
+    outputs: the backward handles the normal's upstream analytically (the double backward of SDF.gradient's
+    autograd.grad(create_graph=True)), so callers may put norms of `normal` inside losses."""
+
+    @staticmethod
+    def forward(ctx, xyz, sdf_field, want_feat, want_normal, *params):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        shape = tuple(xyz.shape[:-1])
+        p = xyz.detach().reshape(-1, 3).float().contiguous()
+        n = p.shape[0]
+        dev = p.device
+        fdesc = field_desc(sdf_field.opt)
+        gdesc = sdf_field.embed_fn.embedder_obj.desc
+        for t in params:
+            if not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
+                raise RuntimeError("ls2fm: fused point query needs contiguous fp32 GPU parameters")
+        pstruct = _params_struct(list(params), False, float(sdf_field.beta_speed), with_rad=False)
+        sdf = torch.empty(n, device=dev)
+        feat = torch.empty(n, _lib.FEAT + 1, device=dev) if want_feat else None
+        normal = torch.empty(n, 3, device=dev) if want_normal else None
+        ws = _sdf_workspace(dev)
+        check(lib.ls2fm_sdf_eval(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(sdf), ptr(feat),
+                                 ptr(normal), ptr(ws), stream_ptr()), "ls2fm_sdf_eval")
+        ctx.meta = (fdesc, gdesc, float(sdf_field.beta_speed), n, tuple(xyz.shape))
+        ctx.save_for_backward(p, *params)
+        z = p.new_zeros(())
+        return (sdf.view(*shape, 1), feat.view(*shape, -1) if want_feat else z, normal.view(*shape, 3) if want_normal else z)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_sdf, d_feat, d_normal):
+        lib = _lib.load()
+        fdesc, gdesc, beta_speed, n, xyz_shape = ctx.meta
+        p, *ps = ctx.saved_tensors
+        if d_sdf is None and d_feat is None and d_normal is None:
+            return (None,) * (4 + len(ps))
+
+        def prep(t, width):
+            return None if t is None else t.reshape(-1, width).float().contiguous()
+        d_sdf, d_feat, d_normal = prep(d_sdf, 1), prep(d_feat, _lib.FEAT + 1), prep(d_normal, 3)
+        flat, grads = flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
+        grads[7].zero_()                               # beta does not enter a point query
+        gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
+        pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
+        d_p = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        ws_bytes = lib.ls2fm_sdf_points_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(gdesc), n)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
+        ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
+        check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
+                                       ptr(d_feat), ptr(d_normal), ctypes.byref(gstruct), ptr(d_p), ptr(ws), stream_ptr()),
+              "ls2fm_sdf_points_bwd")
+        return (None if d_p is None else d_p.view(xyz_shape), None, None, None, *grads)
+
+
+def query_points(sdf_field, xyz, want_feat=False, want_normal=False):
+    """-> (sdf [...,1], feat [...,17] | None, normal [...,3] | None), graph attached"""
+    ts, _ = param_tensors(sdf_field, None)
+    sdf, feat, normal = _SdfPoints.apply(xyz, sdf_field, want_feat, want_normal, *ts)
+    return sdf, (feat if want_feat else None), (normal if want_normal else None)
+
+
 def sdf_volume(sdf_field, n_side, step, origin, first=0, count=None, reference_indexing=True):
     """no-graph SDF sweep over an n_side^3 lattice built on the device (ls2fm_sdf_volume): flat float32 [count].
     step / origin: 3 doubles each, per output column; reference_indexing: the lattice arithmetic of the reference's

@@ -42,6 +42,9 @@ class SDF(nn.Module):
         self.sdf_threshold = float(vol.sdf_threshold)
         self.iters_max = int(vol.iters_max_st)
         self.scale_mlp = opt.SDF.NN_Init.scale_mlp
+        # grad-enabled infer_sdf / gradient / get_surface_pts: "fused" = one autograd node per call (ls2fm_sdf_eval forward,
+        # ls2fm_sdf_points_bwd backward), "composed" = HIP hash-grid op + torch layers + autograd's double backward
+        self.point_queries = "fused"
         self.define_network(opt)
 
     def define_network(self, opt):
@@ -62,6 +65,8 @@ class SDF(nn.Module):
     def infer_sdf(self, xyz, mode="ret_sdf"):
         if fused.can_eval_without_graph(self, xyz):
             sdf, feat = fused.sdf_eval(self, xyz, want_feat=(mode != "ret_sdf"))
+        elif self.point_queries == "fused" and fused.can_query_points(self, xyz):
+            sdf, feat, _ = fused.query_points(self, xyz, want_feat=(mode != "ret_sdf"))      # one node, fused backward
         else:
             enc = self.embed_fn(xyz, rescale=self.rescale, bound_min=self.bound_min, bound_max=self.bound_max)
             feat = self.SDF_MLP(enc)
@@ -88,6 +93,9 @@ class SDF(nn.Module):
 
     def gradient(self, p):
         """d sdf / d p, itself differentiable (callers put its norm inside losses)."""
+        if self.point_queries == "fused" and torch.is_grad_enabled() and fused.can_query_points(self, p):
+            p.requires_grad_(True)                      # the reference marks its argument (SDF.py:104, SURVEY C-9)
+            return fused.query_points(self, p, want_normal=True)[2]      # analytic normal; its backward is the fused one too
         with torch.enable_grad():
             p.requires_grad_(True)
             y = self.infer_sdf(p, mode="ret_sdf")

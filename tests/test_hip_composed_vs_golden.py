@@ -15,11 +15,17 @@ TOL = 2e-5        # fp32, different summation orders (atomics, GPU GEMMs); north
 GTOL = 1e-4
 
 
+@pytest.mark.parametrize("queries", ["fused", "composed"])
 @pytest.mark.parametrize("case", GOLDEN_CASES)
-def test_infer_sdf_gradient_double_backward(case, manifest):
+def test_infer_sdf_gradient_double_backward(case, queries, manifest):
+    """SDF.infer_sdf / gradient / get_surface_pts with a graph against the reference's own values and gradients (pts_*, surf_*
+    goldens), through the fused point-query node (ls2fm_sdf_eval + ls2fm_sdf_points_bwd) and through the composed form"""
+    from ls2fm import fused
     g = load_golden(case)
     opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
+    sdf.point_queries = queries
     pts = torch.from_numpy(g["pts"]).to(DEV)
+    assert fused.can_query_points(sdf, pts) == (case != "dtu_bgsdf")     # the background-sphere min: composed form only
     y, feat = sdf.infer_sdf(pts.clone(), mode="ret_all")
     assert rel_err(y.cpu(), g["pts_sdf"]) < TOL and rel_err(feat.cpu(), g["pts_feat"]) < TOL
     p_req = pts.clone()
