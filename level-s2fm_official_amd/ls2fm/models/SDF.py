@@ -93,11 +93,10 @@ class SDF(nn.Module):
 
     def gradient(self, p):
         """d sdf / d p, itself differentiable (callers put its norm inside losses)."""
-        if self.point_queries == "fused" and torch.is_grad_enabled() and fused.can_query_points(self, p):
+        with torch.enable_grad():                       # also under no_grad, as the reference (SDF.py:103)
             p.requires_grad_(True)                      # the reference marks its argument (SDF.py:104, SURVEY C-9)
-            return fused.query_points(self, p, want_normal=True)[2]      # analytic normal; its backward is the fused one too
-        with torch.enable_grad():
-            p.requires_grad_(True)
+            if self.point_queries == "fused" and fused.can_query_points(self, p):
+                return fused.query_points(self, p, want_normal=True)[2]  # analytic normal; its backward is the fused one too
             y = self.infer_sdf(p, mode="ret_sdf")
             (g,) = torch.autograd.grad(outputs=y, inputs=p, grad_outputs=torch.ones_like(y), create_graph=True,
                                        retain_graph=True, only_inputs=True, allow_unused=True)

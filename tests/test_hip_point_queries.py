@@ -22,7 +22,7 @@ def _scalar(sdf, pts, with_feat=True):
     n = sdf.gradient(p)
     surf, nlen = sdf.get_surface_pts(p)
     w = torch.tensor([0.3, -0.5, 0.8], device=pts.device)
-    val = ((n.norm(dim=-1) - 1) ** 2).mean() + 0.2 * (n * w).sum(-1).mean() + 0.1 * y.mean() + 0.3 * (surf ** 2).mean() \\
+    val = ((n.norm(dim=-1) - 1) ** 2).mean() + 0.2 * (n * w).sum(-1).mean() + 0.1 * y.mean() + 0.3 * (surf ** 2).mean() \
         + 0.05 * nlen.mean()
     if with_feat:
         val = val + 0.05 * (feat[..., 1:] ** 2).mean()
