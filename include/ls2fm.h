@@ -326,6 +326,17 @@ int ls2fm_adam_step(int32_t n_tensors, float* const* params, const float* const*
                     float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, void* stream);
 
+/* The same update with the schedule RESIDENT ON THE DEVICE, for optimisation steps captured into a hipGraph (a replay cannot
+ * take a new learning rate or step count from the host).  sched_state: DEVICE, 32 bytes {double step, lr, gamma; float
+ * step_size, bc2_sqrt} -- the caller initialises step = 0 (updates done so far), lr = the rate of the NEXT update and gamma =
+ * ExponentialLR's factor (utils of the stage loops: BA.py:87-88, gamma = (lr_end / lr)^(1 / max_iter)); every call first
+ * advances it (step += 1, bias corrections from the new step, lr *= gamma afterwards: optimizer.step() then scheduler.step())
+ * in a one-thread kernel, then runs the update with those values.  Replaces torch.optim.Adam.step() + ExponentialLR.step().
+ */
+int ls2fm_adam_step_scheduled(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, void* sched_state, float beta1, float beta2,
+                              float eps, float weight_decay, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the

@@ -33,8 +33,23 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - h.step_size * (m / denom);
 }
 
+// Device-resident schedule of a capturable optimizer: a hipGraph replay cannot take a new learning rate or step count from the
+// host, so both live in memory and a one-thread kernel in front of the update advances them
+//   step += 1 ; step_size = lr / (1 - b1^step) ; bc2_sqrt = sqrt(1 - b2^step) ; lr *= gamma   (torch's ExponentialLR: one
+//   multiplication per scheduler step, in double, as Python evaluates it)
+struct AdamSched { double step, lr, gamma; float step_size, bc2_sqrt; };
+
+__global__ void adam_advance_kernel(AdamSched* st, double beta1, double beta2) {
+    st->step += 1.0;
+    const double bc1 = 1.0 - pow(beta1, st->step), bc2 = 1.0 - pow(beta2, st->step);
+    st->step_size = (float)(st->lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+    st->lr *= st->gamma;
+}
+
 __global__ void __launch_bounds__(kAdamThreads)
-adam_kernel(AdamJobs jobs, AdamHyper h) {
+adam_kernel(AdamJobs jobs, AdamHyper h, const AdamSched* __restrict__ sched) {
+    if (sched) { h.step_size = sched->step_size; h.bc2_sqrt = sched->bc2_sqrt; }
     int j = 0;
     while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
     const int64_t base = (int64_t)(blockIdx.x - jobs.first_block[j]) * kAdamTile;
@@ -67,6 +82,9 @@ adam_kernel(AdamJobs jobs, AdamHyper h) {
 
 }  // namespace
 
+static int adam_launch(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, AdamHyper h, const AdamSched* sched, hipStream_t stream);
+
 extern "C" int ls2fm_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                                float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int64_t step, void* stream) {
@@ -82,6 +100,29 @@ extern "C" int ls2fm_adam_step(int32_t n_tensors, float* const* params, const fl
     h.one_minus_beta2 = (float)(1.0 - (double)beta2);
     h.eps = eps;
     h.weight_decay = weight_decay;
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, h, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ls2fm_adam_step_scheduled(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                                         float* const* exp_avg_sq, const int64_t* numel, void* sched_state, float beta1,
+                                         float beta2, float eps, float weight_decay, void* stream) {
+    LS2FM_CHECK_ARG(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)) && sched_state);
+    LS2FM_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f);
+    static_assert(sizeof(AdamSched) == 32, "ls2fm_adam_step_scheduled: sched_state is 32 bytes {double step, lr, gamma; float[2]}");
+    adam_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>((AdamSched*)sched_state, (double)beta1, (double)beta2);
+    AdamHyper h;
+    h.step_size = 0.f;
+    h.bc2_sqrt = 1.f;
+    h.w1 = (float)(1.0 - (double)beta1);
+    h.beta2 = beta2;
+    h.one_minus_beta2 = (float)(1.0 - (double)beta2);
+    h.eps = eps;
+    h.weight_decay = weight_decay;
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, h, (const AdamSched*)sched_state, (hipStream_t)stream);
+}
+
+static int adam_launch(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, AdamHyper h, const AdamSched* sched, hipStream_t stream) {
     for (int32_t t = 0; t < n_tensors;) {
         AdamJobs jobs;
         jobs.count = 0;
@@ -95,7 +136,7 @@ extern "C" int ls2fm_adam_step(int32_t n_tensors, float* const* params, const fl
             blocks += (int)((numel[t] + kAdamTile - 1) / kAdamTile);
         }
         jobs.first_block[jobs.count] = blocks;
-        if (blocks) adam_kernel<<<blocks, kAdamThreads, 0, (hipStream_t)stream>>>(jobs, h);
+        if (blocks) adam_kernel<<<blocks, kAdamThreads, 0, stream>>>(jobs, h, sched);
     }
     return ls2fm_launch_status();
 }

@@ -535,10 +535,12 @@ def sdf_volume(sdf_field, n_side, step, origin, first=0, count=None, reference_i
     return out
 
 
-def sphere_trace(sdf_field, o, d, history=False):
+def sphere_trace(sdf_field, o, d, history=False, sync=True):
     """the reference's root-find loop (SDF.py:149-200) in one kernel.
     o, d [R,3] -> near [R], far [R], pts_tracks [R,K,3], t_end [R] (far-end distance after K trips), K
-    history=True: t_end comes back as [R,K+1], the far-end distance after every trip (parity tests)"""
+    history=True: t_end comes back as [R,K+1], the far-end distance after every trip (parity tests)
+    sync=False: no host round trip -- the full track [R, iters_max + 1, 3], t_end [R, iters_max + 1] and K as a DEVICE int32[1]
+    (sharded rays: already max-reduced over the ranks); the caller masks the trips beyond K (SDF.sphere_tracing(static_trips=True))"""
     lib = _lib.load()
     o = o.detach().float().contiguous()
     d = d.detach().float().contiguous()
@@ -556,8 +558,13 @@ def sphere_trace(sdf_field, o, d, history=False):
     check(lib.ls2fm_sphere_trace(ctypes.byref(fdesc), ctypes.byref(sdf_field.embed_fn.embedder_obj.desc),
                                  ctypes.byref(pstruct), ptr(o), ptr(d), n, float(sdf_field.sdf_threshold), it, ptr(near),
                                  ptr(far), ptr(track), ptr(t_end), ptr(trips), ptr(ws), stream_ptr()), "ls2fm_sphere_trace")
-    k = int(trips.item())           # the reference syncs here too (its loop condition is a host-side .sum())
     from . import dist as _dist
+    if not sync:
+        if _dist.is_distributed():
+            import torch.distributed as tdist
+            tdist.all_reduce(trips, op=tdist.ReduceOp.MAX)
+        return near, far, track, t_end, trips
+    k = int(trips.item())           # the reference syncs here too (its loop condition is a host-side .sum())
     k = _dist.global_max_int(k, dev)                  # sharded rays: keep K identical to the single-GPU run
     pts = track[:, :max(k, 1), :]                     # K == 0: the single current point (SDF.py:201-202)
     return near, far, pts, (t_end[:, :k + 1] if history else t_end[:, k]), k

@@ -16,10 +16,17 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """``scheduled_gamma``: Adam + ExponentialLR(gamma) with the step count and learning rate RESIDENT ON THE DEVICE
+    (ls2fm_adam_step_scheduled): ``step()`` then takes nothing from the host, so a whole optimisation step -- render, loss,
+    backward, update, schedule -- can be captured into ONE hipGraph and replayed (ls2fm.stage).  ``param_groups[i]["lr"]`` is
+    kept in step on the host for logging / state_dict; do not attach a torch scheduler as well."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, scheduled_gamma=None):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.scheduled_gamma = None if scheduled_gamma is None else float(scheduled_gamma)
+        self._sched = {}            # group index -> device float64[4] = {step, lr, gamma, (step_size, bc2_sqrt as two floats)}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,6 +50,30 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = int(st["step"]) + 1
                 by_step.setdefault(st["step"], []).append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st))
+            if self.scheduled_gamma is not None:
+                if len(by_step) > 1:
+                    raise RuntimeError("ls2fm.optim.FusedAdam(scheduled_gamma=...): the parameters of a group must step together")
+                gi = self.param_groups.index(group)
+                if gi not in self._sched:
+                    first = next(iter(by_step)) - 1 if by_step else 0
+                    dev = group["params"][0].device
+                    self._sched[gi] = torch.tensor([float(first), float(group["lr"]), self.scheduled_gamma, 0.0], device=dev,
+                                                   dtype=torch.float64)
+                for step, items in by_step.items():
+                    n = len(items)
+                    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+                    numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
+                    _lib.check(lib.ls2fm_adam_step_scheduled(n, ptrs([p for p, _, _ in items]), ptrs([g for _, g, _ in items]),
+                                                             ptrs([s["exp_avg"] for _, _, s in items]),
+                                                             ptrs([s["exp_avg_sq"] for _, _, s in items]), numel,
+                                                             _lib.ptr(self._sched[gi]), float(group["betas"][0]),
+                                                             float(group["betas"][1]), float(group["eps"]),
+                                                             float(group["weight_decay"]), _lib.stream_ptr()),
+                               "ls2fm_adam_step_scheduled")
+                    for p, _, _ in items:
+                        torch.autograd.graph.increment_version(p)
+                group["lr"] = float(group["lr"]) * self.scheduled_gamma        # host mirror of the device schedule
+                continue
             for step, items in by_step.items():
                 n = len(items)
                 ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
@@ -56,3 +87,13 @@ class FusedAdam(torch.optim.Optimizer):
                 for p, _, _ in items:       # the kernel wrote through raw pointers: tell autograd (and every cache keyed
                     torch.autograd.graph.increment_version(p)       # on Tensor._version, e.g. the interleaved tables)
         return loss
+
+    def replayed(self, n=1):
+        """a captured step containing this optimizer's update was replayed n times: advance the host mirrors (state['step'],
+        param_groups[i]['lr']) the device schedule already advanced"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p in self.state and self.state[p]:
+                    self.state[p]["step"] = int(self.state[p]["step"]) + n
+            if self.scheduled_gamma is not None:
+                group["lr"] = float(group["lr"]) * self.scheduled_gamma ** n

@@ -1,0 +1,110 @@
+"""The stage drivers' optimisation step (ls2fm.stage) against
+  (a) CALLER-LEVEL GOLDENS recorded from the reference's own CameraSet.render + BA.compute_loss / summarize_loss + backward
+      (tests/golden/make_golden_caller.py: pipelines/Camera.py:448-538, BA.py:186-218) with a fixed ray pick,
+  (b) a plain-torch restatement of the same step (composed render, torch losses, torch.optim.Adam + ExponentialLR) over a
+      short trajectory -- eagerly and as ONE captured hipGraph per step (tracing, point queries, fused render + loss head,
+      backward, Adam with the schedule on the device)."""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from helpers import named_grads, options_for
+from ls2fm.models.SDF import SDF
+from ls2fm.models.RadF import RadF
+from ls2fm.models.Renderer import Renderer
+from ls2fm import stage
+from ls2fm.losses import RenderLossHead
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _product(g):
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    meta["bg_sdf"] = None
+    opt = options_for(meta, DEV)
+    sdf, rad, ren = SDF(opt).to(DEV), RadF(opt).to(DEV), Renderer(opt)
+    sdf.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sdf/")}, strict=True)
+    rad.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("rad/")}, strict=True)
+    return meta, opt, sdf, rad, ren
+
+
+@pytest.mark.parametrize("case", ["caller_dtu_dual", "caller_eth3d_single"])
+@pytest.mark.parametrize("static_trips", [False, True])
+def test_render_losses_vs_reference_caller_goldens(case, static_trips):
+    g = load_golden(case)
+    meta, opt, sdf, rad, ren = _product(g)
+    w = meta["weights"]
+    head = RenderLossHead(DEV, w_rgb=w["rgb"], w_eikonal=w["eikonal_loss"], w_dc=w["DC_Loss"])
+    centers, rays = torch.from_numpy(g["centers"]).to(DEV), torch.from_numpy(g["rays"]).to(DEV)
+    gt = torch.from_numpy(g["rgbs_gt"]).to(DEV)
+    ret = stage.render_losses(opt, ren, sdf, rad, head, centers, rays, gt, static_trips=static_trips)
+    for k in ("rgb", "depth_mlp", "normal_mlp", "sdfs_volume", "normals"):
+        assert rel_err(ret[k].cpu(), g[f"ret/{k}"]) < 2e-5, k
+    assert np.array_equal(ret["mask_bg"].cpu().numpy(), g["mask_bg"])
+    for k, key in (("rgb_loss", "rgb_loss"), ("DC_loss", "DC_loss"), ("PSNR", "PSNR"), ("eikonal_loss", "eikonal_loss"),
+                   ("loss_all", "loss_all")):
+        a, b = float(ret[k]), float(g[key])
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+    ret["loss_all"].backward()
+    for pre, mod in (("sdf", sdf), ("rad", rad)):
+        for k, v in named_grads(mod).items():
+            assert rel_err(v, g[f"grad/{pre}/{k}"]) < (5e-4 if k == "beta" else 1e-4), (pre, k)
+
+
+def _torch_step(opt, ren, sdf, rad, optim, sched, centers, rays, gt, w):
+    """the reference's lines, composed form + torch ops"""
+    optim.zero_grad(set_to_none=True)
+    ret = ren.forward_composed(opt, centers, rays, sdf, rad)
+    d_points, _, _, mask_finish = sdf.sphere_tracing(centers.view(1, -1, 3), rays.view(1, -1, 3), sdf, impl="torch")
+    depth = ret["depth_mlp"]
+    d_points = d_points.view(*depth.shape)
+    gray = gt.mean(dim=-1)
+    mask_bg = (gray < 0.95) & (gray > 0.05)
+    mask_finish = mask_finish.view(*depth.shape) & mask_bg.view(*depth.shape)
+    if mask_finish.sum() > 0:
+        dc = torch.nn.functional.smooth_l1_loss(d_points[mask_finish], depth[mask_finish], reduction="mean")
+    else:
+        dc = torch.zeros_like(d_points).mean()
+    rgb_loss = torch.nn.functional.l1_loss(ret["rgb"], gt)
+    nrm = torch.norm(ret["normals"][mask_bg], dim=-1)
+    eik = torch.nn.functional.l1_loss(nrm, torch.ones_like(nrm))
+    total = 10 ** w["rgb"] * rgb_loss + 10 ** w["eikonal_loss"] * eik + 10 ** w["DC_Loss"] * dc
+    total.backward()
+    optim.step()
+    sched.step()
+    return float(total.detach())
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_stage_trajectory_matches_plain_torch(capture):
+    g = load_golden("caller_dtu_dual")
+    meta, opt, sdf_a, rad_a, ren = _product(g)
+    _, _, sdf_b, rad_b, _ = _product(g)
+    w = dict(rgb=3, eikonal_loss=1, DC_Loss=0)
+    lr, lr_end, iters = 5e-3, 5e-4, 20
+    st = stage.RenderStage(opt, ren, sdf_a, rad_a, weights=w, lr=lr, lr_end=lr_end, max_iter=iters, eps=1e-15, capture=capture)
+    pb = list(sdf_b.parameters()) + list(rad_b.parameters())
+    ob = torch.optim.Adam(pb, lr=lr, eps=1e-15)
+    sb = torch.optim.lr_scheduler.ExponentialLR(ob, (lr_end / lr) ** (1.0 / iters))
+    gen = torch.Generator().manual_seed(5)
+    base_c, base_r = torch.from_numpy(g["centers"]).to(DEV), torch.from_numpy(g["rays"]).to(DEV)
+    gt = torch.from_numpy(g["rgbs_gt"]).to(DEV)
+    la, lb = [], []
+    for it in range(8):
+        jitter = (0.01 * torch.randn(base_r.shape, generator=gen)).to(DEV)              # new rays every step
+        c, r = base_c, (base_r + jitter).contiguous()
+        la.append(float(st.step(c, r, gt)["loss_all"]))
+        lb.append(_torch_step(opt, ren, sdf_b, rad_b, ob, sb, c, r, gt, w))
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 3e-3 * abs(y), (la, lb)                     # same trajectory (Adam amplifies last-bit noise)
+    assert la[-1] < la[0]
+    assert abs(st.optim.param_groups[0]["lr"] - ob.param_groups[0]["lr"]) < 1e-12
+    assert int(st.optim.state[st.params[0]]["step"]) == 8
+    for (n, p), q in zip(list(sdf_a.named_parameters()) + list(rad_a.named_parameters()), pb):
+        if not n.endswith("embedder_obj.params"):
+            assert rel_err(p.detach().cpu(), q.detach().cpu()) < 5e-2, n
