@@ -82,7 +82,11 @@ def main():
         opt.Renderer = MG.AttrDict(rand_rays=rand_rays)
         opt.loss_weight = MG.AttrDict(ba=dict(BA_WEIGHTS))
         sdf, rad, ren = SDF(opt), RadF(opt), Renderer(opt)
-        MG.randomize_module(sdf, gen)
+        # a MILD perturbation of the geometric initialisation: the hash path is live (non-zero table gradients) while the field
+        # stays close to a sphere SDF, so that sphere tracing converges -- on a strongly random field `t += sdf` amplifies
+        # last-bit differences of the field evaluation every trip and d_points / mask_finish (hence DC_loss) would not be
+        # reproducible by ANY second implementation (tests/test_hip_sphere_trace_parity.py measures that)
+        MG.randomize_module(sdf, gen, table_amp=0.02, w_std=0.01)
         MG.randomize_module(rad, gen)
         s = (opt.data.bound_max[0] - opt.data.bound_min[0]) / 2
         n_views = 2
@@ -134,6 +138,7 @@ def main():
         out["meta_json"] = np.frombuffer(__import__("json").dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
         os.unlink(hash_json)
+        out["trips_note"] = np.int32(0)
         print(f"[golden] {name}: rgb_loss={ret.rgb_loss.item():.6f} DC={ret.DC_loss.item():.6f} PSNR={ret.PSNR.item():.4f} "
               f"eik={eik.item():.5f} all={loss.all.item():.4f} mask_bg={int(ret.mask_bg.sum())}/{ret.mask_bg.numel()}")
 
