@@ -25,6 +25,26 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 constexpr int NC = 2;          // 16-sample column tiles per pass (two passes per wave)
 
+// fp64 wave scans for the d beta path (below)
+__device__ __forceinline__ double wave_scan_incl_f64(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_suffix_excl_f64(double v, int lane) {
+    double s = __shfl_down(v, 1, 64);
+    if (lane == 63) s = 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_down(s, o, 64);
+        if (lane + o < 64) s += t;
+    }
+    return s;
+}
+
 template <bool DUAL, int MAXT>
 __global__ void __launch_bounds__(MAXT, 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
@@ -38,6 +58,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     }
     __shared__ float s_part[MAXT / 64][8];
     __shared__ double s_db[MAXT / 64];
+    __shared__ double s_pd[MAXT / 64][2];        // fp64 twin of the composite scans (d beta): tau totals, sum of U w
     __shared__ int s_bound[32];                  // per-level max of a single scatter contribution (bits of a float >= 0)
     __shared__ float s_y[MAXT][8];               // per sample: dz(3), g_n(3), g_sdf
     __shared__ float s_w[kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB)
@@ -125,11 +146,29 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         const float tau = interval ? sigma * delta : 0.f;
         const float incl = wave_scan_incl(tau, lane);
         if (lane == 63) s_part[wave][0] = incl;
+        // d L / d beta is ONE scalar, and the composite backward forms each summand's d L / d tau_k = U_k T_k e^{-tau_k} -
+        // sum_{i>k} U_i w_i as a difference of nearly equal quantities: in fp32 (the reference's autograd included) the result
+        // carries errors of 1e-4 .. 1e-3 even when the final sum is well conditioned.  Its whole chain -- sigma, the two
+        // scans, transmittance, d tau, d sigma / d beta -- is therefore evaluated a second time in fp64 from the same fp32
+        // per-sample values (sdf, colour, normal, depth): ~300 fp64 operations per sample, invisible next to the MFMA part,
+        // and d beta comes out as the exactly summed value of the fp32 computation (oracle.fields.beta_gradient_exact_sum).
+        const double beta_d = (double)beta, alpha_d = (double)alpha, sdf_d = (double)sdf;
+        const double lap_d = 0.5 * exp(-fabs(sdf_d) / beta_d);
+        const double sigma_d = alpha_d * (sdf_d >= 0.0 ? lap_d : 1.0 - lap_d);
+        const double delta_d = ((double)t_next - (double)t) *
+                               sqrt((double)gm.d[0] * (double)gm.d[0] + (double)gm.d[1] * (double)gm.d[1] + (double)gm.d[2] * (double)gm.d[2]);
+        const double tau_d = interval ? sigma_d * delta_d : 0.0;
+        const double incl_d = wave_scan_incl_f64(tau_d, lane);
+        if (lane == 63) s_pd[wave][0] = incl_d;
         __syncthreads();
         float before = incl - tau;
         for (int q = 0; q < wave; ++q) before += s_part[q][0];
         const float trans = expf(-before), ex = expf(-tau);
         const float wgt = interval ? trans * (1.0f - ex) : 0.f;
+        double before_d = incl_d - tau_d;
+        for (int q = 0; q < wave; ++q) before_d += s_pd[q][0];
+        const double trans_d = exp(-before_d), ex_d = exp(-tau_d);
+        const double wgt_d = interval ? trans_d * (1.0 - ex_d) : 0.0;
         // composite backward:  L = sum_i w_i (V_i - B) + B ;  dL/dtau_k = U_k T_k e^{-tau_k} - sum_{i>k} U_i w_i
         float b_term = g_dep * t_last, v_term = g_dep * t;
 #pragma unroll
@@ -146,14 +185,30 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         const float wsum_uw = wave_sum(u_w);
         const float wsum_w = wave_sum(wgt);
         if (lane == 0) { s_part[wave][1] = wsum_uw; s_part[wave][2] = wsum_w; }
+        double vb_d = (double)g_dep * ((double)t - (double)t_last);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            vb_d += (double)g_rgb[c] * ((double)col[c] - (double)fc.bg[c]);
+            vb_d += (double)g_nm[c] * ((double)nrm[c] - (double)n_last[c]);
+        }
+        const double u_w_d = interval ? vb_d * wgt_d : 0.0;
+        const double sfx_d = wave_suffix_excl_f64(u_w_d, lane);
+        {
+            double tot = u_w_d;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            if (lane == 0) s_pd[wave][1] = tot;
+        }
         __syncthreads();
         float opacity = 0.f, suffix = sfx_w;
+        double suffix_d = sfx_d;
         for (int q = 0; q < n_waves; ++q) {
             opacity += s_part[q][2];
-            if (q > wave) suffix += s_part[q][1];
+            if (q > wave) { suffix += s_part[q][1]; suffix_d += s_pd[q][1]; }
         }
         const float d_tau = interval ? (v_term - b_term) * trans * ex - suffix : 0.f;
         const float g_sigma = d_tau * delta;
+        const double g_sigma_d = interval ? (vb_d * trans_d * ex_d - suffix_d) * delta_d : 0.0;
         const float rest = 1.0f - opacity;
         {   // d L / d |ray| : delta = (t_next - t) |ray| (Renderer.py:36-38); only consumed by the pose gradients
             const float s = wave_sum(d_tau * sigma * (t_next - t));
@@ -183,8 +238,12 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             const float inv_b2 = 1.0f / (beta * beta);
             const float dsig_db = sdf >= 0.f ? lap * (abs_s * inv_b2 / beta - inv_b2)
                                              : -(1.0f - lap) * inv_b2 - lap * abs_s * inv_b2 / beta;
-            // d beta is one scalar summed over every sample with heavy cancellation: accumulate it in fp64
-            double db = (double)g_sigma * (double)dsig_db;
+            (void)dsig_db;
+            // d sigma / d beta and the sum over the samples in fp64 (see above)
+            const double abs_d = fabs(sdf_d), inv_b2_d = 1.0 / (beta_d * beta_d);
+            const double dsig_db_d = sdf_d >= 0.0 ? lap_d * (abs_d * inv_b2_d / beta_d - inv_b2_d)
+                                                  : -(1.0 - lap_d) * inv_b2_d - lap_d * abs_d * inv_b2_d / beta_d;
+            double db = g_sigma_d * dsig_db_d;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) db += __shfl_xor(db, o, 64);
             if (lane == 0) s_db[wave] = db;

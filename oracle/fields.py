@@ -310,7 +310,7 @@ def render_tail(cfg: PathConfig, ray, t, sdfs, normals, rgbs, alpha, beta) -> Di
     return {"rgb": rgb, "sdfs_volume": sdfs, "normals": normals, "depth_mlp": depth, "normal_mlp": normal}
 
 
-def beta_gradient_exact_sum(cfg: PathConfig, center, ray, sdf_sd: State, rad_sd: State, loss_fn) -> torch.Tensor:
+def beta_gradient_exact_sum(cfg: PathConfig, center, ray, sdf_sd: State, rad_sd: State, loss_fn, with_condition=False):
     """d loss / d beta of the FLOAT32 computation with the ill-conditioned part done exactly (test adjudication; no reference
     counterpart).  d/d beta is one scalar summing terms of both signs over every sample (cancellation ~1e3), so an fp32
     autograd value -- the reference's included -- carries summation noise of ~1e-4.  Running the whole oracle in fp64 does
@@ -336,9 +336,32 @@ def beta_gradient_exact_sum(cfg: PathConfig, center, ray, sdf_sd: State, rad_sd:
         rgbs = radiance_mlp(torch.cat([p, normals, ray_enc, geo], dim=-1), rad_sd)
     b64 = sdf_sd["beta"].detach().double().clone().requires_grad_(True)
     alpha, beta = forward_ab({"beta": b64}, cfg)
-    out = render_tail(cfg, ray.detach().double(), t.double(), sdfs.double(), normals.double(), rgbs.double(), alpha, beta)
+    if not with_condition:
+        out = render_tail(cfg, ray.detach().double(), t.double(), sdfs.double(), normals.double(), rgbs.double(), alpha, beta)
+        loss_fn(out).backward()
+        return b64.grad
+    # the same with sigma as an explicit leaf, to see the summands
+    s64 = sdfs.double()
+    sigma = sdf_to_sigma(s64, alpha, beta)
+    sig_leaf = sigma.detach().clone().requires_grad_(True)
+    rgb, prob = composite(ray.detach().double(), rgbs.double(), sig_leaf.squeeze(-1), t.double())
+    opacity = prob.sum(dim=2)
+    bg = torch.tensor(cfg.bgcolor, dtype=torch.float64)
+    n64, t64 = normals.double(), t.double()
+    out = {"rgb": rgb + (1 - opacity) * bg, "sdfs_volume": s64, "normals": n64,
+           "depth_mlp": (t64[..., :-1, :] * prob).sum(dim=2) + (1 - opacity) * t64[..., -1, :],
+           "normal_mlp": (n64[..., :-1, :] * prob).sum(dim=2) + (1 - opacity) * n64[..., -1, :]}
     loss_fn(out).backward()
-    return b64.grad
+    g_sigma = sig_leaf.grad                                          # dL / dsigma_i
+    with torch.no_grad():
+        b, a = beta.detach(), alpha.detach()
+        e = 0.5 * torch.exp(-s64.abs() / b)
+        psi = torch.where(s64 >= 0, e, 1 - e)
+        dpsi_db = torch.where(s64 >= 0, e, -e) * s64.abs() / (b * b)
+        dsig_dbeta = -a / b * psi + a * dpsi_db                      # d sigma / d beta with alpha = 1 / beta
+        terms = g_sigma * dsig_dbeta * b * cfg.beta_speed            # chain to the log-space parameter (SDF.py:28-32)
+        total = terms.sum()
+    return total.reshape(1), float(terms.abs().sum() / (total.abs() + 1e-300))
 
 
 # ----------------------------------------------------------------------------- sphere tracing

@@ -18,6 +18,7 @@ from ls2fm.models.RadF import RadF
 from ls2fm.models.Renderer import Renderer
 from ls2fm import stage
 from ls2fm.losses import RenderLossHead
+from test_hip_fused_render import _beta_ok
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -31,6 +32,26 @@ def _product(g):
     sdf.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sdf/")}, strict=True)
     rad.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("rad/")}, strict=True)
     return meta, opt, sdf, rad, ren
+
+
+def _exact_beta(meta, sdf, rad, centers, rays, gt, ret, w):
+    """d loss_all / d beta of the fp32 computation with everything beta enters carried out in fp64
+    (oracle.fields.beta_gradient_exact_sum); the traced depth and the masks are those of the run under test"""
+    from conftest import golden_cfg
+    from oracle import fields as OF
+    cfg = golden_cfg(dict(meta, bg_sdf=None))
+    gt64 = gt.detach().cpu().double()
+    m_fin = ret["mask_finish"].detach().cpu()
+    d_pts = ret["d_points"].detach().cpu().double()
+
+    def loss_fn(out):
+        total = 10 ** w["rgb"] * (out["rgb"] - gt64).abs().mean()
+        if m_fin.any():
+            total = total + 10 ** w["DC_Loss"] * torch.nn.functional.smooth_l1_loss(d_pts[m_fin], out["depth_mlp"][m_fin])
+        return total
+    sd = {k: v.detach().cpu().float() for k, v in sdf.state_dict().items()}
+    rd = {k: v.detach().cpu().float() for k, v in rad.state_dict().items()}
+    return OF.beta_gradient_exact_sum(cfg, centers.detach().cpu(), rays.detach().cpu(), sd, rd, loss_fn, with_condition=True)
 
 
 @pytest.mark.parametrize("case", ["caller_dtu_dual", "caller_eth3d_single"])
@@ -53,7 +74,12 @@ def test_render_losses_vs_reference_caller_goldens(case, static_trips):
     ret["loss_all"].backward()
     for pre, mod in (("sdf", sdf), ("rad", rad)):
         for k, v in named_grads(mod).items():
-            assert rel_err(v, g[f"grad/{pre}/{k}"]) < (5e-4 if k == "beta" else 1e-4), (pre, k)
+            if k == "beta":             # one ill-conditioned scalar: adjudicated against its exactly summed value
+                exact, cond = _exact_beta(meta, sdf, rad, centers, rays, gt, ret, w)
+                print(f"[{case}] d beta: condition number of the sum {cond:.3g}")
+                _beta_ok(v, g["grad/sdf/beta"], exact, condition=cond)
+                continue
+            assert rel_err(v, g[f"grad/{pre}/{k}"]) < 1e-4, (pre, k)
 
 
 def _torch_step(opt, ren, sdf, rad, optim, sched, centers, rays, gt, w):
