@@ -217,6 +217,7 @@ int ls2fm_interleave_tables(const float* sdf_table, const float* rad_table, int6
  *   inference_only  forward: non-zero = no ls2fm_render_bwd will follow on this workspace.  Otherwise the forward's gather
  *                   pass also counts the items of the backward's table-gradient scatter (the corner cells are known there
  *                   anyway) and scans them beside shade_fwd, so the backward starts its scatter without a counting pass.
+ *   n_level_groups, group_events   see the struct.
  *   loss            the loss head of the stage loops evaluated INSIDE the render (SURVEY.md section 8f row 1 "fuse as an
  *                   epilogue of the render kernel"; replaces pipelines/Camera.py:515-537 + BA.py:206-218 exactly as
  *                   ls2fm_loss_head_fwd/bwd below do, same tensors, same `terms` / `sums` layout): the forward's last kernel
@@ -241,9 +242,16 @@ typedef struct ls2fm_loss_spec {
     float* d_depth_ref;           /* backward output: [n_rays] gradient w.r.t. depth_ref (overwritten), or NULL */
 } ls2fm_loss_spec;
 
+#define LS2FM_MAX_LEVEL_GROUPS 4
 typedef struct ls2fm_render_opts {
     int32_t inference_only;
     const ls2fm_loss_spec* loss;  /* NULL: no fused loss head */
+    /* backward, multi-GPU runs: scatter the table gradients in n_level_groups (2..4) groups of consecutive levels -- group g
+     * holds levels [L g / n, L (g + 1) / n) -- and record group_events[g] (hipEvent_t, may be NULL) on `stream` once group g's
+     * slices of the gradient tables are final, so that their all-reduce overlaps with the scatter of the later groups.
+     * 0 / 1: one pass, no events. */
+    int32_t n_level_groups;
+    void* group_events[LS2FM_MAX_LEVEL_GROUPS];
 } ls2fm_render_opts;
 
 int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(kFillThreads)
 scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
                     int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
                     const float* __restrict__ rec2, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad,
-                    BinMeta bm) {
+                    BinMeta bm, int level_base) {
     __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
     __shared__ int lds_off[kBins];       // first LDS slot of the slab's run
     __shared__ int base[kBins];          // first global item index of the slab's run
@@ -50,7 +50,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     __shared__ Item s_items[kFillCap];
     __shared__ uint32_t s_gidx[kFillCap];
     __shared__ int s_total;
-    const int tid = threadIdx.x, lane = tid & 63, l = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, l = level_base + (int)blockIdx.y;
     for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
     __syncthreads();
     const LevelC L = make_level_c(lv, l, sshift);
@@ -182,15 +182,16 @@ __device__ long long g_acc_stamps[8 * 4096];
 template <bool DUAL>
 __global__ void __launch_bounds__(kAccThreads)
 slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
-                       float* __restrict__ dtable2) {
+                       float* __restrict__ dtable2, int block_base) {
     constexpr int F = DUAL ? 4 : 2;
     __shared__ u64 acc[kAccSlots];
     const int tid = threadIdx.x;
     ACC_STAMP(0);
+    const int bid = block_base + (int)blockIdx.x;        // a launch may cover a range of levels only (ls2fm_render_opts level groups)
     int l = 0;
-    while ((int)blockIdx.x >= plan.first[l + 1]) ++l;
+    while (bid >= plan.first[l + 1]) ++l;
     const int parts = plan.parts[l];
-    const uint32_t wg = blockIdx.x - plan.first[l];
+    const uint32_t wg = bid - plan.first[l];
     const uint32_t slab = wg / parts;
     const int part = (int)(wg % parts);
     const uint32_t size = lv.size[l];
@@ -282,14 +283,16 @@ bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual) { return level
 // payloads from shade_bwd's records, sorted by slab
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
-                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream) {
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo, int level_hi) {
     const int64_t r_pad = (n_rays + 63) / 64 * 64;
     const int sshift = ls2fm_slab_shift(dual);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
-    const dim3 g((unsigned)bm.n_tiles, (unsigned)grid->n_levels);
-    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm);
-    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm);
+    if (level_hi < 0) level_hi = grid->n_levels;
+    if (level_hi <= level_lo) return LS2FM_OK;
+    const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo));
+    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo);
+    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo);
     return ls2fm_launch_status();
 }
 
@@ -345,15 +348,18 @@ extern "C" int ls2fm_debug_acc_stamps(long long* host) {
 // dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid; ls2fm_launch_scatter_zero must
 // have run on them before.
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int level_lo, int level_hi) {
     const bool dual = dtable2 != nullptr;
     const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
     const HostPlan h = make_plan(grid, n_points, sshift);
+    if (level_hi < 0) level_hi = grid->n_levels;
+    const int base = h.plan.first[level_lo], blocks = h.plan.first[level_hi] - base;
+    if (blocks <= 0) return LS2FM_OK;
     if (dual)
-        slab_accumulate_kernel<true><<<h.total, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, dtable2);
+        slab_accumulate_kernel<true><<<blocks, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, dtable2, base);
     else
-        slab_accumulate_kernel<false><<<h.total, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, nullptr);
+        slab_accumulate_kernel<false><<<blocks, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, nullptr, base);
     return ls2fm_launch_status();
 }

@@ -174,9 +174,9 @@ int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grad
 // ------------------------------------------------------------------------------------------- C ABI
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
-                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream);
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int level_lo = 0, int level_hi = -1);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -238,18 +238,30 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
 
-    // hash-table gradients: LDS-owned slabs walking their binned item lists (bin_scatter.hip); tables overwritten in full
+    // hash-table gradients: payloads sorted by slab (scatter_fill), then one streaming pass per LDS-owned slab
+    // (slab_accumulate; bin_scatter.hip); tables overwritten in full; dual field: both grids share geometry, hence items.
+    // opts->n_level_groups > 1 (multi-GPU runs): the levels are processed in that many consecutive groups and an event is
+    // recorded after each group's accumulate, so that the caller can start all-reducing a group's slices of the gradient
+    // tables while the later groups are still being scattered.
     {
-        // payloads sorted by slab, then one streaming pass per slab; dual field: both grids share geometry, hence items
-        ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
-        int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
-                                           ws + w.rpt, ws + w.smax, n_rays, dual, s);
-        ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
-        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
-        ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
-        st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s);
-        ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
-        if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+        int groups = opts ? opts->n_level_groups : 1;
+        groups = groups < 1 ? 1 : (groups > LS2FM_MAX_LEVEL_GROUPS ? LS2FM_MAX_LEVEL_GROUPS : groups);
+        if (groups > L1) groups = L1;
+        for (int gi = 0; gi < groups; ++gi) {
+            const int lo = L1 * gi / groups, hi = L1 * (gi + 1) / groups;
+            ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
+            int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
+                                               ws + w.rpt, ws + w.smax, n_rays, dual, s, lo, hi);
+            ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
+            if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+            ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
+            st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s, lo, hi);
+            ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
+            if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+            if (opts && opts->n_level_groups > 1 && opts->group_events[gi] &&
+                hipEventRecord((hipEvent_t)opts->group_events[gi], s) != hipSuccess)
+                return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
+        }
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();

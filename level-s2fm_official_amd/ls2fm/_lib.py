@@ -85,7 +85,8 @@ class LossSpec(Structure):
 
 
 class RenderOpts(Structure):
-    _fields_ = [("inference_only", c_int32), ("loss", POINTER(LossSpec))]
+    _fields_ = [("inference_only", c_int32), ("loss", POINTER(LossSpec)), ("n_level_groups", c_int32),
+                ("group_events", c_void_p * 4)]
 
 
 _P = c_void_p

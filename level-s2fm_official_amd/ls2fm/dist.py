@@ -76,6 +76,47 @@ def global_max_int(value: int, device) -> int:
     return int(t.item())
 
 
+# ---- overlapped reduction of the table gradients ----------------------------------------------------------------------------
+# One step's gradient message is ~105 MB (two 12-13 M-entry fp32 tables), as long on 7 xGMI links as the step itself, and all of
+# it is produced by the LAST kernels of the backward.  With `enable_table_overlap` the fused backward scatters the levels in
+# n groups (ls2fm_render_opts.n_level_groups), records an event per group, and issues that group's all-reduce of both tables'
+# slices on a communication stream right away: the exchange of the first groups runs beside the scatter of the later ones.
+_COMM_STREAMS = {}
+
+
+def comm_stream(device) -> torch.cuda.Stream:
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _COMM_STREAMS:
+        _COMM_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _COMM_STREAMS[idx]
+
+
+def enable_table_overlap(sdf_field, rad_field=None, n_groups: int = 2) -> None:
+    """mark the hash tables of these fields: their gradients are all-reduced group by group from inside the fused backward
+    (GradAllReducer.all_reduce then only waits for those and reduces the small tensors).  n_groups in 2..4; 0 / 1 turns it off"""
+    tables = [sdf_field.embed_fn.embedder_obj.params]
+    if rad_field is not None and hasattr(rad_field, "embed_fn"):
+        tables.append(rad_field.embed_fn.embedder_obj.params)
+    for t in tables:
+        t._ls2fm_overlap_groups = int(n_groups)
+
+
+def launch_group_reductions(flat, tables, level_offsets, events, n_levels):
+    """called by the fused backward after its kernels are enqueued: tables = gradient views (1-D, inside `flat`) of the hash
+    tables, level_offsets[l] = first ENTRY of level l, events[g] recorded when group g's levels are final"""
+    n = len(events)
+    comm = comm_stream(flat.device)
+    pending = []
+    for gi, ev in enumerate(events):
+        lo, hi = 2 * int(level_offsets[n_levels * gi // n]), 2 * int(level_offsets[n_levels * (gi + 1) // n])
+        comm.wait_event(ev)
+        with torch.cuda.stream(comm):
+            for t in tables:
+                pending.append(dist.all_reduce(t[lo:hi], async_op=True))
+    flat._ls2fm_pending = (pending, [(t.data_ptr(), t.numel()) for t in tables])
+
+
 class GradAllReducer:
     """Sum-all-reduce of `.grad` of a parameter list.  When every gradient already lives in one flat buffer (the fused
     backward allocates them that way and attaches the buffer to the Parameters, ls2fm.fused.flat_gradient_views) that
@@ -118,6 +159,22 @@ class GradAllReducer:
             return
         world = dist.get_world_size()
         whole = self._all_in_flat()
+        pending = getattr(whole, "_ls2fm_pending", None) if whole is not None else None
+        if pending is not None:                            # the tables are already on their way (enable_table_overlap)
+            handles, spans = pending
+            whole._ls2fm_pending = None
+            base = whole.data_ptr()
+            cuts = sorted(((ptr - base) // 4, (ptr - base) // 4 + n) for ptr, n in spans)
+            at, rest = 0, []
+            for lo, hi in cuts + [(whole.numel(), whole.numel())]:
+                if lo > at:
+                    rest.append(dist.all_reduce(whole[at:lo], async_op=True))      # the small tensors between / after the tables
+                at = max(at, hi)
+            for h in handles + rest:
+                h.wait()
+            if self.average:
+                whole.div_(world)
+            return
         if whole is not None:                              # one message: both tables and every small tensor
             dist.all_reduce(whole)
             if self.average:

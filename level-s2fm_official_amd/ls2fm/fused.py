@@ -376,6 +376,19 @@ class _Render(torch.autograd.Function):
         fl, dref, sums, dref_shape = ctx.loss
         opts = _lib.RenderOpts()
         d_dref = None
+        # multi-GPU: scatter the levels in groups and all-reduce a group's table slices while the next group is scattered
+        from . import dist as _dist
+        n_groups = int(getattr(ps[0], "_ls2fm_overlap_groups", 0)) if _dist.is_distributed() else 0
+        events = []
+        if n_groups > 1:
+            n_groups = min(n_groups, 4, g1.n_levels)
+            cur = torch.cuda.current_stream()
+            for gi in range(n_groups):
+                ev = torch.cuda.Event()
+                ev.record(cur)                     # materialises the handle (torch creates events lazily)
+                events.append(ev)
+                opts.group_events[gi] = ev.cuda_event
+            opts.n_level_groups = n_groups
         if fl is not None and (d_terms is not None or d_total is not None):
             if dref is not None and ctx.needs_input_grad[2]:
                 d_dref = torch.empty_like(dref)
@@ -385,6 +398,9 @@ class _Render(torch.autograd.Function):
                                    ctypes.byref(pstruct), ptr(c), ptr(d), ctx.n_rays, ptr(d_rgb), ptr(d_sdfs),
                                    ptr(d_normals), ptr(d_depth), ptr(d_nmlp), ctypes.byref(gstruct), ptr(d_center), ptr(d_ray),
                                    ptr(ctx.ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_bwd")
+        if events:
+            tables = [grads[0]] + ([grads[_RAD_TABLE_AT]] if dual else [])
+            _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels)
         if want_pose:
             d_center, d_ray = d_center.view(ctx.pose_shape), d_ray.view(ctx.pose_shape)
         if d_dref is not None:

@@ -1,0 +1,89 @@
+"""Two processes on ONE GPU (gloo backend over device tensors: the box has a single MI355X, RCCL refuses two ranks per device):
+the benchmark's data-parallel step -- rays sharded by view, fused render with the loss head inside (global counts),
+backward, gradient all-reduce (one flat message; and the overlapped form: table slices reduced level group by level group
+from inside the backward) -- must give every rank the gradients of the single-process run over all rays."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _step(opt, sdf, rad, ren, head, center, ray, gt, dref, masks):
+    for p in list(sdf.parameters()) + list(rad.parameters()):
+        p.grad = None
+    ret, loss = ren.forward_with_loss(opt, center, ray, sdf, rad, head, gt, d_points=dref, **masks)
+    loss["all"].backward()
+    return loss
+
+
+def _worker(rank, world, port, overlap, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "level-s2fm_official_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    from ls2fm import dist as ldist
+    from ls2fm.losses import RenderLossHead
+    from ls2fm.options import make_options
+    from test_hip_fused_render import _randomized, _rays
+    from helpers import named_grads
+    n_rays = 256
+    opt = make_options("BlendedMVS", device=dev, dual_field=True, sample_intvs=32)
+    sdf, rad, ren = _randomized(opt, 111)                                   # identical replicas on every rank
+    center, ray = _rays(n_rays, 2.0, 112)
+    g = torch.Generator().manual_seed(113)
+    gt = torch.rand(1, n_rays, 3, generator=g).to(dev)
+    dref = (torch.rand(1, n_rays, generator=g) * 4).to(dev)
+    mfin = (torch.rand(1, n_rays, generator=g) < 0.5).to(dev)
+    mfin[:, : n_rays // 2] = False                                          # unbalanced between the ranks
+    mbg = (torch.rand(1, n_rays, generator=g) < 0.8).to(dev)
+    head = RenderLossHead(dev, 3.0, 2.0, 1.0, global_counts="allreduce")
+    # ---- single-process reference over all rays (before the process group exists)
+    full_loss = _step(opt, sdf, rad, ren, head, center, ray, gt, dref, dict(mask_finish=mfin, mask_eik=mbg, mask_bg=mbg))
+    full = {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
+    full_terms = {k: float(v) for k, v in full_loss.items()}
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if overlap:
+            ldist.enable_table_overlap(sdf, rad, n_groups=3)
+        sl = slice(rank * n_rays // world, (rank + 1) * n_rays // world)
+        c, r = ldist.shard_rays(center, ray)
+        assert torch.equal(c, center[:, sl])
+        loss = _step(opt, sdf, rad, ren, head, c.contiguous(), r.contiguous(), gt[:, sl].contiguous(), dref[:, sl].contiguous(),
+                     dict(mask_finish=mfin[:, sl], mask_eik=mbg[:, sl], mask_bg=mbg[:, sl]))
+        params = list(sdf.parameters()) + list(rad.parameters())
+        red = ldist.GradAllReducer(params)
+        assert red._all_in_flat() is not None                     # one flat buffer: no packing
+        assert (getattr(red._all_in_flat(), "_ls2fm_pending", None) is not None) == overlap
+        red.all_reduce()
+        torch.cuda.synchronize()
+        got = {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
+        from conftest import rel_err
+        for k in full:
+            assert rel_err(got[k], full[k]) < (2e-4 if k == "s.beta" else 2e-5), k
+        for k in ("rgb_loss", "eikonal_loss", "DC_loss", "all"):          # every rank reports the global means
+            assert abs(float(loss[k]) - full_terms[k]) <= 1e-5 * max(1.0, abs(full_terms[k])), k
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_one_gpu_reproduce_the_single_process_gradients(overlap, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), overlap, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
