@@ -153,6 +153,8 @@ def main():
                          "wins by ~5 %% when the host keeps up, the graph wins when the host CPU is slow or busy)")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce after the backward instead of the "
+                    "level-group reductions issued from inside it")
     ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
     args = ap.parse_args()
     preset = CONFIGS[args.config]
@@ -182,7 +184,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from ls2fm import _lib, fused
-    from ls2fm.dist import GradAllReducer
+    from ls2fm.dist import GradAllReducer, enable_table_overlap
     from ls2fm.options import make_options
     from ls2fm.models.SDF import SDF
     from ls2fm.models.RadF import RadF
@@ -199,6 +201,10 @@ def main():
     assert fused.can_render(ren, opt, center, ray, sdf, rad), "fused HIP path not taken"
     params = list(sdf.parameters()) + list(rad.parameters())
     reducer = GradAllReducer(params) if multi else None
+    if multi and not args.no_overlap:
+        # the ~105 MB gradient exchange is as long as the step on 7 xGMI links and all of it comes out of the backward's last
+        # kernels: scatter the levels in 4 groups and all-reduce a group's table slices while the next ones are scattered
+        enable_table_overlap(sdf, rad, n_groups=4)
 
     from ls2fm.losses import RenderLossHead
     from ls2fm.graph import CapturedStep
@@ -224,6 +230,8 @@ def main():
         return loss
 
     mode = "graph" if args.graph else args.launch
+    if multi and mode != "graph":
+        mode = "eager"                  # collectives are issued from inside the backward: keep them out of graph captures
     # every step -- eager or captured -- runs on ONE non-default stream: autograd's gradient accumulators stay tied to
     # the stream of their first backward, and mixing streams costs synchronisations (and breaks captures)
     s_main = torch.cuda.Stream(device=dev)
