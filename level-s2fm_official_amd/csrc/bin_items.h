@@ -10,8 +10,11 @@ namespace {
 constexpr int kAccSlots = 2 << kSlabShift;       // 16384 u64 accumulators = 128 KiB of LDS per workgroup
 constexpr int kSlabBins = 128;                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
 constexpr int kBins = kSlabBins;
-constexpr int kCountThreads = 512;
-constexpr int kFillThreads = 512;                // one sample point per thread
+#ifndef LS2FM_FILL_TILE
+#define LS2FM_FILL_TILE 256
+#endif
+constexpr int kCountThreads = LS2FM_FILL_TILE;
+constexpr int kFillThreads = LS2FM_FILL_TILE;    // one sample point per thread
 constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
 constexpr int kAccThreads = 1024;
 constexpr int kMaxParts = 16;

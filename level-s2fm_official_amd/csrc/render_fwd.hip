@@ -229,7 +229,9 @@ struct EncodeExtras {
     const float* pts;         // [n,3] free points instead of ray samples (point queries), or null
 };
 
-constexpr int kEncThreads = kFillTile;       // 512: one workgroup = one (level, tile of the scatter's counting sort)
+constexpr int kEncThreads = 512;             // sample points of one level per workgroup = kEncRows tiles of the scatter's counting sort
+constexpr int kEncRows = kEncThreads / kFillTile;
+static_assert(kEncThreads % kFillTile == 0, "a gather workgroup covers whole tiles");
 constexpr int kEncReserved = 8;              // leading workgroups (a multiple of 8: block -> XCD mapping stays b % 8)
 
 // position of sample i, its cell on the level, the 8 corner entries (absolute) and fractions
@@ -266,7 +268,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                   const float* __restrict__ table1, const float* __restrict__ table2, int64_t n_points, int64_t p_pad,
                   int n_chunks, XcdPlan plan, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac,
                   EncodeExtras ex) {
-    __shared__ int hist[kBins];
+    __shared__ int hist[kEncRows][kBins];
     const int tid = threadIdx.x;
     if (blockIdx.x < kEncReserved) {
         if (ex.packed && (int)blockIdx.x < ex.n_prep_tasks)
@@ -293,7 +295,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     lv.hashed = second ? lv2.hashed[l] : lv1.hashed[l];
     const bool counting = ex.tile_counts != nullptr && !second;          // workgroup-uniform
     if (counting) {
-        for (int b = tid; b < kBins; b += kEncThreads) hist[b] = 0;
+        for (int b = tid; b < kEncRows * kBins; b += kEncThreads) (&hist[0][0])[b] = 0;
         __syncthreads();
     }
     const int64_t i = (int64_t)chunk * kEncThreads + tid;
@@ -370,15 +372,18 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
             for (int cp = 0; cp < 4; ++cp) {
                 const uint32_t i0 = c.idx[2 * cp] - lv.offset, i1 = c.idx[2 * cp + 1] - lv.offset;
                 const uint32_t s0 = i0 >> ex.sshift, s1 = i1 >> ex.sshift;
-                atomicAdd(&hist[s0], 1);
-                if (s1 != s0) atomicAdd(&hist[s1], 1);       // split pair: two half items
+                atomicAdd(&hist[tid / kFillTile][s0], 1);
+                if (s1 != s0) atomicAdd(&hist[tid / kFillTile][s1], 1);       // split pair: two half items
             }
         }
     }
     if (counting) {
         __syncthreads();
-        int* row = ex.tile_counts + ((int64_t)l * ex.n_tiles + chunk) * kBins;
-        for (int b = tid; b < kBins; b += kEncThreads) row[b] = hist[b];
+        // tiles kEncRows * chunk .. + kEncRows - 1 of this level (rows beyond the last tile: never read)
+        for (int b = tid; b < kEncRows * kBins; b += kEncThreads) {
+            const int tile = kEncRows * chunk + b / kBins;
+            if (tile < ex.n_tiles) ex.tile_counts[((int64_t)l * ex.n_tiles + tile) * kBins + b % kBins] = hist[b / kBins][b % kBins];
+        }
     }
 #ifdef LS2FM_STAMPS
     __syncthreads();
