@@ -67,6 +67,15 @@ def globalize_loss_sums(sums: torch.Tensor, mode: str = "allreduce") -> None:
         raise ValueError(f"global_counts={mode!r}: expected 'allreduce' or 'uniform'")
 
 
+def global_any(flag) -> bool:
+    """`flag` (bool / 0-dim bool tensor) on any rank"""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.as_tensor(flag).to(torch.int32).reshape(1).clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())
+
+
 def global_max_int(value: int, device) -> int:
     """e.g. the sphere-tracing trip count K (SDF.py:167 tests a mask over ALL rays)"""
     if not is_distributed():

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import dist as ldist
 from .. import fused
 from ..util_layers import get_layer_dims
 from ..utils.custom_functions import RayAABBIntersector
@@ -126,7 +127,9 @@ class SDF(nn.Module):
             s_e = torch.where(s_e.abs() <= thr, torch.zeros_like(s_e), s_e)
             live_s = (s_s.abs() > thr) if live_s is None else live_s & (s_s.abs() > thr)
             live_e = (s_e.abs() > thr) if live_e is None else live_e & (s_e.abs() > thr)
-            if trips == self.iters_max or not bool(live_s.any()):
+            # the reference's break tests a mask over ALL rays (SDF.py:167): sharded runs reduce it over the ranks, one
+            # collective per trip -- every rank must take this same (torch) path, as with the fused kernel's single max-reduce
+            if trips == self.iters_max or not ldist.global_any(live_s.any()):
                 break
             trips += 1
             t_s = t_s + s_s

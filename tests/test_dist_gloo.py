@@ -70,6 +70,13 @@ def _worker(rank, world, port, out_dir):
         m = ldist.global_mean(vals[lo:hi][mask[lo:hi]].sum(), mask[lo:hi].sum())
         assert abs(m.item() - vals[mask].mean().item()) < 1e-6
         assert ldist.global_max_int(3 + 4 * rank, "cpu") == 7
+        assert ldist.global_any(torch.tensor(rank == 1)) is True and ldist.global_any(False) is False
+        # (sum, count) pairs of the loss head -> global counts: the two documented modes
+        sums = torch.tensor([1.0, 3, 2, 10, 0.5, float(rank), 4, 3], dtype=torch.float64) * (rank + 1)
+        a = sums.clone(); ldist.globalize_loss_sums(a, "allreduce")
+        assert torch.equal(a, torch.tensor([3.0, 9, 6, 30, 1.5, 2, 12, 9], dtype=torch.float64))
+        b = sums.clone(); ldist.globalize_loss_sums(b, "uniform")
+        assert torch.equal(b[1::2], sums[1::2] * 2) and torch.equal(b[0::2], sums[0::2])
         with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:
