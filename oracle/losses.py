@@ -7,8 +7,9 @@ renderer's outputs.  Each line is the reference's own torch expression:
     mse           Camera.py:533                  mse_loss(rgb[mask_bg], rgbs_gt[mask_bg])       (PSNR = -10 log10)
     all           BA.py:206-218                  sum 10**w * loss
 
-Parity note: these are one-line torch calls, so the restatement is pinned by construction rather than by golden vectors
-(the reference's CameraSet needs its dataset / pycolmap stack to be instantiated).
+Parity: PINNED -- tests/test_oracle_caller_golden.py composes oracle.fields.render + sphere_tracing + this loss head the way
+CameraSet.render / BA.compute_loss / summarize_loss do and checks every term, PSNR, the summed loss and all parameter gradients
+against tests/golden/caller_*.npz, recorded from those reference functions themselves (tests/golden/make_golden_caller.py).
 """
 import torch
 import torch.nn.functional as torch_F
