@@ -153,6 +153,7 @@ def main():
                          "wins by ~5 %% when the host keeps up, the graph wins when the host CPU is slow or busy)")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--torch-loss", action="store_true", help="loss head as separate PyTorch ops instead of the fused kernel")
+    ap.add_argument("--overlap-groups", type=int, default=2, help="N > 1: level groups of the overlapped table-gradient reduction (2..4)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce after the backward instead of the "
                     "level-group reductions issued from inside it")
     ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
@@ -204,7 +205,7 @@ def main():
     if multi and not args.no_overlap:
         # the ~105 MB gradient exchange is as long as the step on 7 xGMI links and all of it comes out of the backward's last
         # kernels: scatter the levels in 4 groups and all-reduce a group's table slices while the next ones are scattered
-        enable_table_overlap(sdf, rad, n_groups=4)
+        enable_table_overlap(sdf, rad, n_groups=args.overlap_groups)
 
     from ls2fm.losses import RenderLossHead
     from ls2fm.graph import CapturedStep

@@ -368,14 +368,16 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
     float* part1 = ws + w.mpart;
     float* part2 = part1 + (int64_t)kWgradMlpBlocks * 64 * kRegsSdf;
     float* part3 = part2 + (int64_t)kWgradMlpBlocks * 64 * (dual ? kRegsGeo : 0);
-    ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, s);
-    wgrad_mlp_kernel<false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles);
-    ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
+    // second MLP first: the order only matters through how the two kernels share the CUs with scatter_fill / slab_accumulate
+    // on the other queue -- measured (A/B on one box, graph replay of the benchmark step) 0.579 vs 0.583 ms
     if (dual) {
         ls2fm_prof_begin(LS2FM_PROF_WGRAD_GEO, s);
         wgrad_mlp_kernel<true><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles);
         ls2fm_prof_end(LS2FM_PROF_WGRAD_GEO, s);
     }
+    ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, s);
+    wgrad_mlp_kernel<false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles);
+    ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
     ls2fm_prof_begin(LS2FM_PROF_WGRAD_TAIL, s);
     if (sdf_only) {          // point queries: no decoder columns, the SDF MLP's partials only (blocks [0, kRegsSdf) of the reduction)
         wgrad_reduce_all_kernel<<<kRegsSdf, kWmThreads, 0, s>>>(part1, part2, part3, blocks, 0, 0, ws + w.wg);

@@ -17,12 +17,17 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # LS2FM_DIST_SINGLE=1 (tests): a one-rank process group takes the distributed code paths too -- the only way to run them
+    # against RCCL on a single-GPU box
+    least = 1 if os.environ.get("LS2FM_DIST_SINGLE", "0") == "1" else 2
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= least
 
 
 def shard_rays(center: torch.Tensor, ray: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None
@@ -111,19 +116,54 @@ def enable_table_overlap(sdf_field, rad_field=None, n_groups: int = 2) -> None:
         t._ls2fm_overlap_groups = int(n_groups)
 
 
+_COALESCED = {"ok": None}
+
+
+def _all_reduce_together(slices):
+    """sum-all-reduce several tensors as ONE collective launch where the backend coalesces (RCCL: one grouped kernel instead of
+    one per tensor -- a launch has a fixed cost of tens of microseconds, and a level group is two slices, one per table);
+    falls back to one launch per tensor.  Returns the async work handles."""
+    if len(slices) > 1 and _COALESCED["ok"] is not False:
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")          # (torch marks the coalesced entry point as deprecated)
+                work = dist.all_reduce_coalesced(list(slices), async_op=True)
+            _COALESCED["ok"] = True
+            return [work]
+        except (RuntimeError, NotImplementedError, AttributeError, TypeError):
+            if _COALESCED["ok"]:
+                raise                                     # it worked before: a real failure, not a missing feature
+            _COALESCED["ok"] = False
+    return [dist.all_reduce(t, async_op=True) for t in slices]
+
+
 def launch_group_reductions(flat, tables, level_offsets, events, n_levels):
     """called by the fused backward after its kernels are enqueued: tables = gradient views (1-D, inside `flat`) of the hash
-    tables, level_offsets[l] = first ENTRY of level l, events[g] recorded when group g's levels are final"""
+    tables, level_offsets[l] = first ENTRY of level l, events[g] recorded when group g's levels are final.  One collective
+    launch per group; the LAST one waits for the whole backward instead of its event and carries everything else that lives
+    in `flat` (the MLP / beta gradients between and after the tables), so a step issues len(events) launches in total."""
     n = len(events)
+    cur = torch.cuda.current_stream(flat.device)
     comm = comm_stream(flat.device)
+    base = flat.data_ptr()
+    spans = sorted(((t.data_ptr() - base) // 4, (t.data_ptr() - base) // 4 + t.numel()) for t in tables)
+    rest, at = [], 0
+    for lo, hi in spans + [(flat.numel(), flat.numel())]:
+        if lo > at:
+            rest.append(flat[at:lo])
+        at = max(at, hi)
     pending = []
     for gi, ev in enumerate(events):
         lo, hi = 2 * int(level_offsets[n_levels * gi // n]), 2 * int(level_offsets[n_levels * (gi + 1) // n])
-        comm.wait_event(ev)
+        last = gi == n - 1
+        if last:
+            comm.wait_stream(cur)              # every gradient is final once the backward's stream gets here
+        else:
+            comm.wait_event(ev)
         with torch.cuda.stream(comm):
-            for t in tables:
-                pending.append(dist.all_reduce(t[lo:hi], async_op=True))
-    flat._ls2fm_pending = (pending, [(t.data_ptr(), t.numel()) for t in tables])
+            pending.extend(_all_reduce_together([t[lo:hi] for t in tables] + (rest if last else [])))
+    flat._ls2fm_pending = pending
 
 
 class GradAllReducer:
@@ -169,17 +209,9 @@ class GradAllReducer:
         world = dist.get_world_size()
         whole = self._all_in_flat()
         pending = getattr(whole, "_ls2fm_pending", None) if whole is not None else None
-        if pending is not None:                            # the tables are already on their way (enable_table_overlap)
-            handles, spans = pending
+        if pending is not None:                            # everything is already on its way (enable_table_overlap)
             whole._ls2fm_pending = None
-            base = whole.data_ptr()
-            cuts = sorted(((ptr - base) // 4, (ptr - base) // 4 + n) for ptr, n in spans)
-            at, rest = 0, []
-            for lo, hi in cuts + [(whole.numel(), whole.numel())]:
-                if lo > at:
-                    rest.append(dist.all_reduce(whole[at:lo], async_op=True))      # the small tensors between / after the tables
-                at = max(at, hi)
-            for h in handles + rest:
+            for h in pending:
                 h.wait()
             if self.average:
                 whole.div_(world)

@@ -382,11 +382,14 @@ class _Render(torch.autograd.Function):
         events = []
         if n_groups > 1:
             n_groups = min(n_groups, 4, g1.n_levels)
-            cur = torch.cuda.current_stream()
-            for gi in range(n_groups):
-                ev = torch.cuda.Event()
-                ev.record(cur)                     # materialises the handle (torch creates events lazily)
-                events.append(ev)
+            events = getattr(ps[0], "_ls2fm_group_events", None)      # kept with the table Parameter: re-recorded every step
+            if events is None or len(events) != n_groups:
+                cur = torch.cuda.current_stream()
+                events = [torch.cuda.Event() for _ in range(n_groups)]
+                for ev in events:
+                    ev.record(cur)                 # materialises the handle (torch creates events lazily)
+                ps[0]._ls2fm_group_events = events
+            for gi, ev in enumerate(events):
                 opts.group_events[gi] = ev.cuda_event
             opts.n_level_groups = n_groups
         if fl is not None and (d_terms is not None or d_total is not None):

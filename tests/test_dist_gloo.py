@@ -77,6 +77,15 @@ def _worker(rank, world, port, out_dir):
         assert torch.equal(a, torch.tensor([3.0, 9, 6, 30, 1.5, 2, 12, 9], dtype=torch.float64))
         b = sums.clone(); ldist.globalize_loss_sums(b, "uniform")
         assert torch.equal(b[1::2], sums[1::2] * 2) and torch.equal(b[0::2], sums[0::2])
+        # a level group's two table slices go out as one coalesced launch where the backend can (else one each)
+        buf = torch.arange(24, dtype=torch.float32) * (rank + 1)
+        works = ldist._all_reduce_together([buf[2:7], buf[13:20]])
+        for wk in works:
+            wk.wait()
+        want = torch.arange(24, dtype=torch.float32) * (rank + 1)
+        want[2:7] = torch.arange(2, 7, dtype=torch.float32) * 3
+        want[13:20] = torch.arange(13, 20, dtype=torch.float32) * 3
+        assert torch.equal(buf, want), (buf, want)
         with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:

@@ -27,13 +27,14 @@ def _step(opt, sdf, rad, ren, head, center, ray, gt, dref, masks):
     return loss
 
 
-def _worker(rank, world, port, overlap, out_dir):
+def _worker(rank, world, port, overlap, out_dir, backend="gloo"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "level-s2fm_official_amd"), os.path.join(root, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      LS2FM_DIST_SINGLE="1" if world == 1 else "0")
     torch.cuda.set_device(0)
     dev = "cuda:0"
     from ls2fm import dist as ldist
@@ -56,7 +57,7 @@ def _worker(rank, world, port, overlap, out_dir):
     full_loss = _step(opt, sdf, rad, ren, head, center, ray, gt, dref, dict(mask_finish=mfin, mask_eik=mbg, mask_bg=mbg))
     full = {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
     full_terms = {k: float(v) for k, v in full_loss.items()}
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         if overlap:
             ldist.enable_table_overlap(sdf, rad, n_groups=3)
@@ -71,6 +72,8 @@ def _worker(rank, world, port, overlap, out_dir):
         assert (getattr(red._all_in_flat(), "_ls2fm_pending", None) is not None) == overlap
         red.all_reduce()
         torch.cuda.synchronize()
+        if backend == "nccl" and overlap:
+            assert ldist._COALESCED["ok"] is True                 # RCCL: a level group's two slices went out as one launch
         got = {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
         from conftest import rel_err
         for k in full:
@@ -87,3 +90,10 @@ def _worker(rank, world, port, overlap, out_dir):
 def test_two_ranks_one_gpu_reproduce_the_single_process_gradients(overlap, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), overlap, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_one_rank_rccl_overlapped_reduction(tmp_path):
+    """the same step through a real RCCL communicator (world size 1: all this box allows): the overlapped reduction's streams,
+    events, coalesced launches and async handles run against the backend the multi-GPU bench uses; the sums are identities"""
+    mp.spawn(_worker, args=(1, _free_port(), True, str(tmp_path), "nccl"), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
