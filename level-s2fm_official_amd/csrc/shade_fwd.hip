@@ -1,6 +1,7 @@
 // shade_fwd: per-sample field evaluation + per-ray compositing of Renderer.forward on the matrix cores.
 //
-//   workgroup = one ray (its N samples are the N dimension of every GEMM), wave = 64 samples = four 16-column tiles.
+//   workgroup = one ray (its N samples are the N dimension of every GEMM), wave = CT 16-column tiles of consecutive samples
+//   (CT = 2: 32 samples per wave and 4 waves/SIMD for rays of up to 256 samples; CT = 4 beyond).
 //   Everything is kept TRANSPOSED, [feature x sample], so that the accumulator tile of one v_mfma_f32_16x16x4_f32
 //   (lane 16 g + jl holds rows 4 g + r, column jl) is directly the B operand of the next GEMM over that feature
 //   dimension (k-slot g <-> row 4 g + r): the whole chain
@@ -31,8 +32,10 @@ __device__ __forceinline__ float sum_over_groups(float v) {
     return v;
 }
 
-template <bool DUAL, int MAXT>
-__global__ void __launch_bounds__(MAXT, 2)
+// CT = 16-column tiles (of consecutive samples) per wave: 4 -> a wave covers 64 samples with ~250 registers (2 waves/SIMD);
+// 2 -> 32 samples per wave, half the per-lane state, twice the waves (4 per SIMD) to hide the chain's latencies behind.
+template <bool DUAL, int MAXS, int CT>
+__global__ void __launch_bounds__(MAXS * 4 / CT, CT == 2 ? 4 : 2)
 shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, const float* __restrict__ center,
                  const float* __restrict__ ray, int64_t p_pad, const float* __restrict__ E1,
                  const float* __restrict__ J1, const float* __restrict__ E2, float* __restrict__ rgb_out,
@@ -40,9 +43,9 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
                  float* __restrict__ nm_out, float* __restrict__ SDFV, float* __restrict__ NRM,
                  float* __restrict__ RGBS, float* __restrict__ FE, float* __restrict__ FE2, float* __restrict__ ROUT,
                  float* __restrict__ LPART, int64_t r_pad, ls2fm_loss_spec loss) {
-    __shared__ float s_part[MAXT / 64][10];     // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
+    __shared__ float s_part[MAXS / (16 * CT)][10];   // per wave: tau total, then w-sums of rgb(3) depth n(3) opacity
     __shared__ float s_view[3];
-    __shared__ float s_x[MAXT][8];              // per sample: sdf, normal(3), colour(3)
+    __shared__ float s_x[MAXS][8];              // per sample: sdf, normal(3), colour(3)
     __shared__ float s_w[kMfmaSdfFloats];       // MFMA-ordered weights of the field being evaluated (29 KB)
     const int N = fc.n_samples;
     const int64_t r = blockIdx.x;
@@ -71,12 +74,12 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     }
 
     // ---- this lane's four samples (column jl of the wave's four tiles)
-    int64_t is[4];
-    float pw[4][3];
-    bool live_c[4];
+    int64_t is[CT];
+    float pw[CT][3];
+    bool live_c[CT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int ns = 64 * wave + 4 * jl + c;          // a lane's four columns are CONSECUTIVE samples: 16-byte loads
+    for (int c = 0; c < CT; ++c) {
+        const int ns = 16 * CT * wave + CT * jl + c;    // a lane's columns are CONSECUTIVE samples: 16- (8-) byte loads
         live_c[c] = ns < N;
         const int nn = live_c[c] ? ns : N - 1;
         is[c] = r * N + nn;
@@ -84,31 +87,41 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         sample_position(fc, gm, sample_depth(gm, nn, N), pw[c], x);
     }
 
-    // all four samples live and 16-byte aligned (p_pad is a multiple of 64): one float4 per channel row
-    const bool vec4 = live_c[3] && ((is[0] & 3) == 0);
-    const int64_t i0 = is[0], i1 = is[1], i2 = is[2], i3 = is[3];
-    auto load4 = [=](const float* __restrict__ row) -> float4 {      // by value: by-reference captures cost spilled registers
-        if (vec4) return *reinterpret_cast<const float4*>(row + i0);
-        return make_float4(row[i0], row[i1], row[i2], row[i3]);
+    // all of the lane's samples live and aligned (p_pad is a multiple of 64): one float4 / float2 per channel row
+    struct Cols { float v[CT]; };
+    const bool vec = live_c[CT - 1] && ((is[0] & (CT - 1)) == 0);
+    const int64_t i0 = is[0], i1 = is[1], i2 = is[CT - 2], i3 = is[CT - 1];
+    auto loadv = [=](const float* __restrict__ row) -> Cols {        // by value: by-reference captures cost spilled registers
+        Cols o;
+        if (CT == 4) {
+            if (vec) { const float4 t = *reinterpret_cast<const float4*>(row + i0); o.v[0] = t.x; o.v[1] = t.y; o.v[CT - 2] = t.z; o.v[CT - 1] = t.w; }
+            else { o.v[0] = row[i0]; o.v[1] = row[i1]; o.v[CT - 2] = row[i2]; o.v[CT - 1] = row[i3]; }
+        } else {
+            if (vec) { const float2 t = *reinterpret_cast<const float2*>(row + i0); o.v[0] = t.x; o.v[1] = t.y; }
+            else { o.v[0] = row[i0]; o.v[1] = row[i1]; }
+        }
+        return o;
     };
     // ---- B operands of layer 0: ub[t][c] = U[k' = 4t + g][sample c]
-    float ub[9][4];
+    float ub[9][CT];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((4 * t + g) < ch1) e = load4(E1 + (int64_t)(4 * t + g) * p_pad);
-        ub[t][0] = e.x; ub[t][1] = e.y; ub[t][2] = e.z; ub[t][3] = e.w;
+        Cols e{};
+        if ((4 * t + g) < ch1) e = loadv(E1 + (int64_t)(4 * t + g) * p_pad);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) ub[t][c] = e.v[c];
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ub[8][c] = g < 3 ? (g == 0 ? pw[c][0] : (g == 1 ? pw[c][1] : pw[c][2])) / fc.rescale : 1.0f;
+    for (int c = 0; c < CT; ++c) ub[8][c] = g < 3 ? (g == 0 ? pw[c][0] : (g == 1 ? pw[c][1] : pw[c][2])) / fc.rescale : 1.0f;
 
     __syncthreads();          // weights staged
 
     // ---- SDF field
-    f32x4 racc[3][4], facc[4];
-    float f0p[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 racc[3][CT], facc[CT];
+    float f0p[CT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CT; ++c) {
+        f0p[c] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) facc[c][q] = mw.b1a[0][q][lane];
 #pragma unroll
@@ -116,21 +129,21 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        f32x4 acc[4];
+        f32x4 acc[CT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float a = s_w0a[(m * 9 + t) * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
+            for (int c = 0; c < CT; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
         }
-        float ga[4][4];
+        float ga[CT][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float w10 = s_w10[(m * 4 + q) * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < CT; ++c) {
                 float h, s1, s2;
                 softplus100(acc[c][q], h, s1, s2);
                 acc[c][q] = h;
@@ -142,7 +155,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         for (int q = 0; q < 4; ++q) {
             const float a1 = s_w1a[(m * 4 + q) * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) facc[c] = mfma4(a1, acc[c][q], facc[c]);
+            for (int c = 0; c < CT; ++c) facc[c] = mfma4(a1, acc[c][q], facc[c]);
         }
 #pragma unroll
         for (int mk = 0; mk < 3; ++mk)
@@ -150,15 +163,15 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             for (int q = 0; q < 4; ++q) {
                 const float at = s_w0ta[((mk * 4 + m) * 4 + q) * 64 + lane];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) racc[mk][c] = mfma4(at, ga[c][q], racc[mk][c]);
+                for (int c = 0; c < CT; ++c) racc[mk][c] = mfma4(at, ga[c][q], racc[mk][c]);
             }
     }
 
     // sdf and the analytic normal  n = kappa (R_p / rescale + inv_ext . J^T R_enc)
-    float sdf[4], nrm[4][3];
-    float part[4][3];
+    float sdf[CT], nrm[CT][3];
+    float part[CT][3];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) part[c][0] = part[c][1] = part[c][2] = 0.f;
+    for (int c = 0; c < CT; ++c) part[c][0] = part[c][1] = part[c][2] = 0.f;
 #pragma unroll
     for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
@@ -167,16 +180,14 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             if (ch < ch1) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const float4 jv = load4(J1 + (int64_t)(ch * 3 + a) * p_pad);
-                    part[0][a] = fmaf(jv.x, racc[mk][0][q], part[0][a]);
-                    part[1][a] = fmaf(jv.y, racc[mk][1][q], part[1][a]);
-                    part[2][a] = fmaf(jv.z, racc[mk][2][q], part[2][a]);
-                    part[3][a] = fmaf(jv.w, racc[mk][3][q], part[3][a]);
+                    const Cols jv = loadv(J1 + (int64_t)(ch * 3 + a) * p_pad);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) part[c][a] = fmaf(jv.v[c], racc[mk][c][q], part[c][a]);
                 }
             }
         }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CT; ++c) {
         const float f0 = sum_over_groups(f0p[c]) + mw.b10[0];
         sdf[c] = fc.inside ? f0 / fc.scale_mlp : -f0 / fc.scale_mlp;
 #pragma unroll
@@ -186,22 +197,31 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             nrm[c][a] = fc.kappa * sum_over_groups(v);
         }
     }
-    const bool l0 = live_c[0], l1 = live_c[1], l2 = live_c[2], l3 = live_c[3];
-    auto store4 = [=](float* __restrict__ row, float v0, float v1, float v2, float v3) {
-        if (vec4) {
-            *reinterpret_cast<float4*>(row + i0) = make_float4(v0, v1, v2, v3);
+    const bool l0 = live_c[0], l1 = live_c[1], l2 = live_c[CT - 2], l3 = live_c[CT - 1];
+    auto storev = [=](float* __restrict__ row, const f32x4 (&acc)[CT], int q) {
+        if (CT == 4) {
+            if (vec) {
+                *reinterpret_cast<float4*>(row + i0) = make_float4(acc[0][q], acc[1][q], acc[CT - 2][q], acc[CT - 1][q]);
+            } else {
+                if (l0) row[i0] = acc[0][q];
+                if (l1) row[i1] = acc[1][q];
+                if (l2) row[i2] = acc[CT - 2][q];
+                if (l3) row[i3] = acc[CT - 1][q];
+            }
         } else {
-            if (l0) row[i0] = v0;
-            if (l1) row[i1] = v1;
-            if (l2) row[i2] = v2;
-            if (l3) row[i3] = v3;
+            if (vec) {
+                *reinterpret_cast<float2*>(row + i0) = make_float2(acc[0][q], acc[1][q]);
+            } else {
+                if (l0) row[i0] = acc[0][q];
+                if (l1) row[i1] = acc[1][q];
+            }
         }
     };
 #pragma unroll
-    for (int q = 0; q < 4; ++q) store4(FE + (int64_t)(4 * g + q) * p_pad, facc[0][q], facc[1][q], facc[2][q], facc[3][q]);
+    for (int q = 0; q < 4; ++q) storev(FE + (int64_t)(4 * g + q) * p_pad, facc, q);
 
     // ---- second field (Geometry_feat of RadF): features only
-    f32x4 facc2[4];
+    f32x4 facc2[CT];
     if (DUAL) {
         __syncthreads();      // every wave is done with the SDF weights
         {
@@ -211,35 +231,36 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((4 * t + g) < ch2) e = load4(E2 + (int64_t)(4 * t + g) * p_pad);
-            ub[t][0] = e.x; ub[t][1] = e.y; ub[t][2] = e.z; ub[t][3] = e.w;
+            Cols e{};
+            if ((4 * t + g) < ch2) e = loadv(E2 + (int64_t)(4 * t + g) * p_pad);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) ub[t][c] = e.v[c];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) facc2[c][q] = mw.b1a[1][q][lane];
         __syncthreads();      // second field's weights staged
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            f32x4 acc[4];
+            f32x4 acc[CT];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float a = s_w0a[(m * 9 + t) * 64 + lane];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
+                for (int c = 0; c < CT; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float a1 = s_w1a[(m * 4 + q) * 64 + lane];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) facc2[c] = mfma4(a1, softplus100_value(acc[c][q]), facc2[c]);
+                for (int c = 0; c < CT; ++c) facc2[c] = mfma4(a1, softplus100_value(acc[c][q]), facc2[c]);
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store4(FE2 + (int64_t)(4 * g + q) * p_pad, facc2[0][q], facc2[1][q], facc2[2][q], facc2[3][q]);
+        for (int q = 0; q < 4; ++q) storev(FE2 + (int64_t)(4 * g + q) * p_pad, facc2, q);
     }
     __syncthreads();          // s_view ready
 
@@ -253,7 +274,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             wf2[k][q] = DUAL ? pk->wc[k][49 + 4 * g + q] : 0.f;
         }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CT; ++c) {
         float col[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -271,7 +292,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             col[k] = 1.0f / (1.0f + expf(-z));
         }
         if (g == 0) {
-            float* dst = s_x[64 * wave + 4 * jl + c];
+            float* dst = s_x[16 * CT * wave + CT * jl + c];
             dst[0] = sdf[c];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { dst[1 + a] = nrm[c][a]; dst[4 + a] = col[a]; }
@@ -284,9 +305,10 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     const int64_t i = r * N + (live ? n : N - 1);
     const float t = sample_depth(gm, live ? n : N - 1, N);
     const float t_next = sample_depth(gm, (live ? n : N - 1) + 1, N);
-    const float sdf_n = s_x[n][0];
-    const float nrm_n[3] = {s_x[n][1], s_x[n][2], s_x[n][3]};
-    const float col_n[3] = {s_x[n][4], s_x[n][5], s_x[n][6]};
+    const int nx = live ? n : N - 1;             // (CT < 4: more threads than samples; rows beyond the last tile are never written)
+    const float sdf_n = s_x[nx][0];
+    const float nrm_n[3] = {s_x[nx][1], s_x[nx][2], s_x[nx][3]};
+    const float col_n[3] = {s_x[nx][4], s_x[nx][5], s_x[nx][6]};
     const float sigma = sigma_of(sdf_n, pk->alpha, pk->beta);
     if (live) {
         sdfs_out[i] = sdf_n;
@@ -367,16 +389,20 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,
                            int64_t n_rays, const WsLayout& w, float* ws, float* rgb, float* sdfs_volume, float* normals,
                            float* depth_mlp, float* normal_mlp, const ls2fm_loss_spec* loss, hipStream_t s) {
-    const int threads = (fc.n_samples + 63) / 64 * 64;
+    // up to 256 samples per ray: two tiles per wave (4 waves/SIMD; 71.6 -> 66.1 us at the benchmark); longer rays keep four
+    // (a 1024-thread workgroup of the two-tile form does not fit the register budget of 4 waves/SIMD without spilling into LDS)
+    const bool small = fc.n_samples <= 256;
+    const int per_wave = small ? 32 : 64;
+    const int threads = (fc.n_samples + per_wave - 1) / per_wave * 64;
     ls2fm_loss_spec ls{};            // rgb_gt == null: plain render
     if (loss) ls = *loss;
-#define LS2FM_SHADE_FWD(DUAL, MAXT)                                                                                \
-    shade_fwd_kernel<DUAL, MAXT><<<(unsigned)n_rays, threads, 0, s>>>(                                              \
+#define LS2FM_SHADE_FWD(DUAL, MAXS, CT)                                                                            \
+    shade_fwd_kernel<DUAL, MAXS, CT><<<(unsigned)n_rays, threads, 0, s>>>(                                          \
         fc, ch1, ch2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb, sdfs_volume, \
         normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe, DUAL ? ws + w.fe2 : nullptr,        \
         ws + w.rout, ws + w.lpart, w.r_pad, ls)
-    if (dual) { if (threads <= 256) LS2FM_SHADE_FWD(true, 256); else LS2FM_SHADE_FWD(true, 512); }
-    else      { if (threads <= 256) LS2FM_SHADE_FWD(false, 256); else LS2FM_SHADE_FWD(false, 512); }
+    if (dual) { if (small) LS2FM_SHADE_FWD(true, 256, 2); else LS2FM_SHADE_FWD(true, 512, 4); }
+    else      { if (small) LS2FM_SHADE_FWD(false, 256, 2); else LS2FM_SHADE_FWD(false, 512, 4); }
 #undef LS2FM_SHADE_FWD
     return LS2FM_OK;
 }
