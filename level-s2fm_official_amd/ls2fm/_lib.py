@@ -167,7 +167,13 @@ def ptr(t) -> c_void_p:
     return c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> c_void_p:
+    """the caller's current HIP stream (raw handle: ~1 us; torch.cuda.current_stream() builds a Stream object, ~20 us)"""
+    if _RAW_STREAM is not None:
+        return c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -142,13 +142,21 @@ def _plan(renderer, opt, sdf_field, rad_field) -> _Plan:
     return pl
 
 
-def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
-    if not (center.is_cuda and ray.is_cuda) or not _plan(renderer, opt, sdf_field, rad_field).ok:
-        return False
+def render_plan(renderer, opt, center, ray, sdf_field, rad_field):
+    """the cached plan when the fused kernels serve this call, else None (one plan check per call: pass it on to render())"""
+    if not (center.is_cuda and ray.is_cuda):
+        return None
+    pl = _plan(renderer, opt, sdf_field, rad_field)
+    if not pl.ok:
+        return None
     n_points = center.shape[0] * center.shape[1] * int(opt.SDF.VolSDF.sample_intvs) if center.dim() == 3 else 0
     if n_points > _lib.MAX_RENDER_POINTS:       # 32-bit offsets inside one call: bigger batches take the composed form
-        return False
-    return True                 # pose gradients (center / ray requiring grad) are part of the fused backward
+        return None
+    return pl                   # pose gradients (center / ray requiring grad) are part of the fused backward
+
+
+def can_render(renderer, opt, center, ray, sdf_field, rad_field) -> bool:
+    return render_plan(renderer, opt, center, ray, sdf_field, rad_field) is not None
 
 
 _HAS_SDF_EVAL = True
@@ -411,10 +419,11 @@ class _Render(torch.autograd.Function):
         return (d_center, d_ray, d_dref, None, None, None, *grads)  # ctx.ws is kept: backward may run again (retain_graph)
 
 
-def render(renderer, opt, center, ray, sdf_field, rad_field, loss=None, d_points=None):
+def render(renderer, opt, center, ray, sdf_field, rad_field, loss=None, d_points=None, plan=None):
     """Renderer.forward through the fused kernels -> the reference's result dict.  With `loss` (a FusedLoss) the loss head
-    runs inside the render and the dict also holds 'loss_terms' ([5]: rgb, eikonal, DC, mse, all) and 'loss_total'."""
-    pl = _plan(renderer, opt, sdf_field, rad_field)
+    runs inside the render and the dict also holds 'loss_terms' ([5]: rgb, eikonal, DC, mse, all) and 'loss_total'.
+    `plan`: what render_plan() just returned for the same arguments (saves the second check)."""
+    pl = plan if plan is not None else _plan(renderer, opt, sdf_field, rad_field)
     want_bwd = torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad or any(p.requires_grad for p in pl.ts)
                                             or (d_points is not None and d_points.requires_grad))
     out = _Render.apply(center, ray, d_points if loss is not None else None, pl.cfg, loss, want_bwd, *pl.ts)

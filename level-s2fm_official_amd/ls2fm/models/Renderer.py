@@ -71,8 +71,9 @@ class Renderer(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, opt, center, ray, SDF_Field, Rad_Field):
-        if fused.can_render(self, opt, center, ray, SDF_Field, Rad_Field):
-            return fused.render(self, opt, center, ray, SDF_Field, Rad_Field)
+        plan = fused.render_plan(self, opt, center, ray, SDF_Field, Rad_Field)
+        if plan is not None:
+            return fused.render(self, opt, center, ray, SDF_Field, Rad_Field, plan=plan)
         return self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
 
     def forward_with_loss(self, opt, center, ray, SDF_Field, Rad_Field, head, rgbs_gt, d_points=None, mask_finish=None,
@@ -82,10 +83,11 @@ class Renderer(nn.Module):
         the forward's last kernel, the upstream of rgb / normals / depth formed in the backward's first -- no loss kernels and
         no [B,R,N,3] gradient tensor between forward and backward.  Same values and gradients as `head(self.forward(...),
         rgbs_gt, ...)`, which is what runs when the configuration is served by the composed form."""
-        if fused.can_render(self, opt, center, ray, SDF_Field, Rad_Field):
+        plan = fused.render_plan(self, opt, center, ray, SDF_Field, Rad_Field)
+        if plan is not None:
             spec = head.spec(rgbs_gt, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg,
                              n_rays=center.shape[0] * center.shape[1])
-            ret = fused.render(self, opt, center, ray, SDF_Field, Rad_Field, loss=spec, d_points=d_points)
+            ret = fused.render(self, opt, center, ray, SDF_Field, Rad_Field, loss=spec, d_points=d_points, plan=plan)
             return ret, head.as_dict(ret.pop("loss_terms"), ret.pop("loss_total"))
         ret = self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
         return ret, head(ret, rgbs_gt, d_points=d_points, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg)
