@@ -71,7 +71,7 @@ points_bwd_kernel(FieldC fc, LevelScales lsc, int n_levels, WsLayout w, const Pa
         if (c < 2 * n_levels) {
             e = ws[w.e1 + (int64_t)c * P + i];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) acc = fmaf(ws[w.j1 + (int64_t)(c * 3 + a) * P + i], gns[a], acc);
+            for (int a = 0; a < 3; ++a) acc = fmaf(ws[w.j1 + ((int64_t)c * P + i) * 3 + a], gns[a], acc);         // [channel][point][3]
         }
         u[3 + c] = e;
         v[3 + c] = acc;

@@ -333,8 +333,8 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                     g0 = fmaf(dw, v[k].x, g0);
                     g1 = fmaf(dw, v[k].y, g1);
                 }
-                __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-                __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+                __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * p_pad + i) * 3 + gd);      // [channel][point][3]
+                __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * p_pad + i) * 3 + gd);
             }
         } else {
             const float* __restrict__ table = second ? table2 : table1;
@@ -361,8 +361,8 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                         g0 = fmaf(dw, v[k].x, g0);
                         g1 = fmaf(dw, v[k].y, g1);
                     }
-                    __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * 3 + gd) * p_pad + i);
-                    __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * 3 + gd) * p_pad + i);
+                    __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * p_pad + i) * 3 + gd);  // [channel][point][3]
+                    __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * p_pad + i) * 3 + gd);
                 }
             }
         }

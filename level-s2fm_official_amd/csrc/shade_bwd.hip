@@ -342,9 +342,13 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 const int ch = 4 * t + g;
                 const bool on = ch < ch1;
                 ub[t][cc] = on ? f_e1[(uint32_t)ch * P32 + is[cc]] : 0.f;
+                // J rows are [channel][point][3]: one 12-byte load per (channel, sample)
+                struct __attribute__((aligned(4))) J3 { float v[3]; };
+                J3 jv{{0.f, 0.f, 0.f}};
+                if (on) jv = *reinterpret_cast<const J3*>(f_j1 + ((uint32_t)ch * P32 + is[cc]) * 3u);
                 float acc = 0.f;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) acc = fmaf(on ? f_j1[(uint32_t)(ch * 3 + a) * P32 + is[cc]] : 0.f, gns[cc][a], acc);
+                for (int a = 0; a < 3; ++a) acc = fmaf(jv.v[a], gns[cc][a], acc);
                 vb[t][cc] = acc;
             }
 #pragma unroll

@@ -178,12 +178,38 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         for (int q = 0; q < 4; ++q) {
             const int ch = 16 * mk + 4 * g + q;
             if (ch < ch1) {
+                // J rows are [channel][point][3]: the lane's CT consecutive samples are 3 CT consecutive floats
+                const float* __restrict__ jrow = J1 + (int64_t)ch * p_pad * 3;
+                float jv[CT][3];
+                if (vec) {
+                    if (CT == 4) {
+                        const float4* q4 = reinterpret_cast<const float4*>(jrow + i0 * 3);
+                        const float4 x0 = q4[0], x1 = q4[1], x2 = q4[2];
+                        const float f[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const Cols jv = loadv(J1 + (int64_t)(ch * 3 + a) * p_pad);
+                        for (int c = 0; c < CT; ++c)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) part[c][a] = fmaf(jv.v[c], racc[mk][c][q], part[c][a]);
+                            for (int a = 0; a < 3; ++a) jv[c][a] = f[3 * c + a];
+                    } else {
+                        const float2* q2 = reinterpret_cast<const float2*>(jrow + i0 * 3);
+                        const float2 x0 = q2[0], x1 = q2[1], x2 = q2[2];
+                        const float f[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) jv[c][a] = f[(3 * c + a) % 6];
+                    }
+                } else {
+                    const int64_t ix[4] = {i0, i1, i2, i3};
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) jv[c][a] = jrow[ix[CT == 4 ? c : (c == 0 ? 0 : 1)] * 3 + a];
                 }
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) part[c][a] = fmaf(jv[c][a], racc[mk][c][q], part[c][a]);
             }
         }
 #pragma unroll
