@@ -7,6 +7,7 @@ each iteration of which is  `CameraSet.render` (pipelines/Camera.py:448-538: Ren
 mask_finish, rgb_loss / DC_loss / PSNR)  ->  compute_loss / summarize_loss (eikonal over mask_bg, 10^w weighted sum:
 BA.py:186-218)  ->  loss.all.backward()  ->  Adam.step()  ->  ExponentialLR.step().
 
+`surface_losses` is the point side of a BA iteration (BA.py:117-131, compute_loss "sfm" branch) on the fused point queries;
 `render_losses` is that render-and-loss part for rays that are already picked (ray picking, poses, key points, COLMAP
 bookkeeping are the drivers' camera-side logic: SURVEY section 2, out of scope); `RenderStage` adds the update and, with
 `capture=True`, records the WHOLE step -- tracing kernel, point-query node of the traced depth, fused render with the loss
@@ -41,6 +42,21 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
                sdf_tracks=sdf_last.view(b, r, 1), rgb_loss=losses["rgb_loss"], DC_loss=losses["DC_loss"],
                eikonal_loss=losses["eikonal_loss"], mse=losses["mse"], PSNR=psnr(losses["mse"]), loss_all=losses["all"])
     return ret
+
+
+def surface_losses(opt, sdf_field, xyzs, res=None):
+    """The POINT side of a bundle-adjustment iteration (pipelines/BA.py:117-131) and the "sfm" branch of BA.compute_loss
+    (BA.py:199-202): tracked 3-D points are projected onto the surface, `xyzs_new, normals_value = get_surface_pts(xyzs)`,
+    re-evaluated, `sdfs = infer_sdf(xyzs_new)`, and give  sdf_surf = L1(sdfs, 0),  eikonal_loss = L1(normals_value, 1)
+    and  mask_surf = |sdfs| < 2 * (extent / 10 / opt.Res).  Every field evaluation is one fused point-query node
+    (ls2fm_sdf_eval forward, ls2fm_sdf_points_bwd backward with the analytic double backward of the normal); the
+    re-projection term the drivers add on top of `xyzs_new` is camera-side logic (world2cam / cam2img), out of scope."""
+    xyzs_new, normals_value = sdf_field.get_surface_pts(xyzs)
+    sdfs = sdf_field.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1)
+    res = int(opt.Res) if res is None else int(res)
+    sdf_threshold = (sdf_field.bound_max.reshape(-1)[0] - sdf_field.bound_min.reshape(-1)[0]) / 10 / res
+    return dict(xyzs_new=xyzs_new, gradients=normals_value, sdfs=sdfs, mask_surf=sdfs.abs() < 2 * sdf_threshold,
+                sdf_surf=sdfs.abs().mean(), eikonal_loss=(normals_value - 1).abs().mean())
 
 
 class RenderStage:

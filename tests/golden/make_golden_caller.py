@@ -47,7 +47,9 @@ def look_at_poses(n, s, gen):
     return torch.stack(out)
 
 
-def main():
+def import_reference_pipelines():
+    """-> (make_golden module, reference SDF, RadF, Renderer classes, pipelines.Camera, pipelines.BA) with the stubs of the
+    module docstring installed; cwd is left at the reference root (its option loader reads relative paths)"""
     import make_golden as MG
     assert os.path.isdir(MG.REF)
     MG.install_stubs()
@@ -71,6 +73,11 @@ def main():
     from models.Renderer import Renderer
     from pipelines import Camera as RefCamera
     from pipelines import BA as RefBA
+    return MG, SDF, RadF, Renderer, RefCamera, RefBA
+
+
+def main():
+    MG, SDF, RadF, Renderer, RefCamera, RefBA = import_reference_pipelines()
 
     for ci, (name, dataset, L, log2_T, dual, N, H, W, rand_rays) in enumerate(CASES):
         torch.manual_seed(7000 + ci)

@@ -50,3 +50,30 @@ def test_oracle_caller_chain_vs_reference(case):
             # beta: an ill-conditioned sum; the oracle repeats the reference's fp32 op order, so it lands close
             tol = 2e-3 if k == "beta" else 5e-5
             assert rel_err(got, g[key]) < tol, (pre, k, rel_err(got, g[key]))
+
+
+@pytest.mark.parametrize("case", ["points_step_dtu", "points_step_eth3d"])
+def test_oracle_points_step_vs_reference(case):
+    """the point side of a BA iteration (get_surface_pts -> infer_sdf -> sdf_surf / eikonal, BA.py:117-131, 199-202) as the
+    reference's own classes computed it (tests/golden/make_golden_points_step.py)"""
+    g = load_golden(case)
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    meta["bg_sdf"] = None
+    cfg = golden_cfg(meta)
+    w = meta["weights"]
+    table = cfg.table()
+    sd = golden_state(g, "sdf", requires_grad=True)
+    xyzs = torch.from_numpy(g["xyzs"]).clone().requires_grad_(True)
+    xyzs_new, nlen = F.get_surface_pts(xyzs, sd, cfg, table)
+    sdfs = F.infer_sdf(xyzs_new, sd, cfg, table, "ret_sdf").view(-1, 1)
+    assert rel_err(xyzs_new, g["xyzs_new"]) < 2e-6 and rel_err(nlen, g["normals_value"]) < 2e-6 and rel_err(sdfs, g["sdfs"]) < 2e-5
+    assert np.array_equal((sdfs.abs() < 2 * float(g["sdf_threshold"])).numpy(), g["mask_surf"])
+    sdf_surf, eik = sdfs.abs().mean(), (nlen - 1).abs().mean()
+    total = 10 ** w["sdf_surf"] * sdf_surf + 10 ** w["eikonal_loss"] * eik
+    for name, val in (("sdf_surf", sdf_surf), ("eikonal_loss", eik), ("loss_all", total)):
+        assert abs(float(val.detach()) - float(g[name])) <= 5e-6 * max(abs(float(g[name])), 1e-3), name
+    total.backward()
+    assert rel_err(xyzs.grad, g["grad/xyzs"]) < 5e-5
+    for k, v in sd.items():
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert rel_err(got, g[f"grad/sdf/{k}"]) < 5e-5, k
