@@ -2,7 +2,8 @@
 """Randomised sweep: fused render (fwd + bwd, with and without pose gradients) against the composed autograd form over
 random ray counts, sample counts, datasets, level counts / table sizes, field modes and upstream-gradient subsets.
 Quantities the fp32 composed form itself cannot resolve to the bar (sums of terms of both signs over every sample: d beta,
-the last layer's bias / weight_g under random cotangents) are re-judged against the CPU oracle run in fp64.
+the last layer's bias / weight_g under random cotangents) are re-judged: d beta against its exactly summed value
+(oracle.fields.beta_gradient_exact_sum), the others against the CPU oracle run in fp64.
 usage: python tests/fuzz_fused.py [n_cases] [seed] [only_case]    (pytest entry: tests/test_hip_fuzz.py)"""
 import os
 import random
@@ -24,7 +25,7 @@ KEYS = ["rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"]
 
 
 def _tol(name):
-    return 1e-4          # d beta included: failures against the fp32 composed form are re-judged against the fp64 oracle
+    return 1e-4          # d beta included: failures against the fp32 composed form are re-judged (see one_case)
 
 
 def oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot, pose=False):
@@ -42,6 +43,17 @@ def oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, cent
     if pose:
         out["d_center"], out["d_ray"] = c64.grad, r64.grad
     return out
+
+
+def exact_beta(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot):
+    """(d loss / d beta of the fp32 computation summed exactly, condition number of that sum)"""
+    cfg = OF.dataset_config(ds, dual_field=dual, sample_intvs=n_samples, n_levels=L, log2_hashmap_size=log2_T,
+                            base_resolution=base, bgcolor=tuple(bg), inside=bool(opt.data.inside))
+    osd = {k: v.detach().cpu().float() for k, v in sdf.state_dict().items()}
+    ord_ = {k: v.detach().cpu().float() for k, v in rad.state_dict().items()}
+    cot64 = {k: v.cpu().double() for k, v in cot.items()}
+    return OF.beta_gradient_exact_sum(cfg, center.detach().cpu().float(), ray.detach().cpu().float(), osd, ord_,
+                                      lambda ret: sum((ret[k] * cot64[k]).sum() for k in used), with_condition=True)
 
 
 def one_case(case, rng, skip=False):
@@ -97,11 +109,22 @@ def one_case(case, rng, skip=False):
         o64 = oracle64_grads(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot, pose)
         still = []
         for k, _ in bad:
+            if k == "s.beta":
+                # d beta: the kernel sums it in fp64, so it is held to the bar against the EXACTLY SUMMED value of the fp32
+                # computation (oracle.fields.beta_gradient_exact_sum: fp32 field, everything beta enters in fp64 -- an all-fp64
+                # oracle evaluates a slightly different field, see its docstring), widened only by the conditioning of the sum
+                exact, cond = exact_beta(opt, ds, dual, n_samples, L, log2_T, base, bg, sdf, rad, center, ray, used, cot)
+                ef = rel_err(res["fused"][1][k], exact)
+                ec = rel_err(res["composed"][1][k], exact)
+                bar = max(_tol(k), 2.0 * 6e-8 * cond)
+                judged += f" [{k}: fused vs exact sum {ef:.1e}, composed {ec:.1e}, condition {cond:.2g}, bar {bar:.1e}]"
+                if not ef < bar:
+                    still.append((k, ef))
+                continue
             ef, ec = rel_err(res["fused"][1][k], o64[k]), rel_err(res["composed"][1][k], o64[k])
             judged += f" [{k}: fused vs fp64 oracle {ef:.1e}, composed vs fp64 oracle {ec:.1e}]"
-            # as good as fp32 autograd on an ill-conditioned sum is good enough -- except d beta, which the kernel sums in
-            # fp64 and which is held to the bar against the true (fp64) value outright
-            if not ef < (_tol(k) if k == "s.beta" else max(_tol(k), 2.0 * ec)):
+            # as good as fp32 autograd on an ill-conditioned sum is good enough
+            if not ef < max(_tol(k), 2.0 * ec):
                 still.append((k, ef))
         bad = still
     tag = (f"case {case}: {ds} dual={dual} rays={n_rays} N={n_samples} L={L} T=2^{log2_T} base={base} pose={pose} "
