@@ -137,9 +137,9 @@ __device__ __forceinline__ int wave_scan_incl_i32(int v, int lane) {
 }
 
 // nt = workgroup size: a multiple of 64, 64 <= nt <= 512.  The job's [n_tiles][16] block of counts goes through LDS in
-// pieces of 256 tiles (coalesced, independent loads in flight together: a thread walking its column in global memory pays one
+// pieces of 512 tiles (the benchmark: one piece; coalesced, independent loads in flight together: a thread walking its column in global memory pays one
 // dependent ~1 us access per tile, 20+ us per job -- and these jobs share a launch with shade_fwd).
-constexpr int kScanTiles = 256;
+constexpr int kScanTiles = 512;
 constexpr int kScanArenaInts = kScanTiles * kScanGroup + (512 / kScanGroup) * kScanGroup + LS2FM_MAX_LEVELS + 1;
 // `arena`: kScanArenaInts ints of the caller's LDS (the host kernel lends one of its own arrays: its LDS budget decides how
 // many of its workgroups fit a CU)
@@ -193,30 +193,41 @@ constexpr int kScanArenaInts = kScanTiles * kScanGroup + (512 / kScanGroup) * kS
     if (!s_last) return;
     const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
     constexpr int kChunks = (kBins + 63) / 64;
-    for (int lv = wave; lv < LS2FM_MAX_LEVELS; lv += n_waves) {
+    constexpr int kHeld = 4;                     // levels a wave keeps in registers between the two passes (16 levels / >= 4 waves)
+    int held[kHeld][kChunks];
+#pragma unroll
+    for (int h = 0; h < kHeld; ++h) {
+        const int lv = wave + h * n_waves;
         int tot = 0;
-        if (lv < sj.n_levels)
-            for (int c = 0; c < kChunks; ++c) {
-                const int bb = 64 * c + lane;
-                tot += bb < kBins ? __hip_atomic_load(&bm.count[lv * kBins + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            }
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int bb = 64 * c + lane;
+            held[h][c] = (lv < sj.n_levels && bb < kBins)
+                             ? __hip_atomic_load(&bm.count[lv * kBins + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            tot += held[h][c];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-        if (lane == 0) level_total[lv] = tot;
+        if (lane == 0 && lv < LS2FM_MAX_LEVELS) level_total[lv] = tot;
     }
     __syncthreads();
-    for (int lv = wave; lv < sj.n_levels; lv += n_waves) {
+#pragma unroll
+    for (int h = 0; h < kHeld; ++h) {
+        const int lv = wave + h * n_waves;
+        if (lv >= sj.n_levels) continue;
         int before = 0;
         for (int q = 0; q < lv; ++q) before += level_total[q];
         int run2 = 0;
+#pragma unroll
         for (int c = 0; c < kChunks; ++c) {
             const int bb = 64 * c + lane;
-            const int cnt = bb < kBins ? __hip_atomic_load(&bm.count[lv * kBins + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const int cnt = held[h][c];
             const int incl = wave_scan_incl_i32(cnt, lane);
             if (bb < kBins) bm.start[lv * kBins + bb] = before + run2 + incl - cnt;
             run2 += __shfl(incl, 63, 64);
         }
     }
+    // (more levels than kHeld * n_waves: not with 16 levels and the 4..8 waves of the kernels that run these jobs)
     if (tid == 0) *scan_ticket_dev(bm) = 0;
 }
 
