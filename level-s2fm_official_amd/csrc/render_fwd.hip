@@ -8,6 +8,7 @@
 //   shade_fwd    : block per ray, lane per sample: SDF MLP + analytic normal + (second field) + collapsed
 //                  radiance + VolSDF sigma, then the front-to-back composite as a wave/block scan
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "bin_items.h"
@@ -436,27 +437,30 @@ extern "C" int ls2fm_interleave_tables(const float* sdf_table, const float* rad_
 // cost-balanced cut of the walking order [grid 1 levels .., grid 2 levels ..] x chunks into 8 XCD pieces
 static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid_desc* g2, int l2, int n_samples, int n_chunks,
                              bool counting, int* most) {
-    static const double dense_w = [] { const char* e = getenv("LS2FM_DENSE_W"); return e ? atof(e) : -1.0; }();   // experiments
     double cost[2 * LS2FM_MAX_LEVELS], total = 0.0;
-    // two grids (same geometry): the walking order alternates them level by level, so every XCD's piece holds both kinds of
-    // pass-levels -- the first grid's are dearer (Jacobian channels, and the scatter's item counting when a backward follows:
-    // with "all of grid 1, then all of grid 2" the four XCDs owning grid 1 finished 20 us after the others)
-    static const double g1_env = [] { const char* e = getenv("LS2FM_G1_W"); return e ? atof(e) : -1.0; }();
-    const double g1_w = g1_env > 0.0 ? g1_env : (counting ? 1.5 : 1.1);          // measured (tools/enc_probe.py)
+    // Relative cost of a pass-level = summed workgroup durations INSIDE a training step (tools/enc_xcd_instep.py: the launch
+    // follows a backward, the L2s no longer hold the table slices; a fine hashed level of the second grid = 1): dense levels
+    // 0.23-0.33; hashed levels grow with the number of distinct cells a wave's consecutive samples touch (scale / n_samples):
+    // 0.71, 0.93, then 1.0.  The FIRST grid's pass-levels also write the Jacobian channels and, when a backward follows, count
+    // the scatter's items: hashed levels +10 %, dense levels +50 % (their increments collide in the LDS histogram).  Two grids
+    // (same geometry) alternate level by level in the walking order, so every XCD's piece holds both kinds (with "all of grid
+    // 1, then all of grid 2" the XCDs owning grid 1 finished 20 us late).
+    static double cm[4] = {0.27, 1.5, 1.1, 0.45};
+    static const bool cm_env = [] {
+        const char* e = getenv("LS2FM_CM");                      // experiments: "dense,first_dense,first_hashed,slope"
+        if (e) sscanf(e, "%lf,%lf,%lf,%lf", &cm[0], &cm[1], &cm[2], &cm[3]);
+        return e != nullptr;
+    }();
+    (void)cm_env;
     const int n_pl = l1 + l2;
     for (int pl = 0; pl < n_pl; ++pl) {
         const bool second = l2 > 0 && (pl & 1);
         const ls2fm_grid_desc* gd = second ? g2 : g1;
         const int l = l2 > 0 ? pl >> 1 : pl;
-        if (dense_w >= 0.0) {
-            cost[pl] = gd->hashed[l] ? 1.0 : dense_w;
-        } else {        // measured (tools/enc_ticks.py): dense levels ~0.28 of a fine hashed level; hashed levels grow with the
-                        // number of distinct cells a wave's consecutive samples touch (scale / n_samples)
-            const double rho = (double)gd->scale[l] / (double)n_samples;
-            const double h = 0.45 + 0.25 * log2(1.0 + rho);
-            cost[pl] = gd->hashed[l] ? (h > 0.95 ? 0.95 : h) : 0.28;
-        }
-        if (l2 > 0 && !second) cost[pl] *= g1_w;
+        const double rho = (double)gd->scale[l] / (double)n_samples;
+        const double h = 0.45 + cm[3] * log2(1.0 + rho);
+        cost[pl] = gd->hashed[l] ? (h > 1.0 ? 1.0 : h) : cm[0];
+        if (!second) cost[pl] *= gd->hashed[l] ? (counting ? cm[2] : 1.05) : (counting ? cm[1] : 1.1);
         total += cost[pl];
     }
     XcdPlan plan;

@@ -16,7 +16,8 @@ bench.randomize([sdf, rad])
 center, ray = bench.synthetic_rays(1024, 5.0, "cuda")
 n = 20
 lib = _lib.load()
-with torch.no_grad():
+train = len(sys.argv) > 1 and sys.argv[1] == "train"      # grad enabled: the launch also counts the scatter's items
+with (torch.enable_grad() if train else torch.no_grad()):
     for _ in range(3):
         ren.forward(opt, center, ray, sdf, rad)
     torch.cuda.synchronize()
@@ -38,5 +39,5 @@ t = [b / n / 100.0 for b in buf]          # us of summed workgroup time per laun
 ref = max(t)
 d = sdf.embed_fn.embedder_obj.desc
 for pl in range(32):
-    l = pl % 16
-    print(f"grid {pl // 16} level {l:2d} scale {d.scale[l]:8.1f} hashed {d.hashed[l]}  sum {t[pl]:9.1f} us  rel {t[pl] / ref:5.2f}")
+    l = pl >> 1                                  # walking order: (level 0, grid 1), (level 0, grid 2), (level 1, grid 1), ...
+    print(f"grid {pl & 1} level {l:2d} scale {d.scale[l]:8.1f} hashed {d.hashed[l]}  sum {t[pl]:9.1f} us  rel {t[pl] / ref:5.2f}")
