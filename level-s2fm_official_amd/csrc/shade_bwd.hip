@@ -45,11 +45,14 @@ __device__ __forceinline__ double wave_suffix_excl_f64(double v, int lane) {
     return s;
 }
 
-template <bool DUAL, int MAXT>
+// POSE: center / ray require gradients (BA "sfm_refine" with one camera, BA.py:153-154) -- the only case that needs the rows of
+// W0'^T DA that belong to the MLP's position inputs: 16 more MFMAs per hidden block and 8 more registers.
+template <bool DUAL, int MAXT, bool POSE>
 __global__ void __launch_bounds__(MAXT, 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
-                 Upstream up, float* __restrict__ out, int want_pose, ZeroJob zero) {
+                 Upstream up, float* __restrict__ out, ZeroJob zero) {
+    constexpr bool want_pose = POSE;
     // leading workgroups: the zero fills the rest of the backward needs (weight-gradient accumulators, point-split coarse
     // levels of the gradient tables) -- no memset / kernel launches and no cross-stream edge in front of the scatter
     if ((int)blockIdx.x < zero.blocks) {
@@ -611,8 +614,11 @@ int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, i
         zero.nb = count / 2;
         if (dtable2) { zero.c = reinterpret_cast<float4*>(dtable2 + 2 * first); zero.nc = count / 2; }
     }
-#define LS2FM_SHADE_BWD(DUAL, MAXT) \
-    shade_bwd_kernel<DUAL, MAXT><<<(unsigned)(n_rays + zero.blocks), threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, want_pose, zero)
+#define LS2FM_SHADE_BWD(DUAL, MAXT)                                                                                          \
+    do {                                                                                                                    \
+        if (want_pose) shade_bwd_kernel<DUAL, MAXT, true><<<(unsigned)(n_rays + zero.blocks), threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero); \
+        else shade_bwd_kernel<DUAL, MAXT, false><<<(unsigned)(n_rays + zero.blocks), threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero); \
+    } while (0)
     if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
     else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD
