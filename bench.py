@@ -173,6 +173,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path); the CPU figure is the "
                          "`cpu_baseline` leg of the GPU run")
+    # LS2FM_BENCH_BACKEND=gloo (tests of the N > 1 wiring on a one-GPU box: RCCL refuses two ranks per device, gloo carries
+    # device tensors): every rank then shares GPU 0 -- the figures of such a run mean nothing, its control flow is the real one
+    backend = os.environ.get("LS2FM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -182,7 +187,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ls2fm import _lib, fused
     from ls2fm.dist import GradAllReducer, enable_table_overlap

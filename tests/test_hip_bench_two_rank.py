@@ -1,0 +1,37 @@
+"""bench.py's N > 1 wiring, end to end, on the one GPU a test box has: two ranks launched the way the driver launches them
+(torch.distributed.run, one process per rank) with LS2FM_BENCH_BACKEND=gloo -- RCCL refuses two ranks per device, gloo carries
+device tensors.  The figures of such a run mean nothing (both ranks share the GPU, the all-reduce goes through the host); what
+is tested is the control flow the 2/4/8-GPU runs take: process-group set-up, sharded rays, the overlapped table-gradient
+reduction issued from inside the backward, barriers, the block-count and max-over-ranks reductions, ONE JSON line on rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+def test_bench_two_ranks_one_gpu(extra):
+    env = dict(os.environ, LS2FM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--rays", "256", "--samples", "32", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["launch"] == "eager"
+    assert d["config"]["parallelism"].startswith("dp2")
