@@ -10,8 +10,8 @@
 namespace {
 
 const char* const kNames[LS2FM_PROF_COUNT] = {
-    "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "wgrad_mlp_geo", "wgrad_dec_reduce",
-    "slab_accumulate", "scatter_fill", "finalize", "sdf_eval", "sphere_trace", "post_shade", "loss_head_fwd",
+    "prep_weights", "ray_encode_sdf", "ray_encode_rad", "shade_fwd", "shade_bwd", "wgrad_mlp_geo", "wgrad_dec",
+    "slab_accumulate", "scatter_fill", "reduce_finalize", "sdf_eval", "sphere_trace", "post_shade", "loss_head_fwd",
     "loss_head_bwd", "wgrad_mlp_sdf", "pose_grad", "ray_encode_pair"};
 
 struct Span { int id; hipEvent_t a, b; };

@@ -12,154 +12,40 @@
 //   finalize      un-collapse the radiance chain, weight-norm backward, d beta
 #include <cstdlib>
 
-#include "render_common.h"
+#include "wgrad_tail.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------- finalize
-// weight-norm backward of a whole layer:  W = (g/||v||) v  ->  dg = <dW,v>/||v|| ; dv = (g/||v||) dW - g <dW,v>/||v||^3 v.
-// Called by all 256 threads; 16 lanes cooperate on a row (coalesced accesses, 16-wide shuffle reduction).
-__device__ void weight_norm_bwd_rows(const float* v, const float* g, const float* dw, int dw_ld, int rows, int n_in,
-                                     float* dv, float* dg, int tid) {
-    const int sub = tid & 15;
-    for (int row0 = 0; row0 < rows; row0 += 16) {
-        const int row = row0 + (tid >> 4);
-        const bool on = row < rows;
-        float ss = 0.f, dot = 0.f;
-        if (on)
-            for (int k = sub; k < n_in; k += 16) {
-                const float x = v[row * n_in + k];
-                ss = fmaf(x, x, ss);
-                dot = fmaf(dw[row * dw_ld + k], x, dot);
-            }
-#pragma unroll
-        for (int m = 8; m > 0; m >>= 1) { ss += __shfl_xor(ss, m, 16); dot += __shfl_xor(dot, m, 16); }
-        if (on) {
-            const float nrm = sqrtf(ss);
-            const float s = g[row] / nrm;
-            const float c = g[row] * dot / (nrm * nrm * nrm);
-            for (int k = sub; k < n_in; k += 16) dv[row * n_in + k] = s * dw[row * dw_ld + k] - c * v[row * n_in + k];
-            if (sub == 0) dg[row] = dot / nrm;
-        }
-    }
+// ------------------------------------------------------------------------------------------- finalize (wgrad_tail.h)
+__global__ void __launch_bounds__(256)
+finalize_kernel(FinalizeArgs fa) {
+    finalize_task(fa, (int)blockIdx.x);
 }
 
+// ONE launch for the sum of the weight-gradient partials and the finalize tasks that consume it: workgroups [0, n_red) reduce
+// a row each (write-through stores, drained) and take a ticket; the kFinalizeTasks workgroups after them wait for the ticket to
+// reach n_red, then run their task on L2-bypassing loads of the reduced block.  All of them fit the chip at once many times over (and beside slab_accumulate's one 128 KB workgroup per
+// CU: 21 KB of LDS), the reducers are dispatched first and wait for nothing, so the waiters cannot starve them; the wait is
+// bounded anyway.  The ticket lives in the slack of the reduced-gradient block, which shade_bwd's leading workgroups zero.
 __global__ void __launch_bounds__(256)
-finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, int rad_in, int dual,
-                const Packed* __restrict__ pk, const float* __restrict__ wg, const float* __restrict__ dbeta, int64_t n_rays) {
-    __shared__ float s_dwc[3][68];
-    __shared__ float s_dbc[4];
-    __shared__ float s_dt1[3][64];
-    __shared__ float s_row[64][68];       // effective-weight gradients of the layer being processed
-    const int tid = threadIdx.x;
-
-    // one workgroup per layer (7 independent tasks; a single workgroup doing all of them was a 58 us latency chain):
-    // 0/1 SDF MLP layers, 2/3 second field's layers, 4..6 radiance layers (each re-derives the small shared terms)
-    const int task = blockIdx.x;
-    if (task < 4) {
-        const int which = task >> 1;
-        if (which && !dual) return;
-        const float* dW0 = wg + (which ? WgLayout::dG0 : WgLayout::dW0);
-        const float* dW1 = wg + (which ? WgLayout::dG1 : WgLayout::dW1);
-        const ls2fm_linear* lin = which ? P.geo_mlp : P.sdf_mlp;
-        const ls2fm_linear_grad* gl = which ? G.geo_mlp : G.sdf_mlp;
-        const int ind = which ? in_dim2 : in_dim;
-        if ((task & 1) == 0) {
-            weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, dW0, 36, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid);
-            if (tid < kHidden) gl[0].bias[tid] = dW0[tid * 36 + 35];
-            return;
-        }
-        for (int idx = tid; idx < kOut * kHidden; idx += 256) {
-            const int o = idx / kHidden, j = idx % kHidden;
-            s_row[o][j] = dW1[o * 65 + j] + ((which == 0 && o == 0) ? wg[WgLayout::dW1r0 + j] : 0.f);
-        }
-        __syncthreads();
-        weight_norm_bwd_rows(lin[1].weight_v, lin[1].weight_g, &s_row[0][0], 68, kOut, kHidden, gl[1].weight_v,
-                             gl[1].weight_g, tid);
-        if (tid < kOut) gl[1].bias[tid] = dW1[tid * 65 + 64];
+wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_red, int* __restrict__ ticket) {
+    const int bid = (int)blockIdx.x;
+    if (bid < n_red) {
+        reduce_partials_row(wp, wg, bid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through stores have landed
+        __syncthreads();                                         // (the row is written by wave 0)
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-
-    // ---- radiance decoder: expand dWc (3 x rad_in) and back through Wc = R2 R1 R0, bc = T1 b0 + R2 b1 + b2
-    for (int idx = tid; idx < 3 * 68; idx += 256) {
-        const int c = idx / 68, k = idx % 68;
-        const float* row = wg + WgLayout::dWc + c * 39;
-        float val = 0.f;
-        if (k < 6) val = row[k];
-        else if (k < 33) val = wg[WgLayout::dWv + c * 27 + (k - 6)];
-        else if (k < 49) val = row[6 + (k - 33)];
-        else if (k < 65) val = dual ? row[22 + (k - 49)] : 0.f;
-        s_dwc[c][k] = val;
-    }
-    if (tid < 3) s_dbc[tid] = wg[WgLayout::dWc + tid * 39 + 38];
-    __syncthreads();
-    for (int idx = tid; idx < 3 * 64; idx += 256) {       // dT1 = dWc R0^T + dbc b0^T
-        const int c = idx / 64, j = idx % 64;
-        float acc = s_dbc[c] * P.rad_mlp[0].bias[j];
-        for (int k = 0; k < rad_in; ++k) acc = fmaf(s_dwc[c][k], pk->r0[j][k], acc);
-        s_dt1[c][j] = acc;
-    }
-    if (task == 4) {
-        for (int idx = tid; idx < 64 * 68; idx += 256) {      // dR0 = T1^T dWc
-            const int j = idx / 68, k = idx % 68;
-            float acc = 0.f;
-            for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][j], s_dwc[c][k], acc);
-            s_row[j][k] = acc;
-        }
-        __syncthreads();
-        weight_norm_bwd_rows(P.rad_mlp[0].weight_v, P.rad_mlp[0].weight_g, &s_row[0][0], 68, 64, rad_in,
-                             G.rad_mlp[0].weight_v, G.rad_mlp[0].weight_g, tid);
-        if (tid < 64) {
-            float acc = 0.f;
-            for (int c = 0; c < 3; ++c) acc = fmaf(pk->t1[c][tid], s_dbc[c], acc);
-            G.rad_mlp[0].bias[tid] = acc;
-        }
-        // beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed ; dL/dbeta = fixed-order sum of the
-        // per-ray partials of shade_bwd (fp64)
-        {
-            __shared__ double s_db[256];
-            double acc = 0.0;
-            for (int64_t r = tid; r < n_rays; r += 256) acc += reinterpret_cast<const double*>(dbeta)[r];
-            s_db[tid] = acc;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) s_db[tid] += s_db[tid + o];
-                __syncthreads();
-            }
-            if (tid == 0) G.beta[0] = (float)(s_db[0] * (double)pk->beta * (double)P.beta_speed);
-        }
-        return;
-    }
-    __syncthreads();          // s_dt1 complete
-    if (task == 5) {
-        for (int idx = tid; idx < 64 * 64; idx += 256) {      // dR1 = R2^T dT1
-            const int m = idx / 64, j = idx % 64;
-            float acc = 0.f;
-            for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][m], s_dt1[c][j], acc);
-            s_row[m][j] = acc;
-        }
-        __syncthreads();
-        weight_norm_bwd_rows(P.rad_mlp[1].weight_v, P.rad_mlp[1].weight_g, &s_row[0][0], 68, 64, 64,
-                             G.rad_mlp[1].weight_v, G.rad_mlp[1].weight_g, tid);
-        if (tid < 64) {
-            float acc = 0.f;
-            for (int c = 0; c < 3; ++c) acc = fmaf(pk->r2[c][tid], s_dbc[c], acc);
-            G.rad_mlp[1].bias[tid] = acc;
-        }
-        return;
-    }
-    for (int idx = tid; idx < 3 * 64; idx += 256) {       // dR2 = dT1 R1^T + dbc b1^T
-        const int c = idx / 64, m = idx % 64;
-        float acc = s_dbc[c] * P.rad_mlp[1].bias[m];
-        for (int j = 0; j < 64; ++j) acc = fmaf(s_dt1[c][j], pk->r1[m][j], acc);
-        s_row[c][m] = acc;
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_red && ++spins < (1 << 24))
+            __builtin_amdgcn_s_sleep(16);
     }
     __syncthreads();
-    weight_norm_bwd_rows(P.rad_mlp[2].weight_v, P.rad_mlp[2].weight_g, &s_row[0][0], 68, 3, 64,
-                         G.rad_mlp[2].weight_v, G.rad_mlp[2].weight_g, tid);
-    if (tid < 3) G.rad_mlp[2].bias[tid] = s_dbc[tid];
+    finalize_task(fa, bid - n_red);                              // reads the reduced block with L2-bypassing loads (wg_load)
 }
 
 }  // namespace
@@ -167,7 +53,7 @@ finalize_kernel(ls2fm_params P, ls2fm_param_grads G, int in_dim, int in_dim2, in
 // weight-norm backward of the SDF MLP alone (point queries, points.hip): tasks 0 and 1 of finalize_kernel
 int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
                               const float* wg, hipStream_t stream) {
-    finalize_kernel<<<2, 256, 0, stream>>>(*params, *grads, in_dim, 0, 0, 0, pk, wg, nullptr, 0);
+    finalize_kernel<<<2, 256, 0, stream>>>(FinalizeArgs{*params, *grads, in_dim, 0, 0, 0, pk, wg, nullptr, 0});
     return ls2fm_launch_status();
 }
 
@@ -231,10 +117,16 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // the one fork of the backward: weight-gradient GEMMs -> reduce -> finalize run on the side stream, beside the table scatters
     forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
-    ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs);
+    Ls2fmWgradParts parts{};
+    ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
-    finalize_kernel<<<7, 256, 0, gs>>>(*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg,
-                                       ws + w.dbeta, n_rays);
+    {   // sum of the partials + finalize tasks, one launch (the ticket word: slack of the reduced-gradient block, zeroed above)
+        static_assert(WgLayout::total % 64 != 0 && (WgLayout::total + 63) / 64 * 64 - WgLayout::total >= 1, "ticket word in the block's slack");
+        const int n_red = kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec;
+        const FinalizeArgs fa{*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg, ws + w.dbeta, n_rays};
+        wgrad_tail_kernel<<<n_red + kFinalizeTasks, 256, 0, gs>>>(parts, ws + w.wg, fa, n_red,
+                                                                 reinterpret_cast<int*>(ws + w.wg + WgLayout::total));
+    }
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
 

@@ -320,9 +320,12 @@ int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, co
                            const WsLayout& w, const Packed* pk, const ls2fm_params* params, const float* center,
                            const float* ray, int64_t n_rays, const float* ws, float* d_center, float* d_ray, hipStream_t s);
 
-// wgrad_mlp.hip
+// wgrad_mlp.hip.  `defer`: leave the sum of the partials to the caller (render_bwd.hip runs it in the finalize launch) and
+// describe them here
+struct Ls2fmWgradParts { const float* sdf; const float* geo; const float* dec; int nb_mlp, nb_dec, dual; };
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
-                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only = false);
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only = false,
+                           Ls2fmWgradParts* defer = nullptr);
 
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,

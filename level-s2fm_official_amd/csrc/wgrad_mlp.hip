@@ -13,7 +13,7 @@
 // layout, read back as one ds_read_b128 per lane (4 consecutive samples = the 4 k-slots of 4 MFMAs).
 // Persistent waves keep all 85 accumulator registers for the whole kernel; workgroups reduce through LDS and write one
 // partial each, summed by wgrad_mlp_reduce in a fixed order (deterministic).
-#include "render_common.h"
+#include "wgrad_tail.h"
 
 namespace {
 
@@ -23,13 +23,9 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-constexpr int kWmThreads = 256;
-constexpr int kWmWaves = kWmThreads / 64;
 constexpr int kLd = 20;                          // floats per LDS tile row: 16 samples + 4 pad (16-B aligned rows)
 constexpr int kRowsU = 36, kRowsGf = 20;
 constexpr int kXRows = 2 * kRowsU + kRowsGf + 3 * 16;            // u, v, gf, da, gj, h
-constexpr int kRegsSdf = 48 + 16 + 16 + 5;       // dW0 tiles, dW1 tiles, dW1 row 0, db1
-constexpr int kRegsGeo = 48 + 16 + 4;
 
 template <bool GEO>
 __global__ void __launch_bounds__(kWmThreads, 2)
@@ -237,7 +233,6 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
 // Radiance-decoder columns: dWc (3 x 39) = sum over samples of dz [p, n, f, f2, 1]^T and dWv (3 x 27) = sum over rays of
 // (per-ray sums of dz) renc^T.  Every operand already lies in HBM as [row][sample]: the MFMA operands (row jl, 4
 // consecutive samples) are plain 16-byte loads, no LDS.
-constexpr int kRegsDec = 20;                     // 5 output tiles
 
 __device__ __forceinline__ float4 load4_masked(const float* __restrict__ row, int64_t s, int64_t n, bool on) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -297,59 +292,9 @@ wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__
     for (int q = tid; q < kRegsDec * 64; q += kWmThreads) dst[q] = red[q];
 }
 
-// sum of the per-workgroup partials (fixed order -> deterministic), scattered into the reduced-gradient buffer
-// (WgLayout).  One launch for all three producers: block ranges [0,85) SDF MLP, [85,153) second MLP, then 20 decoder.
 __global__ void __launch_bounds__(kWmThreads)
-wgrad_reduce_all_kernel(const float* __restrict__ part_sdf, const float* __restrict__ part_geo, const float* __restrict__ part_dec,
-                        int nb_mlp, int nb_dec, int dual, float* __restrict__ wg) {
-    __shared__ float s_sum[kWmWaves][64];
-    int k = blockIdx.x, kind = 0;
-    if (k >= kRegsSdf) { k -= kRegsSdf; kind = 1; if (!dual || k >= kRegsGeo) { k -= dual ? kRegsGeo : 0; kind = 2; } }
-    const float* part = kind == 0 ? part_sdf : (kind == 1 ? part_geo : part_dec);
-    const int R = kind == 0 ? kRegsSdf : (kind == 1 ? kRegsGeo : kRegsDec);
-    const int nb = kind == 2 ? nb_dec : nb_mlp;
-    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, jl = lane & 15, g = lane >> 4;
-    float s0 = 0.f, s1 = 0.f;
-    int b = grp;
-    for (; b + kWmWaves < nb; b += 2 * kWmWaves) {
-        s0 += part[((int64_t)b * R + k) * 64 + lane];
-        s1 += part[((int64_t)(b + kWmWaves) * R + k) * 64 + lane];
-    }
-    if (b < nb) s0 += part[((int64_t)b * R + k) * 64 + lane];
-    s_sum[grp][lane] = s0 + s1;
-    __syncthreads();
-    if (grp != 0) return;
-    const float v = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
-    if (kind == 2) {                              // decoder: rows = dz component 4g + q (g = 0, q < 3)
-        const int t = k / 4, c3 = 4 * g + (k & 3);
-        if (c3 >= 3) return;
-        float* dWc = wg + WgLayout::dWc + c3 * 39;
-        float* dWv = wg + WgLayout::dWv + c3 * 27;
-        if (t == 0) dWc[6 + jl] = v;
-        else if (t == 1) dWc[22 + jl] = v;
-        else if (t == 2) { if (jl < 6) dWc[jl] = v; else if (jl == 6) dWc[38] = v; }
-        else if (t == 3) dWv[jl] = v;
-        else if (16 + jl < kView) dWv[16 + jl] = v;
-        return;
-    }
-    const bool GEO = kind == 1;
-    float* dW0 = wg + (GEO ? WgLayout::dG0 : WgLayout::dW0);
-    float* dW1 = wg + (GEO ? WgLayout::dG1 : WgLayout::dW1);
-    if (k < 48) {                                 // dW0'[16m + 4g + q][k' = 16mk + jl] -> the reference's column order
-        const int m = k / 12, mk = (k / 4) % 3, q = k & 3;
-        const int kp = 16 * mk + jl;
-        if (kp < 36) dW0[(16 * m + 4 * g + q) * 36 + (kp < 32 ? 3 + kp : (kp < 35 ? kp - 32 : 35))] = v;
-    } else if (k < 64) {                          // dW1[1 + 4g + q][16m + jl]
-        const int m = (k - 48) / 4, q = k & 3;
-        dW1[(1 + 4 * g + q) * 65 + 16 * m + jl] = v;
-    } else if (!GEO && k < 80) {                  // dW1[0][16m + 4g + q] (both row-0 terms; already summed over jl)
-        const int m = (k - 64) / 4, q = k & 3;
-        if (jl == 0) dW1[16 * m + 4 * g + q] = v;
-    } else {                                      // db1
-        const int t = k - (GEO ? 64 : 80);
-        const int o = GEO ? 1 + 4 * t + g : 4 * t + g;
-        if (jl == 0 && o < kOut) dW1[o * 65 + 64] = v;
-    }
+wgrad_reduce_all_kernel(WgradParts wp, float* __restrict__ wg) {
+    reduce_partials_row(wp, wg, (int)blockIdx.x);
 }
 
 }  // namespace
@@ -360,7 +305,7 @@ int64_t ls2fm_wgrad_mlp_part_floats(int dual) {
 
 // enqueue every weight-gradient kernel of the backward (+ the reduction of their partials) on `s`
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
-                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only) {
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only, Ls2fmWgradParts* defer) {
     const int n_tiles = (int)((w.p + 15) / 16);
     int blocks = (n_tiles + kWmWaves - 1) / kWmWaves;
     if (blocks > kWgradMlpBlocks) blocks = kWgradMlpBlocks;
@@ -380,11 +325,12 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
     ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
     ls2fm_prof_begin(LS2FM_PROF_WGRAD_TAIL, s);
     if (sdf_only) {          // point queries: no decoder columns, the SDF MLP's partials only (blocks [0, kRegsSdf) of the reduction)
-        wgrad_reduce_all_kernel<<<kRegsSdf, kWmThreads, 0, s>>>(part1, part2, part3, blocks, 0, 0, ws + w.wg);
+        wgrad_reduce_all_kernel<<<kRegsSdf, kWmThreads, 0, s>>>(WgradParts{part1, part2, part3, blocks, 0, 0}, ws + w.wg);
     } else {
         wgrad_dec_kernel<<<dec_blocks, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3);
-        wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(part1, part2, part3, blocks,
-                                                                                                 dec_blocks, dual, ws + w.wg);
+        const WgradParts wp{part1, part2, part3, blocks, dec_blocks, dual};
+        if (defer) *defer = wp;
+        else wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(wp, ws + w.wg);
     }
     ls2fm_prof_end(LS2FM_PROF_WGRAD_TAIL, s);
     return LS2FM_OK;

@@ -12,7 +12,8 @@ x 4 B = 64 B per level per point):
   shade_bwd       : P * 2 * MACs  (a, q, dE, r: 4 * 35*64; W1^T g 17*64; second field 2 * 35*64 + 16*64)
   wgrad_mlp_*     : 2 * P * sum(M*N) over the weight-gradient GEMMs of that MLP (f32 MFMA).  The hidden-layer
                     re-derivation the kernel performs instead of reading operands back from HBM is NOT counted as
-                    algorithmic work.  (wgrad_dec_reduce: decoder columns + the partial sums of all three.)
+                    algorithmic work.  (wgrad_dec: the decoder columns; reduce_finalize: the fixed-order sum of all three
+                    producers' partials and the finalize tasks, one launch.)
 While the profiler is enabled the library launches serially (no side-stream overlap), so every span is the duration of
 that kernel alone and agrees with rocprofv3's per-kernel averages.
 """
