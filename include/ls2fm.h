@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 2
+#define LS2FM_ABI_VERSION 3
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -235,7 +235,7 @@ typedef struct ls2fm_loss_spec {
     const uint8_t* mask_dc;       /* [n_rays] or NULL: mask_finish */
     const uint8_t* mask_mse;      /* [n_rays] or NULL: mask_bg */
     const float* weights;         /* DEVICE float[3] = 10^w of (rgb, eikonal, DC) */
-    float* terms;                 /* DEVICE float[6]: forward output (layout of ls2fm_loss_head_fwd) */
+    float* terms;                 /* DEVICE float[8]: forward output (layout of ls2fm_loss_head_fwd) */
     double* sums;                 /* DEVICE double[8]: forward output, backward input */
     const float* d_terms;         /* backward: DEVICE float[5] upstream of terms[0..4], or NULL = zeros */
     const float* d_total;         /* backward: DEVICE float[1] additional upstream of the weighted total, or NULL */
@@ -290,6 +290,27 @@ int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* gri
                        int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
                        void* workspace, void* stream);
 
+/* ls2fm_sdf_eval (sdf only) with the packed weights a preceding ls2fm_sdf_eval / ls2fm_sphere_trace call left in `workspace`
+ * (same stream, same parameters): no weight preparation launch.  Used between a tracing call and the evaluation of its track. */
+int ls2fm_sdf_eval_prepared(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                            const float* p, int64_t n, float* sdf, const void* workspace, void* stream);
+
+/* The tail of SDF.sphere_tracing for a ray batch (models/SDF.py:203-214) and the mask lines of CameraSet.render
+ * (pipelines/Camera.py:515-516), with the trip count K read from the device (what ls2fm_sphere_trace left in `trips`): a
+ * captured stage step never returns to the host.  sdf_tracks [n_rays][k_max] = the graph-enabled SDF values of the track points
+ * (ls2fm_sdf_eval on `track`), k_max = iters_max.
+ *   d_pred [n_rays]   = near + sum_{k < max(K,1)} sdf_tracks[r][k], replaced by far where it exceeds it
+ *   sdf_last [n_rays] = sdf_tracks[r][max(K,1) - 1];   finish [n_rays] (u8) = |sdf_last| < finish_threshold
+ *   rgb_gt [n_rays][3] (optional): mask_bg (u8) = bg_lo < mean(rgb_gt[r]) < bg_hi;  mask_dc (u8) = finish & mask_bg
+ *   gate [n_rays] (u8): 1 where d_pred was not clamped (the backward's pass-through mask)
+ * _bwd: d_sdf_tracks [n_rays][k_max] = (k < max(K,1) && gate[r]) * d_dpred[r] + (k == max(K,1) - 1) * d_sdf_last[r]; either
+ * upstream may be NULL. */
+int ls2fm_trace_depth_fwd(const float* sdf_tracks, const int32_t* trips, const float* near, const float* far, int64_t n_rays,
+                          int32_t k_max, float finish_threshold, const float* rgb_gt, float bg_lo, float bg_hi, float* d_pred,
+                          float* sdf_last, uint8_t* finish, uint8_t* mask_bg, uint8_t* mask_dc, uint8_t* gate, void* stream);
+int ls2fm_trace_depth_bwd(const float* d_dpred, const float* d_sdf_last, const int32_t* trips, const uint8_t* gate,
+                          int64_t n_rays, int32_t k_max, float* d_sdf_tracks, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Loss head over the renderer's outputs: the scalar terms the reference's stages form
  * right after Renderer.forward, in one kernel each way instead of ~35 launch-bound PyTorch kernels.
@@ -301,7 +322,8 @@ int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* gri
  *   (sphere-traced d_points; NULL = no DC term); mask_* uint8 [n_rays] or NULL (= every ray): mask_eik selects the rays
  *   whose samples enter the eikonal mean, mask_dc = mask_finish, mask_mse = mask_bg.
  *   weights float[3] (DEVICE) = 10^w of (rgb, eikonal, DC).
- *   terms float[6] (DEVICE, overwritten) = {rgb L1 mean, eikonal mean, DC mean, masked MSE, weighted total, total again}.
+ *   terms float[8] (DEVICE, overwritten) = {rgb L1 mean, eikonal mean, DC mean, masked MSE, weighted total, total again,
+ *   PSNR = -10 log10(masked MSE) (Camera.py:534), 0}.
  *   sums double[8] (DEVICE, overwritten) = {S|rgb-gt|, n, S| |n|-1 |, n, S smooth_l1, n, S (rgb-gt)^2, n}: kept by the
  *   caller for the backward, and what a sharded run all-reduces for global normalisation.  Deterministic (fixed-order
  *   fp64 partials).  The workspace (ls2fm_loss_head_workspace_bytes) is zero-filled ONCE by the caller and reusable.
@@ -319,7 +341,7 @@ int ls2fm_loss_head_bwd(const float* rgb, const float* rgb_gt, const float* norm
                         const float* depth_ref, const uint8_t* mask_eik, const uint8_t* mask_dc, const uint8_t* mask_mse,
                         int64_t n_rays, int32_t n_samples, const float* weights, const float* d_terms, const float* d_total,
                         float* d_rgb, float* d_normals, float* d_depth, float* d_depth_ref, const double* sums, void* stream);
-/* terms float[6] (DEVICE, overwritten) from sums double[8] (DEVICE) -- e.g. after a sharded run all-reduced the sums. */
+/* terms float[8] (DEVICE, overwritten) from sums double[8] (DEVICE) -- e.g. after a sharded run all-reduced the sums. */
 int ls2fm_loss_terms_from_sums(const double* sums, const float* weights, float* terms, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

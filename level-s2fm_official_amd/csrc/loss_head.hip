@@ -35,6 +35,8 @@ __device__ __forceinline__ void finish_terms(const double* s, const float* w, fl
     terms[0] = rgb; terms[1] = eik; terms[2] = dc; terms[3] = mse;
     terms[4] = fmaf(w[2], dc, fmaf(w[1], eik, w[0] * rgb));
     terms[5] = terms[4];
+    terms[6] = -10.0f * log10f(mse);              // PSNR (Camera.py:534): ready with the terms, no torch op between forward and backward
+    terms[7] = 0.f;
     for (int k = 0; k < kSums; ++k) sums_out[k] = s[k];
 }
 

@@ -379,6 +379,29 @@ extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_de
     return ls2fm_launch_status();
 }
 
+// sdf only, with the packed weights a preceding ls2fm_sdf_eval / ls2fm_sphere_trace left in `workspace` (same stream, same
+// parameters): no weight prep -- a 14 us latency chain -- between a tracing call and the evaluation of its track
+extern "C" int ls2fm_sdf_eval_prepared(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                       const float* p, int64_t n, float* sdf, const void* workspace, void* stream) {
+    LS2FM_CHECK_ARG(field_ok(field, grid, params) && n >= 0);
+    if (n == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(p && sdf);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const Packed* pk = (const Packed*)workspace;
+    const FieldC fc = make_field_c(field);
+    const LevelSet lv = make_level_set(grid);
+    ls2fm_prof_begin(LS2FM_PROF_SDF_EVAL, s);
+    if (n <= 65536)
+        sdf_eval_wide_kernel<<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table,
+                                                                      p, n, sdf);
+    else
+        sdf_eval_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p,
+                                                                          Lattice{}, n, sdf, nullptr, nullptr);
+    ls2fm_prof_end(LS2FM_PROF_SDF_EVAL, s);
+    return ls2fm_launch_status();
+}
+
 extern "C" int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                                 int64_t n_side, int64_t first, int64_t count, int32_t ref_indexing, const double* step,
                                 const double* origin, float* sdf, void* workspace, void* stream) {

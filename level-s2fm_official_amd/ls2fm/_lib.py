@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -116,6 +116,10 @@ _SIGNATURES = {
     "ls2fm_loss_terms_from_sums": (c_int32, [_P, _P, _P, _P]),
     "ls2fm_sphere_trace": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
                                      c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ls2fm_sdf_eval_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P]),
+    "ls2fm_trace_depth_fwd": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_float, _P, c_float, c_float, _P, _P, _P, _P, _P, _P,
+                                        _P]),
+    "ls2fm_trace_depth_bwd": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "ls2fm_loss_head_workspace_bytes": (c_int64, []),
     "ls2fm_loss_head_fwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
     "ls2fm_loss_head_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -271,12 +271,13 @@ def _refresh_dual_table(lib, plan, sdf_table, rad_table):
 
 class FusedLoss:
     """What the fused loss head of one render needs (ls2fm_loss_spec): built by ls2fm.losses.RenderLossHead.spec()."""
-    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts")
+    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts", "psnr")
 
     def __init__(self, weights, rgb_gt, mask_eik=None, mask_dc=None, mask_mse=None, global_counts="allreduce"):
         self.weights, self.rgb_gt = weights, rgb_gt
         self.mask_eik, self.mask_dc, self.mask_mse = mask_eik, mask_dc, mask_mse
         self.global_counts = global_counts
+        self.psnr = None                        # set by the render: terms[6] = -10 log10(mse)
 
 
 def _loss_struct(fl, depth_ref, terms, sums, d_terms=None, d_total=None, d_depth_ref=None):
@@ -339,7 +340,7 @@ class _Render(torch.autograd.Function):
             dref = None if depth_ref is None else depth_ref.detach().reshape(-1).float().contiguous()
             if fl.rgb_gt.numel() != 3 * n_rays or (dref is not None and dref.numel() != n_rays):
                 raise RuntimeError("ls2fm: fused loss head: rgb_gt / d_points do not match the rays")
-            terms = torch.empty(6, device=dev, dtype=torch.float32)
+            terms = torch.empty(8, device=dev, dtype=torch.float32)      # rgb, eikonal, DC, mse, all, all, PSNR, -
             sums = torch.empty(8, device=dev, dtype=torch.float64)
             lspec = _loss_struct(fl, dref, terms, sums)
             opts.loss = ctypes.pointer(lspec)
@@ -361,6 +362,7 @@ class _Render(torch.autograd.Function):
         ctx.save_for_backward(c, d, *ps)
         if fl is None:
             return rgb, sdfs, normals, depth, nmlp
+        fl.psnr = terms[6]                      # (no graph: the stages only log it)
         return rgb, sdfs, normals, depth, nmlp, terms[:5], terms[5]
 
     @staticmethod
@@ -430,6 +432,7 @@ def render(renderer, opt, center, ray, sdf_field, rad_field, loss=None, d_points
     ret = {"rgb": out[0], "sdfs_volume": out[1], "normals": out[2], "depth_mlp": out[3], "normal_mlp": out[4]}
     if loss is not None:
         ret["loss_terms"], ret["loss_total"] = out[5], out[6]
+        ret["loss_psnr"] = loss.psnr.detach()
     return ret
 
 
@@ -541,6 +544,103 @@ def query_points(sdf_field, xyz, want_feat=False, want_normal=False):
     return sdf, (feat if want_feat else None), (normal if want_normal else None)
 
 
+class _TracedDepth(torch.autograd.Function):
+    """SDF.sphere_tracing's differentiable tail for a whole ray batch as ONE autograd node (ls2fm_sdf_eval on the track points,
+    ls2fm_trace_depth_fwd; backward: ls2fm_trace_depth_bwd, ls2fm_sdf_points_bwd), with the trip count K staying on the device.
+    -> d_pred [R], sdf_last [R] (differentiable), finish, mask_bg, mask_dc (uint8 [R])"""
+
+    @staticmethod
+    def forward(ctx, track, trips, near, far, rgb_gt, finish_thr, sdf_field, trace_ws, *params):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        n_rays, k_max = track.shape[0], track.shape[1]
+        p = track.detach().reshape(-1, 3).float().contiguous()
+        dev = p.device
+        fdesc = field_desc(sdf_field.opt)
+        gdesc = sdf_field.embed_fn.embedder_obj.desc
+        for t in params:
+            if not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
+                raise RuntimeError("ls2fm: fused point query needs contiguous fp32 GPU parameters")
+        pstruct = _params_struct(list(params), False, float(sdf_field.beta_speed), with_rad=False)
+        sdf = torch.empty(n_rays * k_max, device=dev)
+        if trace_ws is not None:                # the tracing call's workspace: its packed weights are these parameters'
+            check(lib.ls2fm_sdf_eval_prepared(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n_rays * k_max,
+                                              ptr(sdf), ptr(trace_ws), stream_ptr()), "ls2fm_sdf_eval_prepared")
+        else:
+            ws = _sdf_workspace(dev)
+            check(lib.ls2fm_sdf_eval(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n_rays * k_max,
+                                     ptr(sdf), None, None, ptr(ws), stream_ptr()), "ls2fm_sdf_eval")
+        d_pred = torch.empty(n_rays, device=dev)
+        last = torch.empty(n_rays, device=dev)
+        finish, gate = (torch.empty(n_rays, device=dev, dtype=torch.uint8) for _ in range(2))
+        gt = None
+        mask_bg = mask_dc = None
+        if rgb_gt is not None:
+            gt = rgb_gt.detach().reshape(-1, 3).float().contiguous()
+            if gt.shape[0] != n_rays:
+                raise RuntimeError("ls2fm: traced depth: rgbs_gt does not match the rays")
+            mask_bg, mask_dc = (torch.empty(n_rays, device=dev, dtype=torch.uint8) for _ in range(2))
+        check(lib.ls2fm_trace_depth_fwd(ptr(sdf), ptr(trips), ptr(near), ptr(far), n_rays, k_max, float(finish_thr), ptr(gt), 0.05,
+                                        0.95, ptr(d_pred), ptr(last), ptr(finish), ptr(mask_bg), ptr(mask_dc), ptr(gate),
+                                        stream_ptr()), "ls2fm_trace_depth_fwd")
+        ctx.meta = (fdesc, gdesc, float(sdf_field.beta_speed), n_rays, k_max)
+        ctx.save_for_backward(p, trips, gate, *params)
+        outs = (d_pred, last, finish, mask_bg if mask_bg is not None else finish, mask_dc if mask_dc is not None else finish)
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_dpred, d_last, *_):
+        lib = _lib.load()
+        fdesc, gdesc, beta_speed, n_rays, k_max = ctx.meta
+        p, trips, gate, *ps = ctx.saved_tensors
+        n_in = 8
+        if d_dpred is None and d_last is None:
+            return (None,) * (n_in + len(ps))
+        d_dpred = None if d_dpred is None else d_dpred.reshape(-1).float().contiguous()
+        d_last = None if d_last is None else d_last.reshape(-1).float().contiguous()
+        d_sdf = torch.empty(n_rays * k_max, device=p.device)
+        check(lib.ls2fm_trace_depth_bwd(ptr(d_dpred), ptr(d_last), ptr(trips), ptr(gate), n_rays, k_max, ptr(d_sdf), stream_ptr()),
+              "ls2fm_trace_depth_bwd")
+        flat, grads = flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
+        grads[7].zero_()                               # beta does not enter a point query
+        gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
+        pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
+        n = n_rays * k_max
+        ws_bytes = lib.ls2fm_sdf_points_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(gdesc), n)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
+        ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
+        check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
+                                       None, None, ctypes.byref(gstruct), None, ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
+        return (None,) * n_in + tuple(grads)
+
+
+def traced_depth(sdf_field, track, trips, near, far, rgbs_gt=None, trace_ws=None):
+    """track [R, iters_max (+1), 3], trips int32[1] on the device, near / far [R] (what sphere_trace(sync=False) returns) ->
+    d_pred [R], sdf_last [R] (graph attached), finish_mask [R] bool, and with rgbs_gt [R,3]: mask_bg, mask_finish & mask_bg as
+    uint8 [R] (what the fused loss head takes) -- else None, None"""
+    k_max = max(int(sdf_field.iters_max), 1)
+    pts = track[:, :k_max, :]
+    thr = _finish_threshold(sdf_field)
+    ts, _ = param_tensors(sdf_field, None)
+    d_pred, last, finish, mask_bg, mask_dc = _TracedDepth.apply(pts, trips, near.reshape(-1), far.reshape(-1), rgbs_gt, thr, sdf_field,
+                                                                trace_ws, *ts)
+    if rgbs_gt is None:
+        return d_pred, last, finish.bool(), None, None
+    return d_pred, last, finish.bool(), mask_bg, mask_dc
+
+
+def _finish_threshold(sdf_field):
+    """(bound_max[0] - bound_min[0]) / 10 / Res in the reference's fp32 arithmetic (SDF.py:213-214), from the options: no device
+    round trip (the module's bound tensors live on the GPU)"""
+    import numpy as np
+    data = sdf_field.opt.data
+    extent = np.float32(data.bound_max[0]) - np.float32(data.bound_min[0])
+    return float(extent / np.float32(10) / np.float32(sdf_field.opt.Res))
+
+
 def sdf_volume(sdf_field, n_side, step, origin, first=0, count=None, reference_indexing=True):
     """no-graph SDF sweep over an n_side^3 lattice built on the device (ls2fm_sdf_volume): flat float32 [count].
     step / origin: 3 doubles each, per output column; reference_indexing: the lattice arithmetic of the reference's
@@ -591,6 +691,7 @@ def sphere_trace(sdf_field, o, d, history=False, sync=True):
         if _dist.is_distributed():
             import torch.distributed as tdist
             tdist.all_reduce(trips, op=tdist.ReduceOp.MAX)
+        track._ls2fm_trace_ws = ws              # packed weights of these parameters: reused by traced_depth (no second prep)
         return near, far, track, t_end, trips
     k = int(trips.item())           # the reference syncs here too (its loop condition is a host-side .sum())
     k = _dist.global_max_int(k, dev)                  # sharded rays: keep K identical to the single-GPU run

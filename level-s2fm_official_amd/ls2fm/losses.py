@@ -49,7 +49,7 @@ class _LossHead(torch.autograd.Function):
         rgb_c, nrm_c, dep_c, gt_c = _lib.cf(rgb), _lib.cf(normals), _lib.cf(depth), _lib.cf(rgb_gt)
         ref_c = _lib.cf(depth_ref) if depth_ref is not None else None
         assert rgb_c.numel() == 3 * n_rays and gt_c.numel() == 3 * n_rays and dep_c.numel() == n_rays
-        terms = torch.empty(6, device=rgb.device, dtype=torch.float32)      # [5] = copy of the total (own output)
+        terms = torch.empty(8, device=rgb.device, dtype=torch.float32)      # [5] = copy of the total (own output), [6] = PSNR
         sums = torch.empty(8, device=rgb.device, dtype=torch.float64)
         _lib.check(lib.ls2fm_loss_head_fwd(_lib.ptr(rgb_c), _lib.ptr(gt_c), _lib.ptr(nrm_c), _lib.ptr(dep_c), _lib.ptr(ref_c),
                                            _lib.ptr(mask_eik), _lib.ptr(mask_dc), _lib.ptr(mask_mse), n_rays, n_samples,

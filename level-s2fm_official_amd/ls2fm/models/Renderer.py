@@ -88,7 +88,9 @@ class Renderer(nn.Module):
             spec = head.spec(rgbs_gt, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg,
                              n_rays=center.shape[0] * center.shape[1])
             ret = fused.render(self, opt, center, ray, SDF_Field, Rad_Field, loss=spec, d_points=d_points, plan=plan)
-            return ret, head.as_dict(ret.pop("loss_terms"), ret.pop("loss_total"))
+            losses = head.as_dict(ret.pop("loss_terms"), ret.pop("loss_total"))
+            losses["PSNR"] = ret.pop("loss_psnr")          # -10 log10(mse), formed with the terms (no graph)
+            return ret, losses
         ret = self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
         return ret, head(ret, rgbs_gt, d_points=d_points, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg)
 

@@ -152,32 +152,26 @@ class SDF(nn.Module):
             track = [p_s]
         return torch.stack(track, dim=1), t_end[-1], trips
 
-    def _sphere_tracing_static(self, o, d, shape2):
+    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None):
         """sphere_tracing without the host round trip for the trip count K (hipGraph-capturable, ls2fm.stage): the kernel leaves K
         on the device and runs every ray for iters_max trips anyway; the differentiable depth sums the first K track points
-        through a device-side mask (K = 0: the single current point, SDF.py:201-202).  Same d_pred / sdf_last / finish_mask as
-        the synchronising form; the RNG-dependent `sampled_pts` (its SHAPE depends on K) is not produced (None)."""
+        through a device-side mask (K = 0: the single current point, SDF.py:201-202) -- one fused node, ls2fm.fused.traced_depth.
+        Same d_pred / sdf_last / finish_mask as the synchronising form; the RNG-dependent `sampled_pts` (its SHAPE depends on K)
+        is not produced (None).  rgbs_gt [.., 3]: the node also forms CameraSet.render's mask_bg and mask_finish & mask_bg
+        (Camera.py:515-516) -> self.last_masks."""
         if not fused.available(self, o):
             raise RuntimeError("ls2fm: static_trips needs the fused tracing kernel (GPU tensors, reference layer sizes)")
         with torch.no_grad():
             near, far, track, _, trips = fused.sphere_trace(self, o.detach(), d.detach(), sync=False)
-        k_max = max(int(self.iters_max), 1)
-        pts = track[:, :k_max, :]
-        sdf_tracks = self.infer_sdf(pts.detach(), mode="ret_sdf")                        # graph-enabled  [R,k_max,1]
-        k_eff = trips.clamp(min=1).to(torch.int64)                                        # [1]
-        live = (torch.arange(k_max, device=o.device)[None, :, None] < k_eff).to(sdf_tracks.dtype)
-        d_pred = (sdf_tracks * live).sum(dim=-2).view(*shape2) + near.view(*shape2)
-        far2 = far.view(*shape2)
-        d_pred = torch.where(d_pred > far2, far2, d_pred)
-        last = sdf_tracks.gather(1, (k_eff - 1).view(1, 1, 1).expand(sdf_tracks.shape[0], 1, 1))[:, 0, :]       # [R,1]
-        extent = self.bound_max.reshape(-1)[0] - self.bound_min.reshape(-1)[0]
-        finish_mask = last.abs() < extent / 10 / self.opt.Res
+        d_pred, last, finish, mask_bg, mask_dc = fused.traced_depth(self, track, trips, near, far, rgbs_gt,
+                                                                    trace_ws=getattr(track, "_ls2fm_trace_ws", None))
         self.last_trips = trips
-        return d_pred, last[:, 0], None, finish_mask
+        self.last_masks = (mask_bg, mask_dc)             # uint8 [R] each (rgbs_gt given): what the fused loss head takes
+        return d_pred.view(*shape2), last, None, finish.view(-1, 1)
 
     def sphere_tracing(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129),
                        n_secant_steps=8, depth_range=(0.0, 2.4), max_points=3500000, rad=1.0, iter=0,
-                       impl="fused", static_trips=False):
+                       impl="fused", static_trips=False, rgbs_gt=None):
         """ray0, ray_direction [B,R,3] -> (d_pred [B,R], sdf_last [B*R], sampled_pts [1, <=4096+B*R, 3],
         finish_mask [B*R,1]).  `d_pred = near + sum_k sdf(track_k)` is differentiable w.r.t. the SDF
         parameters; the root-find itself runs without a graph.  Unused reference arguments are accepted."""
@@ -185,7 +179,7 @@ class SDF(nn.Module):
         o = ray0.reshape(-1, 3)
         d = ray_direction.reshape(-1, 3)
         if static_trips:
-            return self._sphere_tracing_static(o, d, shape2)
+            return self._sphere_tracing_static(o, d, shape2, rgbs_gt)
         with torch.no_grad():
             if impl == "fused" and fused.available(self, o):
                 near, far, pts_tracks, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach())

@@ -30,17 +30,28 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
     centers, rays [B,R,3]; rgbs_gt [B,R,3].  The tracing runs first (it is independent of the render): its masks and depth
     are then inputs of the loss head that runs INSIDE the fused render (Renderer.forward_with_loss)."""
     b, r = centers.shape[:2]
-    d_points, sdf_last, _, mask_finish = sdf_field.sphere_tracing(centers.reshape(1, -1, 3), rays.reshape(1, -1, 3), sdf_field,
-                                                                 iter=0, static_trips=static_trips)
-    gray = rgbs_gt.mean(dim=-1)
-    mask_bg = (gray < 0.95) & (gray > 0.05)                                   # Camera.py:515
-    mask_finish = mask_finish.view(b, r) & mask_bg                            # Camera.py:516
+    if static_trips:
+        # one fused node forms the traced depth AND the two masks of Camera.py:515-516 (uint8, as the loss head takes them):
+        # as torch ops these lines were ~25 launch-bound elementwise kernels of the captured step
+        d_points, sdf_last, _, _ = sdf_field.sphere_tracing(centers.reshape(1, -1, 3), rays.reshape(1, -1, 3), sdf_field, iter=0,
+                                                            static_trips=True, rgbs_gt=rgbs_gt.reshape(-1, 3))
+        mask_bg8, mask_dc8 = sdf_field.last_masks
+        mask_bg, mask_finish = mask_bg8.view(b, r), mask_dc8.view(b, r)
+    else:
+        d_points, sdf_last, _, mask_finish = sdf_field.sphere_tracing(centers.reshape(1, -1, 3), rays.reshape(1, -1, 3), sdf_field,
+                                                                     iter=0)
+        gray = rgbs_gt.mean(dim=-1)
+        mask_bg = (gray < 0.95) & (gray > 0.05)                               # Camera.py:515
+        mask_finish = mask_finish.view(b, r) & mask_bg                        # Camera.py:516
     ret, losses = renderer.forward_with_loss(opt, centers, rays, sdf_field, rad_field, head, rgbs_gt, d_points=d_points.view(b, r),
                                              mask_finish=mask_finish, mask_eik=mask_bg, mask_bg=mask_bg)
+    if static_trips:
+        mask_bg, mask_finish = mask_bg.bool(), mask_finish.bool()
     ret = dict(ret)
     ret.update(tracing_loss=0, mask_bg=mask_bg, mask_finish=mask_finish, d_points=d_points.view(b, r, 1),
                sdf_tracks=sdf_last.view(b, r, 1), rgb_loss=losses["rgb_loss"], DC_loss=losses["DC_loss"],
-               eikonal_loss=losses["eikonal_loss"], mse=losses["mse"], PSNR=psnr(losses["mse"]), loss_all=losses["all"])
+               eikonal_loss=losses["eikonal_loss"], mse=losses["mse"], PSNR=losses["PSNR"] if "PSNR" in losses else psnr(losses["mse"]),
+               loss_all=losses["all"])
     return ret
 
 
