@@ -40,8 +40,13 @@ namespace {
 __global__ void __launch_bounds__(256)
 points_bwd_kernel(FieldC fc, LevelScales lsc, int n_levels, WsLayout w, const Packed* __restrict__ pk, const float* __restrict__ pts,
                   const float* __restrict__ d_sdf, const float* __restrict__ d_feat, const float* __restrict__ d_normal,
-                  float* __restrict__ ws, int want_dx) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                  float* __restrict__ ws, int want_dx, ZeroJob zero) {
+    // leading workgroups: the zero fills the rest of the call needs (as in shade_bwd: no memset nodes in front of the chain)
+    if ((int)blockIdx.x < zero.blocks) {
+        zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, 256);
+        return;
+    }
+    const int64_t i = ((int64_t)blockIdx.x - zero.blocks) * 256 + threadIdx.x;
     if (i >= w.p) return;
     const int64_t P = w.p_pad;
     float p[3], x[3];
@@ -221,20 +226,25 @@ extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_g
     LevelScales lsc;
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L ? grid->scale[l] : 0.f;
 
-    // zero fills: reduced weight-gradient accumulators; the atomically flushed (point-split coarse) levels of the table gradient
-    if (hipMemsetAsync(ws + w.wg, 0, sizeof(float) * (size_t)(w.dbeta - w.wg), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    // zero fills (leading workgroups of points_bwd): reduced weight-gradient accumulators; the atomically flushed (point-split
+    // coarse) levels of the table gradient
+    LS2FM_CHECK_ARG((reinterpret_cast<uintptr_t>(grads->sdf_table) & 15u) == 0);
+    ZeroJob zero{};
+    zero.blocks = 16;
+    zero.a = reinterpret_cast<float4*>(ws + w.wg);
+    zero.na = (w.dbeta - w.wg) / 4;
     {
         int64_t first = 0, count = 0;
         ls2fm_scatter_zero_range(grid, w.p, false, &first, &count);
-        if (count > 0 && hipMemsetAsync(grads->sdf_table + 2 * first, 0, sizeof(float) * 2 * (size_t)count, s) != hipSuccess)
-            return LS2FM_ERR_LAUNCH;
+        if (count > 0) { zero.b = reinterpret_cast<float4*>(grads->sdf_table + 2 * first); zero.nb = count / 2; }
     }
     ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
     int st = ls2fm_launch_points_encode(&f1, grid, params, p, w, ws, s);
     ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
     if (st != LS2FM_OK) return st;
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-    points_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws, d_p != nullptr);
+    points_bwd_kernel<<<(unsigned)((n + 255) / 256 + zero.blocks), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws,
+                                                                                d_p != nullptr, zero);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
     ls2fm_prof_begin(LS2FM_PROF_BIN, s);
     st = ls2fm_launch_post_shade(nullptr, nullptr, n, 1, grid, w.p, ws + w.bins, s);

@@ -523,7 +523,6 @@ class _SdfPoints(torch.autograd.Function):
             return None if t is None else t.reshape(-1, width).float().contiguous()
         d_sdf, d_feat, d_normal = prep(d_sdf, 1), prep(d_feat, _lib.FEAT + 1), prep(d_normal, 3)
         flat, grads = flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
-        grads[7].zero_()                               # beta does not enter a point query
         gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
         pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
         d_p = torch.empty_like(p) if ctx.needs_input_grad[0] else None
@@ -534,6 +533,7 @@ class _SdfPoints(torch.autograd.Function):
         check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
                                        ptr(d_feat), ptr(d_normal), ctypes.byref(gstruct), ptr(d_p), ptr(ws), stream_ptr()),
               "ls2fm_sdf_points_bwd")
+        grads[7] = None                                # beta does not enter a point query: no gradient (not a zero tensor)
         return (None if d_p is None else d_p.view(xyz_shape), None, None, None, *grads)
 
 
@@ -604,7 +604,6 @@ class _TracedDepth(torch.autograd.Function):
         check(lib.ls2fm_trace_depth_bwd(ptr(d_dpred), ptr(d_last), ptr(trips), ptr(gate), n_rays, k_max, ptr(d_sdf), stream_ptr()),
               "ls2fm_trace_depth_bwd")
         flat, grads = flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
-        grads[7].zero_()                               # beta does not enter a point query
         gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
         pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
         n = n_rays * k_max
@@ -614,6 +613,7 @@ class _TracedDepth(torch.autograd.Function):
         ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
         check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
                                        None, None, ctypes.byref(gstruct), None, ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
+        grads[7] = None                                # beta does not enter a point query
         return (None,) * n_in + tuple(grads)
 
 
@@ -621,15 +621,14 @@ def traced_depth(sdf_field, track, trips, near, far, rgbs_gt=None, trace_ws=None
     """track [R, iters_max (+1), 3], trips int32[1] on the device, near / far [R] (what sphere_trace(sync=False) returns) ->
     d_pred [R], sdf_last [R] (graph attached), finish_mask [R] bool, and with rgbs_gt [R,3]: mask_bg, mask_finish & mask_bg as
     uint8 [R] (what the fused loss head takes) -- else None, None"""
-    k_max = max(int(sdf_field.iters_max), 1)
-    pts = track[:, :k_max, :]
+    pts = track                                  # all iters_max + 1 columns (a slice would be copied): K <= iters_max masks the rest
     thr = _finish_threshold(sdf_field)
     ts, _ = param_tensors(sdf_field, None)
     d_pred, last, finish, mask_bg, mask_dc = _TracedDepth.apply(pts, trips, near.reshape(-1), far.reshape(-1), rgbs_gt, thr, sdf_field,
                                                                 trace_ws, *ts)
     if rgbs_gt is None:
-        return d_pred, last, finish.bool(), None, None
-    return d_pred, last, finish.bool(), mask_bg, mask_dc
+        return d_pred, last, finish.view(torch.bool), None, None
+    return d_pred, last, finish.view(torch.bool), mask_bg, mask_dc
 
 
 def _finish_threshold(sdf_field):

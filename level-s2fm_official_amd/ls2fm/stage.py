@@ -46,7 +46,7 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
     ret, losses = renderer.forward_with_loss(opt, centers, rays, sdf_field, rad_field, head, rgbs_gt, d_points=d_points.view(b, r),
                                              mask_finish=mask_finish, mask_eik=mask_bg, mask_bg=mask_bg)
     if static_trips:
-        mask_bg, mask_finish = mask_bg.bool(), mask_finish.bool()
+        mask_bg, mask_finish = mask_bg.view(torch.bool), mask_finish.view(torch.bool)      # 0 / 1 bytes: same storage, no kernel
     ret = dict(ret)
     ret.update(tracing_loss=0, mask_bg=mask_bg, mask_finish=mask_finish, d_points=d_points.view(b, r, 1),
                sdf_tracks=sdf_last.view(b, r, 1), rgb_loss=losses["rgb_loss"], DC_loss=losses["DC_loss"],
