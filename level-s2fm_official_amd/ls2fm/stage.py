@@ -77,10 +77,15 @@ class RenderStage:
         for it in range(500): ret = stage.step(centers, rays, rgbs_gt)
 
     capture=True: the first `step` call records the whole step into a hipGraph at the given batch shape; later calls copy
-    the new rays into the captured input buffers and replay it (shapes must not change; no `.item()` anywhere)."""
+    the new rays into the captured input buffers and replay it (shapes must not change; no `.item()` anywhere).
+
+    extra_loss: a callable `ret -> scalar tensor` evaluated inside the step and ADDED to `loss_all` before the backward -- the
+    terms a driver forms outside the render (BA.run_ba's key-point re-projection error and, through `surface_losses`, its
+    sdf_surf term: BA.py:119-147, 186-202), already weighted.  With capture=True it is recorded with the step: it must read
+    its inputs from tensors that are updated in place and must not synchronise."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
-                 eps=1e-8, extra_params=(), capture=False):
+                 eps=1e-8, extra_params=(), capture=False, extra_loss=None):
         self.opt, self.renderer, self.sdf, self.rad = opt, renderer, sdf_field, rad_field
         dev = next(sdf_field.parameters()).device
         w = weights or {}
@@ -90,6 +95,7 @@ class RenderStage:
         self.gamma = (lr_end / lr) ** (1.0 / max_iter)                        # BA.py:87-88
         self.optim = FusedAdam(self.params, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)
         self.capture = capture
+        self.extra_loss = extra_loss
         self._graph = None
         self._one = torch.ones((), device=dev)
 
@@ -97,6 +103,9 @@ class RenderStage:
         for p in self.params:
             p.grad = None
         ret = render_losses(self.opt, self.renderer, self.sdf, self.rad, self.head, centers, rays, rgbs_gt, static_trips=static_trips)
+        if self.extra_loss is not None:
+            ret["loss_extra"] = self.extra_loss(ret)
+            ret["loss_all"] = ret["loss_all"] + ret["loss_extra"]
         ret["loss_all"].backward(gradient=self._one)
         self.optim.step()
         return ret

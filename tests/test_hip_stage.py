@@ -201,3 +201,50 @@ def _ulp_sensitivity(meta, g, w):
         for k in sens:
             sens[k] = np.maximum(sens[k], np.abs(other[k] - base[k]))
     return sens
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_stage_step_with_point_side_terms(capture):
+    """a BA-shaped step: render terms + the point side (surface_losses on tracked points) as `extra_loss`, against the same step
+    written with torch ops (composed render, torch losses, composed point queries) + torch.optim.Adam"""
+    g = load_golden("caller_dtu_dual")
+    meta, opt, sdf_a, rad_a, ren = _product(g)
+    _, _, sdf_b, rad_b, _ = _product(g)
+    opt.Res = 128
+    w = dict(rgb=3, eikonal_loss=1, DC_Loss=0)
+    gen = torch.Generator().manual_seed(11)
+    xyzs = ((torch.rand(200, 3, generator=gen) * 2 - 1) * 0.7).to(DEV)
+
+    def extra_a(ret):
+        out = stage.surface_losses(opt, sdf_a, xyzs)
+        return 10.0 * out["sdf_surf"] + 3.0 * out["eikonal_loss"]
+    st = stage.RenderStage(opt, ren, sdf_a, rad_a, weights=w, lr=2e-3, lr_end=2e-4, max_iter=10, eps=1e-15, capture=capture,
+                           extra_loss=extra_a)
+    pb = list(sdf_b.parameters()) + list(rad_b.parameters())
+    ob = torch.optim.Adam(pb, lr=2e-3, eps=1e-15)
+    sb = torch.optim.lr_scheduler.ExponentialLR(ob, (2e-4 / 2e-3) ** (1.0 / 10))
+    sdf_b.point_queries = "composed"
+    c, r = torch.from_numpy(g["centers"]).to(DEV), torch.from_numpy(g["rays"]).to(DEV)
+    gt = torch.from_numpy(g["rgbs_gt"]).to(DEV)
+    la, lb = [], []
+    for it in range(5):
+        la.append(float(st.step(c, r, gt)["loss_all"]))
+        ob.zero_grad(set_to_none=True)
+        ret = ren.forward_composed(opt, c, r, sdf_b, rad_b)
+        d_points, _, _, mask_finish = sdf_b.sphere_tracing(c.view(1, -1, 3), r.view(1, -1, 3), sdf_b, impl="torch")
+        depth = ret["depth_mlp"]
+        gray = gt.mean(dim=-1)
+        mask_bg = (gray < 0.95) & (gray > 0.05)
+        mfin = mask_finish.view(*depth.shape) & mask_bg.view(*depth.shape)
+        dc = torch.nn.functional.smooth_l1_loss(d_points.view(*depth.shape)[mfin], depth[mfin]) if mfin.sum() > 0 else depth.sum() * 0
+        nrm = torch.norm(ret["normals"][mask_bg], dim=-1)
+        total = 10 ** w["rgb"] * torch.nn.functional.l1_loss(ret["rgb"], gt) + 10 ** w["eikonal_loss"] * (nrm - 1).abs().mean() \
+            + 10 ** w["DC_Loss"] * dc
+        xs, nl = sdf_b.get_surface_pts(xyzs)
+        total = total + 10.0 * sdf_b.infer_sdf(xs).abs().mean() + 3.0 * (nl - 1).abs().mean()
+        total.backward()
+        ob.step(); sb.step()
+        lb.append(float(total.detach()))
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 3e-3 * abs(y), (la, lb)
+    assert "loss_extra" in st.step(c, r, gt)
