@@ -124,3 +124,71 @@ def test_trace_free_running_vs_oracle_and_reference_goldens(case, manifest, reco
         clear = m & (np.abs(np.abs(ref_s) - thr) > 2e-2 * extent)
         assert np.array_equal(got_f[clear], ref_f[clear]), what
     assert tuple(sampled.shape) == tuple(g["st_sampled_shape"])
+
+
+@pytest.mark.parametrize("dataset,k_override", [("DTU", None), ("ETH3D", None), ("ETH3D", 0), ("BlendedMVS", 3)])
+def test_traced_depth_node_equals_torch_tail(dataset, k_override):
+    """ls2fm.fused.traced_depth (ONE node: track evaluation, masked sum over the first K points, clamp at far, last value, finish
+    mask, the two masks of Camera.py:515-516; K read from the device) against the same tail written with torch ops on the
+    fused point query -- values, masks and every parameter gradient, incl. K = 0 (single current point, SDF.py:201-202), rays
+    whose depth is clamped and an upstream on sdf_last"""
+    from ls2fm import fused
+    from ls2fm.options import make_options
+    from ls2fm.models.SDF import SDF
+    from helpers import named_grads
+    dev = "cuda"
+    enc = dict(n_levels=8, n_features_per_level=2, log2_hashmap_size=14, base_resolution=16)
+    opt = make_options(dataset, device=dev, hash_encoding=enc)
+    torch.manual_seed(3)
+    sdf = SDF(opt).to(dev)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for name, p in sdf.named_parameters():
+            if name.endswith("embedder_obj.params"):
+                p.copy_(((torch.rand(p.shape, generator=gen) * 2 - 1) * 0.05).to(dev))
+            if name.endswith("mlp.0.weight_v"):
+                p[:, 3:] = (torch.randn(p[:, 3:].shape, generator=gen) * 0.03).to(dev)
+    s = float(opt.data.bound_max[0])
+    n = 300
+    o = torch.tensor([0.0, 0.0, -2.5 * s]).repeat(n, 1).to(dev)
+    d = (torch.tensor([0.0, 0.0, 1.0]).repeat(n, 1) + 0.12 * torch.randn(n, 3, generator=gen)).to(dev)
+    gt = torch.rand(n, 3, generator=gen).to(dev)
+    gt[::5] = 0.99
+    with torch.no_grad():
+        near, far, track, _, trips = fused.sphere_trace(sdf, o, d, sync=False)
+    if k_override is not None:
+        trips = torch.full_like(trips, k_override)
+    far = far.clone()
+    far[::7] = -1e4                                                  # forces the clamp on these rays (d > far)
+    cot_d = torch.randn(n, generator=gen).to(dev)
+    cot_l = torch.randn(n, generator=gen).to(dev)
+
+    # (a) the fused node
+    sdf.zero_grad()
+    d_pred, last, finish, mask_bg, mask_dc = fused.traced_depth(sdf, track, trips, near, far, gt)
+    ((d_pred * cot_d).sum() + 0.3 * (last * cot_l).sum()).backward()
+    g_a = named_grads(sdf)
+    # (b) torch ops over the fused point query (what the static tracing path was before the node existed)
+    sdf.zero_grad()
+    k_max = track.shape[1]
+    sdf_tracks = sdf.infer_sdf(track.detach(), mode="ret_sdf")
+    k_eff = trips.clamp(min=1).to(torch.int64)
+    live = (torch.arange(k_max, device=dev)[None, :, None] < k_eff).to(sdf_tracks.dtype)
+    d_ref = (sdf_tracks * live).sum(dim=-2).view(-1) + near
+    d_ref = torch.where(d_ref > far, far, d_ref)
+    last_ref = sdf_tracks.gather(1, (k_eff - 1).view(1, 1, 1).expand(n, 1, 1))[:, 0, 0]
+    ((d_ref * cot_d).sum() + 0.3 * (last_ref * cot_l).sum()).backward()
+    g_b = named_grads(sdf)
+    extent = sdf.bound_max.reshape(-1)[0] - sdf.bound_min.reshape(-1)[0]
+    fin_ref = last_ref.detach().abs() < extent / 10 / opt.Res
+    gray = gt.mean(dim=-1)
+    bg_ref = (gray < 0.95) & (gray > 0.05)
+    assert rel_err(d_pred.cpu(), d_ref.detach().cpu()) < 2e-6 and rel_err(last.cpu(), last_ref.detach().cpu()) < 1e-6
+    assert torch.equal(finish.cpu(), fin_ref.cpu())
+    assert torch.equal(mask_bg.bool().cpu(), bg_ref.cpu()) and torch.equal(mask_dc.bool().cpu(), (fin_ref & bg_ref).cpu())
+    assert torch.equal((d_pred == far).cpu(), (d_ref.detach() == far).cpu()) and bool((d_pred == far).any())     # some rays are clamped
+    for k in g_b:
+        if k == "beta":
+            assert float(g_a[k].abs().max()) == 0.0
+            continue
+        assert rel_err(g_a[k], g_b[k]) < 2e-5, k
