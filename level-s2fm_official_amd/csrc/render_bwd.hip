@@ -39,13 +39,24 @@ wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_
         if (threadIdx.x == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    __shared__ int s_starved;
     if (threadIdx.x == 0) {
         int spins = 0;
         while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_red && ++spins < (1 << 24))
             __builtin_amdgcn_s_sleep(16);
+        s_starved = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_red;
     }
     __syncthreads();
-    finalize_task(fa, bid - n_red);                              // reads the reduced block with L2-bypassing loads (wg_load)
+    const int task = bid - n_red;
+    finalize_task(fa, task);                                     // reads the reduced block with L2-bypassing loads (wg_load)
+    // The wait is bounded (HIP promises no dispatch order inside a launch): if the reducers were starved past the bound, this
+    // task consumed incomplete sums -- poison its outputs so that the step fails loudly (NaN loss / gradient) instead of quietly
+    if (s_starved && threadIdx.x == 0 && (task < 2 || task >= 4 || fa.dual)) {
+        const float nan = __builtin_nanf("");
+        float* b = task < 2 ? fa.G.sdf_mlp[task].bias : (task < 4 ? fa.G.geo_mlp[task - 2].bias : fa.G.rad_mlp[task - 4].bias);
+        b[0] = nan;
+        if (task == 4) fa.G.beta[0] = nan;
+    }
 }
 
 }  // namespace

@@ -35,7 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             by_step = {}
             for p in group["params"]:
                 if p.grad is None:
@@ -53,7 +53,6 @@ class FusedAdam(torch.optim.Optimizer):
             if self.scheduled_gamma is not None:
                 if len(by_step) > 1:
                     raise RuntimeError("ls2fm.optim.FusedAdam(scheduled_gamma=...): the parameters of a group must step together")
-                gi = self.param_groups.index(group)
                 if gi not in self._sched:
                     first = next(iter(by_step)) - 1 if by_step else 0
                     dev = group["params"][0].device
@@ -95,5 +94,14 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 if p in self.state and self.state[p]:
                     self.state[p]["step"] = int(self.state[p]["step"]) + n
+                    # the captured kernel rewrote the parameter through its raw pointer: tell autograd and every cache
+                    # keyed on Tensor._version (the interleaved table copy) -- as step() does
+                    torch.autograd.graph.increment_version(p)
             if self.scheduled_gamma is not None:
                 group["lr"] = float(group["lr"]) * self.scheduled_gamma ** n
+
+    def load_state_dict(self, state_dict):
+        """the device-resident step count / learning rate (scheduled form) are derived state: dropped here and rebuilt from the
+        loaded `step` and `lr` by the next step() -- an optimizer that had already stepped would otherwise keep its old schedule"""
+        super().load_state_dict(state_dict)
+        self._sched = {}

@@ -168,5 +168,8 @@ class RenderStage:
             for gi, t in opt._sched.items():
                 if gi in snap["sched"]:
                     t.copy_(snap["sched"][gi])
-                else:
-                    t.copy_(torch.tensor([0.0, snap["lrs"][gi], opt.scheduled_gamma, 0.0], dtype=torch.float64))
+                else:                       # schedule created by the warm-up: seeded from the step the group had BEFORE it
+                    steps = [int(old["step"]) for p, old in zip(self.params, snap["state"])
+                             if old and any(p is q for q in opt.param_groups[gi]["params"])]
+                    t.copy_(torch.tensor([float(steps[0]) if steps else 0.0, snap["lrs"][gi], opt.scheduled_gamma, 0.0],
+                                         dtype=torch.float64))
