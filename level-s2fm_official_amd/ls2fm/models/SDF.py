@@ -152,26 +152,44 @@ class SDF(nn.Module):
             track = [p_s]
         return torch.stack(track, dim=1), t_end[-1], trips
 
-    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None):
+    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None, want_samples=False):
         """sphere_tracing without the host round trip for the trip count K (hipGraph-capturable, ls2fm.stage): the kernel leaves K
         on the device and runs every ray for iters_max trips anyway; the differentiable depth sums the first K track points
         through a device-side mask (K = 0: the single current point, SDF.py:201-202) -- one fused node, ls2fm.fused.traced_depth.
-        Same d_pred / sdf_last / finish_mask as the synchronising form; the RNG-dependent `sampled_pts` (its SHAPE depends on K)
-        is not produced (None).  rgbs_gt [.., 3]: the node also forms CameraSet.render's mask_bg and mask_finish & mask_bg
+        Same d_pred / sdf_last / finish_mask as the synchronising form.  The RNG-dependent `sampled_pts` (SDF.py:216-224) has
+        a K-dependent SHAPE in the reference; with want_samples it comes back at its largest shape, [1, min(4096, R) * iters_max
+        + R, 3] -- the track points of up to 4096 random rays, then one random point per ray between near and 1.5 x the far-end
+        distance -- with `self.last_sample_mask` ([same] bool, device) marking the rows the reference would have returned (the
+        first K columns of every picked track); the draws come from the device generator, so the call stays capturable.
+        Otherwise None.  rgbs_gt [.., 3]: the node also forms CameraSet.render's mask_bg and mask_finish & mask_bg
         (Camera.py:515-516) -> self.last_masks."""
         if not fused.available(self, o):
             raise RuntimeError("ls2fm: static_trips needs the fused tracing kernel (GPU tensors, reference layer sizes)")
         with torch.no_grad():
-            near, far, track, _, trips = fused.sphere_trace(self, o.detach(), d.detach(), sync=False)
+            near, far, track, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach(), sync=False)
         d_pred, last, finish, mask_bg, mask_dc = fused.traced_depth(self, track, trips, near, far, rgbs_gt,
                                                                     trace_ws=getattr(track, "_ls2fm_trace_ws", None))
         self.last_trips = trips
         self.last_masks = (mask_bg, mask_dc)             # uint8 [R] each (rgbs_gt given): what the fused loss head takes
-        return d_pred.view(*shape2), last, None, finish.view(-1, 1)
+        sampled = None
+        self.last_sample_mask = None
+        if want_samples:
+            with torch.no_grad():
+                n_rays, it = o.shape[0], int(self.iters_max)
+                k = trips.long().reshape(1)
+                u = torch.rand(n_rays, device=o.device)
+                t_up = torch.minimum(1.5 * t_end.gather(1, k.expand(n_rays, 1))[:, 0], far)          # far end after K trips
+                along = o + ((1 - u) * t_up + u * near)[:, None] * d
+                pick = torch.randperm(n_rays, device=o.device)[:4096]
+                cols = torch.arange(it, device=o.device)[None, :] < k.clamp_min(1)                    # K = 0: the current point
+                sampled = torch.cat([track[pick, :it].reshape(1, -1, 3), along.view(1, -1, 3)], dim=1)
+                self.last_sample_mask = torch.cat([cols.expand(pick.shape[0], it).reshape(-1),
+                                                   torch.ones(n_rays, dtype=torch.bool, device=o.device)])
+        return d_pred.view(*shape2), last, sampled, finish.view(-1, 1)
 
     def sphere_tracing(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129),
                        n_secant_steps=8, depth_range=(0.0, 2.4), max_points=3500000, rad=1.0, iter=0,
-                       impl="fused", static_trips=False, rgbs_gt=None):
+                       impl="fused", static_trips=False, rgbs_gt=None, want_samples=False):
         """ray0, ray_direction [B,R,3] -> (d_pred [B,R], sdf_last [B*R], sampled_pts [1, <=4096+B*R, 3],
         finish_mask [B*R,1]).  `d_pred = near + sum_k sdf(track_k)` is differentiable w.r.t. the SDF
         parameters; the root-find itself runs without a graph.  Unused reference arguments are accepted."""
@@ -179,7 +197,7 @@ class SDF(nn.Module):
         o = ray0.reshape(-1, 3)
         d = ray_direction.reshape(-1, 3)
         if static_trips:
-            return self._sphere_tracing_static(o, d, shape2, rgbs_gt)
+            return self._sphere_tracing_static(o, d, shape2, rgbs_gt, want_samples=want_samples)
         with torch.no_grad():
             if impl == "fused" and fused.available(self, o):
                 near, far, pts_tracks, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach())

@@ -17,18 +17,23 @@ graph launch with no host synchronisation (the reference syncs at `mask_finish.s
 """
 from __future__ import annotations
 
+import random
+
 import torch
 
 from .losses import RenderLossHead, psnr
 from .optim import FusedAdam
+from .utils import camera as _cam
 
 
-def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs_gt, static_trips=False):
+def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs_gt, static_trips=False, eikonal_over="bg"):
     """CameraSet.render(mode="train") after the ray pick + the render-side terms of compute_loss: -> the reference's `ret`
     keys (rgb, sdfs_volume, normals, depth_mlp, normal_mlp, mask_bg, rgb_loss, DC_loss, PSNR, tracing_loss) plus
     eikonal_loss (over mask_bg, BA.py:193-194), mse and `loss_all` (the head's 10^w weighted sum).
     centers, rays [B,R,3]; rgbs_gt [B,R,3].  The tracing runs first (it is independent of the render): its masks and depth
-    are then inputs of the loss head that runs INSIDE the fused render (Renderer.forward_with_loss)."""
+    are then inputs of the loss head that runs INSIDE the fused render (Renderer.forward_with_loss).
+    eikonal_over: "bg" = over the rays of mask_bg (BA.py:193-194, Initialization.py:257-258), "all" = over every normal
+    (rendering_refine.py:101-102)."""
     b, r = centers.shape[:2]
     if static_trips:
         # one fused node forms the traced depth AND the two masks of Camera.py:515-516 (uint8, as the loss head takes them):
@@ -44,7 +49,8 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
         mask_bg = (gray < 0.95) & (gray > 0.05)                               # Camera.py:515
         mask_finish = mask_finish.view(b, r) & mask_bg                        # Camera.py:516
     ret, losses = renderer.forward_with_loss(opt, centers, rays, sdf_field, rad_field, head, rgbs_gt, d_points=d_points.view(b, r),
-                                             mask_finish=mask_finish, mask_eik=mask_bg, mask_bg=mask_bg)
+                                             mask_finish=mask_finish, mask_eik=mask_bg if eikonal_over == "bg" else None,
+                                             mask_bg=mask_bg)
     if static_trips:
         mask_bg, mask_finish = mask_bg.view(torch.bool), mask_finish.view(torch.bool)      # 0 / 1 bytes: same storage, no kernel
     ret = dict(ret)
@@ -85,28 +91,51 @@ class RenderStage:
     its inputs from tensors that are updated in place and must not synchronise."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
-                 eps=1e-8, extra_params=(), capture=False, extra_loss=None):
+                 eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None):
+        """lr / lr_color: the reference's two field groups (`[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(),
+        lr_color}]`, BA.py:79-83; lr_color=None: one rate); extra_params: tensors (one more group at `lr`) or
+        `{"params": [...], "lr": x}` dicts (the pose groups of BA.py:60-75).  ONE ExponentialLR factor for all groups,
+        (lr_end / lr) ** (1 / max_iter), as the reference's scheduler (BA.py:87-88).
+        reducer: an `ls2fm.dist.GradAllReducer` over the same parameters, called between backward and the update -- required
+        when a process group is up (the fused loss head then divides by GLOBAL counts: without the reduction every rank would
+        apply 1/world of its local gradient and the replicas would drift apart)."""
         self.opt, self.renderer, self.sdf, self.rad = opt, renderer, sdf_field, rad_field
         dev = next(sdf_field.parameters()).device
         w = weights or {}
         get = (lambda k: w.get(k)) if isinstance(w, dict) else (lambda k: getattr(w, k, None))
         self.head = RenderLossHead(dev, w_rgb=get("rgb"), w_eikonal=get("eikonal_loss"), w_dc=get("DC_Loss"))
-        self.params = [p for p in list(sdf_field.parameters()) + list(rad_field.parameters()) + list(extra_params) if p.requires_grad]
+        groups = [dict(params=[p for p in sdf_field.parameters() if p.requires_grad], lr=lr),
+                  dict(params=[p for p in rad_field.parameters() if p.requires_grad], lr=lr if lr_color is None else lr_color)]
+        loose = [p for p in extra_params if not isinstance(p, dict)]
+        if loose:
+            groups.append(dict(params=[p for p in loose if p.requires_grad], lr=lr))
+        groups += [dict(g) for g in extra_params if isinstance(g, dict)]
+        groups = [g for g in groups if g["params"]]
+        self.params = [p for g in groups for p in g["params"]]
         self.gamma = (lr_end / lr) ** (1.0 / max_iter)                        # BA.py:87-88
-        self.optim = FusedAdam(self.params, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)
+        self.optim = FusedAdam(groups, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)
         self.capture = capture
         self.extra_loss = extra_loss
+        self.eikonal_over = eikonal_over
+        self.reducer = reducer
         self._graph = None
         self._one = torch.ones((), device=dev)
 
     def _eager(self, centers, rays, rgbs_gt, static_trips):
+        from . import dist as _dist
+        if _dist.is_distributed() and self.reducer is None:
+            raise RuntimeError("ls2fm.stage.RenderStage under torch.distributed needs reducer=GradAllReducer(stage.params): the loss "
+                               "head normalises by global counts, the gradients must be summed over the ranks before the update")
         for p in self.params:
             p.grad = None
-        ret = render_losses(self.opt, self.renderer, self.sdf, self.rad, self.head, centers, rays, rgbs_gt, static_trips=static_trips)
+        ret = render_losses(self.opt, self.renderer, self.sdf, self.rad, self.head, centers, rays, rgbs_gt, static_trips=static_trips,
+                            eikonal_over=self.eikonal_over)
         if self.extra_loss is not None:
             ret["loss_extra"] = self.extra_loss(ret)
             ret["loss_all"] = ret["loss_all"] + ret["loss_extra"]
         ret["loss_all"].backward(gradient=self._one)
+        if self.reducer is not None:
+            self.reducer.all_reduce()
         self.optim.step()
         return ret
 
@@ -118,6 +147,10 @@ class RenderStage:
             static = _fused.available(self.sdf, centers)
             return self._eager(centers, rays, rgbs_gt, static_trips=static)
         if self._graph is None:
+            from . import dist as _dist
+            if _dist.is_distributed():
+                raise NotImplementedError("ls2fm.stage.RenderStage(capture=True) under torch.distributed: the step's collectives "
+                                          "(loss counts, trip count, gradient exchange) are not replayed from a hipGraph; use capture=False")
             from .graph import CapturedStep
             self._in = (centers.detach().clone(), rays.detach().clone(), rgbs_gt.detach().clone())
             # the capture warms the step up by running it for real: parameters, Adam state and the schedule are put back
@@ -173,3 +206,207 @@ class RenderStage:
                              if old and any(p is q for q in opt.param_groups[gi]["params"])]
                     t.copy_(torch.tensor([float(steps[0]) if steps else 0.0, snap["lrs"][gi], opt.scheduled_gamma, 0.0],
                                          dtype=torch.float64))
+
+
+# ================================================================================================ the stage LOOPS
+# `Refine.run` (pipelines/rendering_refine.py:72-97) and `BA.run_ba` (pipelines/BA.py:110-188) as loops over `RenderStage`:
+# every iteration is the reference's -- ray pick, multi-view tracing consistency of one random camera's key points, render +
+# tracing + masks + losses, (BA: the point side and the re-projection through the pose parameters), one backward, one Adam
+# update over every parameter group, one ExponentialLR step -- with nothing read back to the host inside an iteration: the
+# reference's `.item()` (the adaptive re-projection weight, BA.py:164), `mask_surf.sum() == 0` and `mask_finish.sum() > 0`
+# branches are device-side selects here, the logs come back as device tensors.  Scene containers are plain tensors: the
+# reference's Camera / Point3D bookkeeping (COLMAP ids, feature tracks) stays with the caller.
+class TrackedViews:
+    """What the loops need of a CameraSet + Point3DSet: world-to-camera poses [V,3,4] (or se(3) parameters [V,6]), one
+    intrinsic matrix [3,3], the images as [V, H*W, 3], per view its key points [n_v, 2] (pixels) and the index of the tracked 3-D
+    point each of them observes [n_v] (Camera.idx2d_to_3d entries != -1), the points [M,3]."""
+
+    def __init__(self, poses, intrinsic, images, keypoints, track_ids, xyzs, H, W):
+        self.poses, self.intrinsic, self.images = poses, intrinsic, images
+        self.keypoints, self.track_ids, self.xyzs = list(keypoints), [t.long() for t in track_ids], xyzs
+        self.H, self.W = int(H), int(W)
+        self.grid = _cam.mesh_grid(H=H, W=W, device=images.device)
+        n_max = max(k.shape[0] for k in self.keypoints)
+        dev = images.device
+        # key points padded to one shape (a captured step has fixed shapes): padding repeats the view's first key point -- a
+        # duplicate ray finishes its sphere tracing exactly when the original does, so the global trip count is unchanged
+        self.kp_pad = torch.stack([torch.cat([k, k[:1].expand(n_max - k.shape[0], 2)]) for k in self.keypoints]).to(dev)
+        self.id_pad = torch.stack([torch.cat([t, t[:1].expand(n_max - t.shape[0])]) for t in self.track_ids]).to(dev)
+        self.kp_live = torch.stack([torch.arange(n_max, device=dev) < k.shape[0] for k in self.keypoints]).float()
+
+
+def keypoint_rays(pose, intrinsic, kypts):
+    """centers / rays of a view's key points as `Camera.get_pts3D` forms them (pipelines/Camera.py:129-133): pose [3,4],
+    kypts [n,2] -> [1,n,3] each"""
+    in_cam = _cam.img2cam(_cam.to_hom(kypts), intrinsic.unsqueeze(0))            # [1,n,3]
+    center = _cam.cam2world(torch.zeros_like(in_cam), pose.unsqueeze(0))
+    return center, _cam.cam2world(in_cam, pose.unsqueeze(0)) - center
+
+
+class TracingConsistency:
+    """The multi-view tracing-consistency block of `CameraSet.render` (pipelines/Camera.py:466-476) as a step's extra loss:
+    the key points of ONE view are sphere-traced onto the surface; tracing_loss = mean ||xyz - surface point||, and the SDF at
+    the end of the tracks becomes `ret.sdfs` (sdf_surf = mean |sdfs|).  The view's rays live in buffers that `select()` rewrites
+    in place, so a captured step sees the new view at replay."""
+
+    def __init__(self, sdf_field, views, w_tracing, w_surf, static_trips=True):
+        self.sdf, self.views, self.static = sdf_field, views, static_trips
+        self.w_tracing = 0.0 if w_tracing is None else 10.0 ** float(w_tracing)
+        self.w_surf = 0.0 if w_surf is None else 10.0 ** float(w_surf)
+        n = views.kp_pad.shape[1]
+        dev = views.kp_pad.device
+        self.center, self.ray = torch.zeros(1, n, 3, device=dev), torch.zeros(1, n, 3, device=dev)
+        self.target, self.live = torch.zeros(n, 3, device=dev), torch.zeros(n, device=dev)
+        self.use_sdfs = True                   # False: `ret.sdfs` was set by the caller before the render (BA.py:122, Camera.py:474)
+
+    @torch.no_grad()
+    def select(self, view, poses):
+        c, r = keypoint_rays(poses[view], self.views.intrinsic, self.views.kp_pad[view])
+        self.center.copy_(c); self.ray.copy_(r)
+        self.target.copy_(self.views.xyzs[self.views.id_pad[view]])
+        self.live.copy_(self.views.kp_live[view])
+
+    def __call__(self, ret):
+        d, sdf_last, _, _ = self.sdf.sphere_tracing(self.center, self.ray, self.sdf, static_trips=self.static)
+        surface = self.center[0] + self.ray[0] * d.reshape(-1, 1)
+        count = self.live.sum()
+        ret["tracing_loss"] = ((self.target - surface).norm(dim=-1) * self.live).sum() / count
+        loss = self.w_tracing * ret["tracing_loss"]
+        if self.use_sdfs:
+            ret["sdf_surf"] = (sdf_last.reshape(-1).abs() * self.live).sum() / count
+            loss = loss + self.w_surf * ret["sdf_surf"]
+        return loss
+
+
+def _pick_rays(views, poses, rays_idx):
+    """CameraSet.render's ray pick for given poses (Camera.py:457-463): the same pixels in every view"""
+    centers, rays = _cam.get_center_and_ray(None, poses, intr=views.intrinsic.unsqueeze(0), rays_idx=rays_idx, xy_grid=views.grid)
+    return centers, rays, views.images[:, rays_idx, :]
+
+
+class RefineLoop:
+    """`Refine` (pipelines/rendering_refine.py:15-126): fields only, fixed poses, eikonal over every normal, tracing consistency
+    and sdf_surf on one random view's key points.
+
+        loop = RefineLoop(opt, renderer, sdf, rad, views, weights=opt.loss_weight.refine, lr_sdf=1e-3, lr_sdf_end=5e-4,
+                          lr_color=1e-3, max_iter=500, rand_rays=8192)
+        logs = loop.run()                      # {"all": [max_iter], "PSNR": ..., ...} device tensors
+
+    picks: optional per-iteration (rays_idx, view) pairs (parity tests replay the reference's draws); default: a device-side
+    `torch.randperm(H * W)` head and a host-side random view per iteration (no device synchronisation either way)."""
+
+    def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, max_iter, rand_rays,
+                 capture=False, static_trips=None):
+        get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
+        self.views, self.max_iter, self.rand_rays = views, int(max_iter), int(rand_rays)
+        from . import fused as _fused
+        static = _fused.available(sdf_field, views.images) if static_trips is None else static_trips
+        self.extra = TracingConsistency(sdf_field, views, get("tracing_loss"), get("sdf_surf"), static_trips=static)
+        self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
+                                 lr_color=lr_color, capture=capture, extra_loss=self.extra, eikonal_over="all")
+        self.poses = views.poses if views.poses.shape[-1] == 4 else _cam.lie.se3_to_SE3(views.poses)
+        self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss")
+
+    def step(self, rays_idx=None, view=None):
+        V = self.poses.shape[0]
+        if rays_idx is None:
+            rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // V]
+        view = random.randint(0, V - 1) if view is None else int(view)
+        self.extra.select(view, self.poses)
+        centers, rays, rgbs_gt = _pick_rays(self.views, self.poses, rays_idx)
+        return self.stage.step(centers, rays, rgbs_gt)
+
+    def run(self, n_iters=None, picks=None):
+        logs = {k: [] for k in self._keys}
+        for it in range(self.max_iter if n_iters is None else int(n_iters)):
+            ret = self.step(*(picks[it] if picks is not None else (None, None)))
+            for k in self._keys:
+                logs[k].append(ret[k].detach().reshape(()).clone())
+        return {("all" if k == "loss_all" else k): torch.stack(v) for k, v in logs.items()}
+
+
+class BALoop:
+    """`BA` in mode "sfm_refine" with several cameras (pipelines/BA.py:24-218; optim_split: rotation / translation parameters
+    with their own rates, BA.py:66-75): per iteration the POINT side -- tracked points projected onto the surface
+    (get_surface_pts), re-evaluated (infer_sdf), re-projected through the live poses against their key points (robust mean over
+    |sdf| < 2 thr), the adaptive weight 10^1 when the error exceeds 10 px (BA.py:163-166) -- then the render side with the
+    poses detached (BA.py:150-151), eikonal over mask_bg, sdf_surf over the points, tracing consistency; one backward; Adam over
+    {rotations, translations, SDF field, radiance field}; ExponentialLR; the points are replaced by their projections
+    (BA.py:181)."""
+
+    def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, lr_pose_r, lr_pose_t,
+                 max_iter, rand_rays, capture=False, static_trips=None):
+        get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
+        self.opt, self.sdf, self.views = opt, sdf_field, views
+        self.max_iter, self.rand_rays = int(max_iter), int(rand_rays)
+        se3 = views.poses if views.poses.shape[-1] == 6 else _cam.lie.SE3_to_se3(views.poses)
+        self.rot = torch.nn.Parameter(se3[:, :3].detach().clone())
+        self.trans = torch.nn.Parameter(se3[:, 3:].detach().clone())
+        # the observation list of util.get_idx3d_camset (utils/util.py:450-464): per view, every key point with a 3-D point
+        self.obs_view = torch.cat([torch.full((t.shape[0],), v, dtype=torch.long) for v, t in enumerate(views.track_ids)]).to(se3.device)
+        self.obs_point = torch.cat(views.track_ids).to(se3.device)
+        self.obs_uv = torch.cat(views.keypoints).to(se3.device)
+        # the loop's OWN copy of the points (BA.py:77): it is what gets projected and replaced every iteration, while the
+        # tracing consistency keeps comparing against the point set's coordinates, which do not move during the loop (and not
+        # after it either: Point3DSet.update_xyzs never runs its lazy map, SURVEY C-13)
+        self.xyzs_all = views.xyzs.detach().clone()
+        self.w_surf = 0.0 if get("sdf_surf") is None else 10.0 ** float(get("sdf_surf"))
+        self.w_reproj_lo = 0.0 if get("reproj_error") is None else 10.0 ** float(get("reproj_error"))
+        self.sdf_threshold = float((float(opt.data.bound_max[0]) - float(opt.data.bound_min[0])) / 10 / int(opt.Res))
+        from . import fused as _fused
+        static = _fused.available(sdf_field, views.images) if static_trips is None else static_trips
+        self.tracing = TracingConsistency(sdf_field, views, get("tracing_loss"), None, static_trips=static)
+        self.tracing.use_sdfs = False
+        self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
+                                 lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="bg",
+                                 extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)])
+        self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")
+        self._render_poses = torch.zeros(se3.shape[0], 3, 4, device=se3.device)
+        # the key-point rays of the tracing consistency come from the CAMERAS' own poses (Camera.get_pts3D -> get_pose,
+        # Camera.py:131), which the loop only writes back after its last iteration (BA.py:184-185): fixed during the loop
+        self._camera_poses = _cam.lie.se3_to_SE3(se3).detach()
+
+    def _extra(self, ret):
+        """the terms BA.run_ba forms outside the render (BA.py:119-147) + the tracing consistency, already weighted"""
+        xyzs_new, _ = self.sdf.get_surface_pts(self.xyzs_all[self.obs_point])
+        sdfs = self.sdf.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1)
+        se3 = torch.cat([self.rot, self.trans], dim=1)
+        poses = _cam.lie.se3_to_SE3(se3[self.obs_view])                                          # one pose per observation
+        in_cam = _cam.world2cam(xyzs_new.unsqueeze(1), poses)
+        uv = _cam.cam2img(in_cam, self.views.intrinsic.expand(in_cam.shape[0], 3, 3))
+        uv = (uv / (uv[..., 2:] + 1e-6))[..., :2].squeeze(1)
+        on_surface = (sdfs.abs() < 2 * self.sdf_threshold).squeeze(-1) & ~torch.isinf(uv).any(dim=-1)
+        err = torch.where(on_surface, (uv - self.obs_uv).norm(dim=-1), torch.zeros((), device=uv.device))
+        n = on_surface.sum()
+        robust = torch.where(on_surface, 2 * torch.log(1 + err ** 2 / 4), torch.zeros((), device=uv.device))
+        reproj = torch.where(n > 0, 0.5 * robust.sum() / n.clamp_min(1) + 0.5 * err.sum() / n.clamp_min(1), torch.zeros((), device=uv.device))
+        w_reproj = torch.where(reproj.detach() > 10, 10.0, 1.0) * (1.0 if self.w_reproj_lo else 0.0)       # BA.py:163-166
+        ret["reproj_error"], ret["w_reproj"] = reproj, w_reproj
+        ret["sdf_surf"] = sdfs.abs().mean()
+        self._new_points = xyzs_new.detach()
+        return w_reproj * reproj + self.w_surf * ret["sdf_surf"] + self.tracing(ret)
+
+    def step(self, rays_idx=None, view=None):
+        V = self.rot.shape[0]
+        if rays_idx is None:
+            rays_idx = torch.randperm(self.views.H * self.views.W, device=self.rot.device)[: self.rand_rays // V]
+        view = random.randint(0, V - 1) if view is None else int(view)
+        with torch.no_grad():
+            self._render_poses.copy_(_cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1)))      # detached (BA.py:150-151)
+        self.tracing.select(view, self._camera_poses)
+        centers, rays, rgbs_gt = _pick_rays(self.views, self._render_poses, rays_idx)
+        ret = self.stage.step(centers, rays, rgbs_gt)
+        with torch.no_grad():
+            self.xyzs_all[self.obs_point] = self._new_points                                     # BA.py:181
+        return ret
+
+    def run(self, n_iters=None, picks=None):
+        logs = {k: [] for k in self._keys}
+        for it in range(self.max_iter if n_iters is None else int(n_iters)):
+            ret = self.step(*(picks[it] if picks is not None else (None, None)))
+            for k in self._keys:
+                logs[k].append(ret[k].detach().reshape(()).clone())
+        return {("all" if k == "loss_all" else k): torch.stack(v) for k, v in logs.items()}
+
+    def poses_se3(self):
+        return torch.cat([self.rot, self.trans], dim=1).detach()

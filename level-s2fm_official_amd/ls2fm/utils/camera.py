@@ -1,4 +1,22 @@
-"""The one helper of the reference's utils/camera.py that sits on the path (camera.py:262-266)."""
+"""Camera-side arithmetic the stage loops need around the path (the reference's utils/camera.py).
+
+`get_3D_points_from_depth` (camera.py:262-266) sits on the render path itself.  The rest -- pinhole projection, the pose
+algebra and the ray pick of `get_center_and_ray` (camera.py:230-252) -- is what `ls2fm.stage`'s loop drivers use to turn poses,
+intrinsics and a ray permutation into the `[B,R,3]` centers / rays the fused render takes, and what a bundle-adjustment step
+differentiates through for its re-projection term (BA.py:124-131).  Plain torch on whatever device the inputs live on (GPU in
+the loops: nothing here synchronises, so a step containing it can be captured).  Same function names and argument meaning as
+the reference's module so that a caller can switch imports; written from the textbook formulas:
+
+    world -> camera   x_c = R x_w + t                      pose = [R | t]  (3 x 4, world-to-camera)
+    camera -> image   u   = K x_c                          (homogeneous; divide by u_z for pixels)
+    se(3) -> SE(3)    R = I + A W + B W^2,  t = (I + B W + C W^2) u,   W = [w]_x,  theta = |w|,
+                      A = sin(theta) / theta,  B = (1 - cos theta) / theta^2,  C = (theta - sin theta) / theta^3
+"""
+from __future__ import annotations
+
+import math
+
+import torch
 
 
 def get_3D_points_from_depth(opt, center, ray, depth, multi_samples=False):
@@ -6,3 +24,130 @@ def get_3D_points_from_depth(opt, center, ray, depth, multi_samples=False):
     if multi_samples:
         center, ray = center[:, :, None], ray[:, :, None]
     return center + ray * depth
+
+
+# ------------------------------------------------------------------------------------------------ projective helpers
+def to_hom(X):
+    """[...,k] -> [...,k+1] with a trailing 1"""
+    return torch.cat([X, torch.ones_like(X[..., :1])], dim=-1)
+
+
+def invert_pose(pose):
+    """[...,3,4] world-to-camera -> camera-to-world: [R^T | -R^T t]"""
+    R, t = pose[..., :3], pose[..., 3:]
+    Rt = R.transpose(-1, -2)
+    return torch.cat([Rt, -Rt @ t], dim=-1)
+
+
+def world2cam(X, pose):
+    """X [B,N,3] world points, pose [B,3,4] -> camera coordinates [B,N,3]"""
+    return to_hom(X) @ pose.transpose(-1, -2)
+
+
+def cam2world(X, pose):
+    return to_hom(X) @ invert_pose(pose).transpose(-1, -2)
+
+
+def cam2img(X, cam_intr):
+    return X @ cam_intr.transpose(-1, -2)
+
+
+def img2cam(X, cam_intr):
+    return X @ torch.linalg.inv(cam_intr).transpose(-1, -2)
+
+
+def mesh_grid(opt=None, H=None, W=None, device=None):
+    """pixel centres [H*W, 2] as (x + 0.5, y + 0.5), row-major (camera.py:253-261)"""
+    H = int(opt.H) if H is None else int(H)
+    W = int(opt.W) if W is None else int(W)
+    device = (opt.device if opt is not None else "cpu") if device is None else device
+    ys = torch.arange(H, dtype=torch.float32, device=device) + 0.5
+    xs = torch.arange(W, dtype=torch.float32, device=device) + 0.5
+    Y, X = torch.meshgrid(ys, xs, indexing="ij")
+    return torch.stack([X, Y], dim=-1).view(-1, 2)
+
+
+def get_center_and_ray(opt, pose, intr=None, rays_idx=None, xy_grid=None):
+    """pose [B,3,4], intr [1|B,3,3] -> camera centers and (unnormalised) ray directions of the picked pixels, [B,R,3] each
+    (camera.py:230-252: the SAME pixels `rays_idx` for every view)"""
+    with torch.no_grad():
+        grid = mesh_grid(opt, device=pose.device) if xy_grid is None else xy_grid
+        if rays_idx is not None:
+            grid = grid[rays_idx, :]
+    B = pose.shape[0]
+    grid = grid.unsqueeze(0).expand(B, -1, -1)
+    in_cam = img2cam(to_hom(grid), intr)                 # points on the z = 1 plane of each camera
+    origin = torch.zeros_like(in_cam)
+    center = cam2world(origin, pose)
+    return center, cam2world(in_cam, pose) - center
+
+
+# ------------------------------------------------------------------------------------------------ se(3)
+def _series(theta, first_denominator, step):
+    """sum_i (-1)^i theta^(2i) / d_i with d_0 = first_denominator and d_{i+1} = d_i step(i + 1) -- the Taylor series of A, B, C
+    (11 terms: exact to fp32 for |theta| < pi, and smooth through theta = 0 where the closed forms are 0 / 0)"""
+    total = torch.zeros_like(theta)
+    denom = float(first_denominator)
+    for i in range(11):
+        if i > 0:
+            denom *= step(i)
+        total = total + ((-1.0) ** i) * theta ** (2 * i) / denom
+    return total
+
+
+def _abc(theta):
+    A = _series(theta, 1.0, lambda i: (2 * i) * (2 * i + 1))             # sin x / x
+    B = _series(theta, 2.0, lambda i: (2 * i + 1) * (2 * i + 2))         # (1 - cos x) / x^2
+    C = _series(theta, 6.0, lambda i: (2 * i + 2) * (2 * i + 3))         # (x - sin x) / x^3
+    return A, B, C
+
+
+def skew(w):
+    w0, w1, w2 = w.unbind(dim=-1)
+    zero = torch.zeros_like(w0)
+    return torch.stack([torch.stack([zero, -w2, w1], dim=-1), torch.stack([w2, zero, -w0], dim=-1),
+                        torch.stack([-w1, w0, zero], dim=-1)], dim=-2)
+
+
+class Lie:
+    """SO(3) / SE(3) exponential and logarithm maps (camera.py:63-147)"""
+
+    skew_symmetric = staticmethod(skew)
+
+    @staticmethod
+    def so3_to_SO3(w):
+        W = skew(w)
+        A, B, _ = _abc(w.norm(dim=-1)[..., None, None])
+        return torch.eye(3, device=w.device, dtype=w.dtype) + A * W + B * (W @ W)
+
+    @staticmethod
+    def se3_to_SE3(wu):
+        w, u = wu[..., :3], wu[..., 3:]
+        W = skew(w)
+        W2 = W @ W
+        A, B, C = _abc(w.norm(dim=-1)[..., None, None])
+        eye = torch.eye(3, device=w.device, dtype=w.dtype)
+        R = eye + A * W + B * W2
+        V = eye + B * W + C * W2
+        return torch.cat([R, V @ u[..., None]], dim=-1)
+
+    @staticmethod
+    def SO3_to_so3(R, eps=1e-7):
+        cos = ((R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2] - 1) / 2).clamp(-1 + eps, 1 - eps)
+        theta = torch.remainder(torch.acos(cos), math.pi)[..., None, None]
+        A, _, _ = _abc(theta)
+        log = (R - R.transpose(-2, -1)) / (2 * A + 1e-8)
+        return torch.stack([log[..., 2, 1], log[..., 0, 2], log[..., 1, 0]], dim=-1)
+
+    @staticmethod
+    def SE3_to_se3(Rt, eps=1e-8):
+        R, t = Rt[..., :3], Rt[..., 3:]
+        w = Lie.SO3_to_so3(R)
+        W = skew(w)
+        theta = w.norm(dim=-1)[..., None, None]
+        A, B, _ = _abc(theta)
+        inv_v = torch.eye(3, device=w.device, dtype=w.dtype) - 0.5 * W + (1 - A / (2 * B)) / (theta ** 2 + eps) * (W @ W)
+        return torch.cat([w, (inv_v @ t)[..., 0]], dim=-1)
+
+
+lie = Lie()

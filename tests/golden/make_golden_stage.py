@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Stage-LOOP golden vectors: K consecutive iterations of the REFERENCE's own stage loops, driven through the
+reference's own `Camera` / `CameraSet` / `Point3DSet` objects, `torch.optim.Adam` and `ExponentialLR`, imported from
+/root/reference where they lie.  Build container only.
+
+    python tests/golden/make_golden_stage.py   ->  tests/golden/stage_<case>.npz   (data only)
+
+  refine_*   `Refine.run`  (pipelines/rendering_refine.py:72-97): per iteration  CameraSet.render(pose_input, rgbs_gt, pointset) --
+             ray pick, multi-view tracing consistency of one random camera's key points (Camera.py:466-476), Renderer.forward,
+             SDF.sphere_tracing, masks, rgb / DC losses, PSNR -- compute_loss / summarize_loss (eikonal over ALL normals,
+             sdf_surf on the key-point tracks, 10^w weights), backward, Adam.step, ExponentialLR.step
+  ba_*       `BA.run_ba`   (pipelines/BA.py:110-188), mode "sfm_refine", two cameras: the point side (get_surface_pts,
+             infer_sdf, re-projection through the pose parameters, mask_surf), the render side, compute_loss (eikonal over
+             mask_bg), the adaptive re-projection weight, backward, Adam over poses + both fields, the point update
+
+Recorded per iteration: the RNG draws that pick inputs (the H*W ray permutation's head, the random camera), every loss term,
+PSNR; at the end: every parameter (fields, poses), the points.  Inputs: poses, intrinsics, images, key points, tracks, the
+initial weights.  Stubs as in make_golden_caller.py (the two third-party CUDA ops come from the oracle).
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+K_ITERS = 20
+CASES = [
+    # name, loop, dataset, L, log2_T, dual, N, H, W, rand_rays, n_kp
+    ("stage_refine_dtu_dual", "refine", "DTU", 8, 12, True, 24, 24, 32, 96, 40),
+    ("stage_refine_eth3d_single", "refine", "ETH3D", 6, 11, False, 16, 20, 28, 80, 32),
+    ("stage_ba_dtu_dual", "ba", "DTU", 8, 12, True, 24, 24, 32, 96, 64),
+]
+OPTIM = dict(algo="Adam", algo_split="SGD", optim_split=True, use_grad_clip=False,
+             sched=dict(type="ExponentialLR"),
+             refine=dict(max_iter=K_ITERS, lr_sdf=1e-3, lr_sdf_end=5e-4, lr_color=1e-3, lr_color_end=5e-4),
+             ba=dict(max_iter=K_ITERS, lr_sdf=1e-4, lr_sdf_end=5e-5, lr_pose=1e-2, lr_pose_end=5e-3, lr_color=1e-3,
+                     lr_color_end=5e-4, lr_pose_r=5e-3, lr_pose_t=1e-2))                      # LevelS2fM.yaml:60-90
+WEIGHTS = dict(refine=dict(eikonal_loss=2, rgb=3, DC_Loss=0, tracing_loss=2, sdf_surf=2),
+               ba=dict(reproj_error=0, eikonal_loss=2, sdf_surf=2, rgb=3, DC_Loss=0, tracing_loss=1))   # LevelS2fM.yaml:98-123
+
+
+def look_out_poses(n, s, gen):
+    """n world-to-camera [3,4] poses near the centre of the scene box, looking outwards (the `inside = False` datasets: the
+    cameras stand inside the surface, models/SDF.py:66-71)"""
+    out = []
+    for v in range(n):
+        ang = 0.4 + 0.08 * v                                    # a small baseline: the views overlap
+        fwd = torch.tensor([np.sin(ang), 0.1, np.cos(ang)], dtype=torch.float32)
+        fwd = fwd / fwd.norm()
+        eye = 0.05 * s * torch.tensor([np.cos(ang), 0.0, -np.sin(ang)], dtype=torch.float32) * (2 * v - 1) + 0.03 * s * torch.randn(3, generator=gen)
+        up = torch.tensor([0.0, 1.0, 0.0])
+        right = torch.linalg.cross(up, fwd); right = right / right.norm()
+        up2 = torch.linalg.cross(fwd, right)
+        R = torch.stack([right, up2, fwd], dim=0)
+        out.append(torch.cat([R, (-R @ eye)[:, None]], dim=1))
+    return torch.stack(out)
+
+
+class Recorder:
+    """logs the RNG draws that pick a step's inputs while the reference loop runs"""
+
+    def __init__(self, hw):
+        self.hw, self.perms, self.cams = hw, [], []
+        self._randperm, self._randint = torch.randperm, random.randint
+
+    def __enter__(self):
+        def randperm(n, *a, **kw):
+            out = self._randperm(n, *a, **kw)
+            if n == self.hw:
+                self.perms.append(out.clone())
+            return out
+
+        def randint(a, b):
+            v = self._randint(a, b)
+            self.cams.append(v)
+            return v
+        torch.randperm, random.randint = randperm, randint
+        return self
+
+    def __exit__(self, *exc):
+        torch.randperm, random.randint = self._randperm, self._randint
+
+
+def main():
+    import make_golden_caller as MC
+    MG, SDF, RadF, Renderer, RefCamera, RefBA = MC.import_reference_pipelines()
+    from pipelines import rendering_refine as RefRefine
+    from pipelines import Point3D as RefPoint3D
+    import utils.camera as ref_camera
+
+    for ci, (name, loop, dataset, L, log2_T, dual, N, H, W, rand_rays, n_kp) in enumerate(CASES):
+        torch.manual_seed(9000 + ci)
+        random.seed(9050 + ci)
+        gen = torch.Generator().manual_seed(9100 + ci)
+        hash_json = MG.write_hash_json(L, log2_T)
+        opt = MG.make_opt(dataset, hash_json, dual, N)
+        opt.H, opt.W = H, W
+        opt.data.image_size = [H, W]
+        opt.camera = MG.AttrDict(model="perspective")
+        opt.Renderer = MG.AttrDict(rand_rays=rand_rays)
+        opt.optim = MG.AttrDict(json.loads(json.dumps(OPTIM)))
+        opt.loss_weight = MG.AttrDict(json.loads(json.dumps(WEIGHTS)))
+        sdf, rad, ren = SDF(opt), RadF(opt), Renderer(opt)
+        MG.randomize_module(sdf, gen, table_amp=0.02, w_std=0.01)      # mild: sphere tracing converges (make_golden_caller.py)
+        MG.randomize_module(rad, gen)
+        s = (opt.data.bound_max[0] - opt.data.bound_min[0]) / 2
+        n_views = 2
+        poses = MC.look_at_poses(n_views, s, gen) if opt.data.inside else look_out_poses(n_views, s, gen)    # world -> camera [V,3,4]
+        se3 = ref_camera.lie.SE3_to_se3(poses)                         # [V,6]: what a Camera keeps (Camera.py:76-83)
+        focal = 0.9 * W
+        intr = torch.tensor([[focal, 0.0, W / 2], [0.0, focal, H / 2], [0.0, 0.0, 1.0]])
+        images = torch.rand(n_views, 3, H, W, generator=gen)           # Camera.render reads img_gt.view(3, -1)
+        flat = images.view(n_views, 3, -1)
+        flat[:, :, ::7] = 0.99                                         # some near-white / near-black pixels: outside mask_bg
+        flat[:, :, 3::11] = 0.01
+
+        # ---- cameras and tracked points: key points of camera 0 are traced onto the surface, the points are perturbed and
+        # projected into camera 1 (+ noise) -> two-view feature tracks with a small re-projection error
+        cset = RefCamera.CameraSet(opt)
+        kp0 = torch.stack([torch.rand(n_kp, generator=gen) * (W - 4) + 2, torch.rand(n_kp, generator=gen) * (H - 4) + 2], dim=-1)
+        for v in range(n_views):
+            cset.add_camera(id=v, img_gt=images[v], kypts2D=kp0.clone(), pose_gt=poses[v:v + 1], Match_mask=None, Inlier_mask=None,
+                            Intrinsic=intr, Extrinsic=se3[v:v + 1])
+        with torch.no_grad():
+            pts0, fin0, _, _ = cset(0).get_pts3D(sdf, np.arange(n_kp))                    # [1,n,3]
+            xyz = pts0[0] + 0.01 * s * torch.randn(n_kp, 3, generator=gen)
+            uv1 = ref_camera.cam2img(ref_camera.world2cam(xyz[None], poses[1:2]), intr[None])[0]
+            uv1 = uv1[:, :2] / uv1[:, 2:] + 0.3 * torch.randn(n_kp, 2, generator=gen)
+            ok = (uv1[:, 0] > 1) & (uv1[:, 0] < W - 1) & (uv1[:, 1] > 1) & (uv1[:, 1] < H - 1) & torch.isfinite(xyz).all(-1)
+        assert int(ok.sum()) >= n_kp // 4, f"too few two-view tracks: {int(ok.sum())}/{n_kp}"
+        kp = [kp0[ok].clone(), uv1[ok].clone()]
+        xyz = xyz[ok]
+        n_pts = xyz.shape[0]
+        pset = RefPoint3D.Point3DSet(opt)
+        for v in range(n_views):
+            cset(v).kypts = kp[v]
+            cset(v).idx2d_to_3d = np.arange(n_pts)
+        for j in range(n_pts):
+            pset.add_point3d(xyz[j:j + 1].clone(), [(0, j), (1, j)])
+
+        out = {}
+        out.update(MG.sd_np(sdf, "sdf0"))
+        out.update(MG.sd_np(rad, "rad0"))
+        out.update({"poses": poses.numpy(), "se3": se3.numpy(), "intrinsic": intr.numpy(), "images": images.numpy(),
+                    "kypts": torch.stack(kp).numpy(), "xyzs": xyz.numpy(), "H": np.int32(H), "W": np.int32(W)})
+
+        # ---- the loop, logged through instance-level wrappers (the loop code itself is the reference's)
+        log = {k: [] for k in ("all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error",
+                               "w_reproj", "mask_bg_count")}
+        render_orig = cset.render
+
+        def render_logged(*a, **kw):
+            ret = render_orig(*a, **kw)
+            log["PSNR"].append(float(ret.PSNR)); log["rgb_loss"].append(float(ret.rgb_loss)); log["DC_loss"].append(float(ret.DC_loss))
+            log["mask_bg_count"].append(int(ret.mask_bg.sum()))
+            return ret
+        cset.render = render_logged
+
+        if loop == "refine":
+            stage = RefRefine.Refine(opt, cset, pset, sdf, rad)                 # consumes one ray permutation (rgbs_gt)
+            wkey = "refine"
+        else:
+            stage = RefBA.BA(opt, cset, pset, sdf, rad, cam_pick_ids=None, mode="sfm_refine")
+            wkey = "ba"
+        summarize_orig = stage.summarize_loss
+
+        def summarize_logged(o, loss):
+            if wkey == "ba":
+                log["w_reproj"].append(float(o.loss_weight.ba.reproj_error))
+            loss = summarize_orig(o, loss)
+            for k, dst in (("eikonal_loss", "eikonal_loss"), ("sdf_surf", "sdf_surf"), ("tracing_loss", "tracing_loss"),
+                           ("reproj_error", "reproj_error"), ("all", "all")):
+                if k in loss:
+                    log[dst].append(float(loss[k]))
+            return loss
+        stage.summarize_loss = summarize_logged
+        with Recorder(H * W) as rec:
+            if loop == "refine":
+                stage.run(sdf, rad, ren)
+            else:
+                stage.run_ba(sdf, rad, ren)
+        assert len(rec.perms) == K_ITERS and len(log["all"]) == K_ITERS, (len(rec.perms), len(log["all"]))
+        n_pick = rand_rays // n_views
+        out["rays_idx"] = torch.stack([p[:n_pick] for p in rec.perms]).numpy()
+        out["cam_pick"] = np.asarray(rec.cams, np.int32)
+        for k, v in log.items():
+            if v:
+                out[f"log/{k}"] = np.asarray(v, np.float64)
+        out.update(MG.sd_np(sdf, "sdf_final"))
+        out.update(MG.sd_np(rad, "rad_final"))
+        if loop == "ba":
+            out["se3_final"] = torch.cat([stage.r_paras(), stage.t_paras()], dim=1).detach().numpy()
+            out["xyzs_final"] = stage.xyzs_all.detach().numpy()
+        meta = dict(dataset=dataset, n_levels=L, log2_hashmap_size=log2_T, dual_field=dual, n_samples=N, loop=loop, iters=K_ITERS,
+                    rand_rays=rand_rays, optim=OPTIM[wkey], weights=WEIGHTS[wkey], bgcolor=list(opt.data.bgcolor),
+                    iters_max_st=int(opt.SDF.VolSDF.iters_max_st), Res=int(opt.Res))
+        out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        os.unlink(hash_json)
+        print(f"[golden] {name}: points={n_pts} loss {log['all'][0]:.4f} -> {log['all'][-1]:.4f}  PSNR {log['PSNR'][0]:.3f} -> "
+              f"{log['PSNR'][-1]:.3f}  cams={rec.cams[:6]}..")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+"""The stage LOOPS (ls2fm.stage.RefineLoop / BALoop) against K = 20 consecutive iterations of the
+REFERENCE's own loops -- `Refine.run` (pipelines/rendering_refine.py:72-97) and `BA.run_ba` (pipelines/BA.py:110-188, mode
+"sfm_refine"), run through the reference's Camera / CameraSet / Point3DSet objects with torch.optim.Adam + ExponentialLR and
+recorded by tests/golden/make_golden_stage.py: per-iteration loss terms and PSNR, the final parameters (fields, poses), the
+final points.  The RNG draws that pick a step's inputs (ray permutation head, the random view of the tracing consistency) are
+replayed from the recording; everything else is the product's: fused render with the loss head inside, fused tracing and
+point queries, FusedAdam with the schedule on the device, no host synchronisation inside an iteration.
+
+Bars: the trajectory bars of test_stage_trajectory_matches_plain_torch (3e-3 on the total loss, 5e-2 on dense weights); a
+20-step Adam trajectory amplifies last-bit differences of the field evaluation through sphere tracing's `t += sdf` and
+through Adam's g / sqrt(v) on near-zero gradients, so single terms get their own, looser bars where noted."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import options_for
+from ls2fm.models.SDF import SDF
+from ls2fm.models.RadF import RadF
+from ls2fm.models.Renderer import Renderer
+from ls2fm import stage
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _scene(g):
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    meta["bg_sdf"] = None
+    opt = options_for(meta, DEV)
+    opt.Res = meta["Res"]
+    sdf, rad, ren = SDF(opt).to(DEV), RadF(opt).to(DEV), Renderer(opt)
+    sdf.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sdf0/")}, strict=True)
+    rad.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("rad0/")}, strict=True)
+    H, W = int(g["H"]), int(g["W"])
+    images = torch.from_numpy(g["images"]).to(DEV)                                 # [V,3,H,W] as the reference's Camera keeps them
+    images = images.reshape(images.shape[0], 3, -1).permute(0, 2, 1).contiguous()  # Camera.render: img_gt.view(3,-1).permute(1,0)
+    kp = [torch.from_numpy(k).to(DEV) for k in g["kypts"]]
+    ids = [torch.arange(k.shape[0], device=DEV) for k in kp]
+    views = stage.TrackedViews(torch.from_numpy(g["poses"]).to(DEV), torch.from_numpy(g["intrinsic"]).to(DEV), images, kp, ids,
+                               torch.from_numpy(g["xyzs"]).to(DEV).clone(), H, W)
+    picks = [(torch.from_numpy(g["rays_idx"][i]).to(DEV), int(g["cam_pick"][i])) for i in range(meta["iters"])]
+    return meta, opt, sdf, rad, ren, views, picks
+
+
+def _close(name, got, ref, rtol, atol=0.0):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    ok = err <= rtol * np.abs(ref) + atol
+    assert ok.all(), f"{name}: worst {err.max():.3g} at iteration {int(err.argmax())}: {got[err.argmax()]:.6g} vs {ref[err.argmax()]:.6g}"
+
+
+def _dense_close(mod, g, prefix, tol=5e-2):
+    for k, v in mod.state_dict().items():
+        if k.endswith("embedder_obj.params"):
+            continue                                            # tables: Adam turns every non-zero gradient into a +-lr step
+        ref = torch.from_numpy(g[f"{prefix}/{k}"])
+        assert float((v.cpu() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6, (prefix, k)
+
+
+@pytest.mark.parametrize("case", ["stage_refine_dtu_dual", "stage_refine_eth3d_single"])
+@pytest.mark.parametrize("capture", [False, True])
+def test_refine_loop_vs_reference_loop(case, capture):
+    g = load_golden(case)
+    meta, opt, sdf, rad, ren, views, picks = _scene(g)
+    o = meta["optim"]
+    loop = stage.RefineLoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                            lr_color=o["lr_color"], max_iter=o["max_iter"], rand_rays=meta["rand_rays"], capture=capture)
+    logs = {k: v.cpu().numpy() for k, v in loop.run(picks=picks).items()}
+    print(f"[{case} capture={capture}] loss {logs['all'][0]:.4f} -> {logs['all'][-1]:.4f} (reference {g['log/all'][0]:.4f} -> "
+          f"{g['log/all'][-1]:.4f}); PSNR {logs['PSNR'][-1]:.4f} vs {g['log/PSNR'][-1]:.4f}")
+    _close("loss.all", logs["all"], g["log/all"], 3e-3)
+    _close("PSNR", logs["PSNR"], g["log/PSNR"], 3e-3)
+    _close("rgb_loss", logs["rgb_loss"], g["log/rgb_loss"], 3e-3)
+    _close("eikonal_loss", logs["eikonal_loss"], g["log/eikonal_loss"], 1e-2)
+    # tracing terms: sums over a few dozen key points whose tracks end at the iteration cap on a still random-ish field
+    _close("sdf_surf", logs["sdf_surf"], g["log/sdf_surf"], 2e-2, atol=2e-4)
+    _close("tracing_loss", logs["tracing_loss"], g["log/tracing_loss"], 2e-2, atol=2e-4)
+    _close("DC_loss", logs["DC_loss"], g["log/DC_loss"], 5e-2, atol=5e-4)
+    _dense_close(sdf, g, "sdf_final")
+    _dense_close(rad, g, "rad_final")
+
+
+def test_ba_loop_vs_reference_loop():
+    g = load_golden("stage_ba_dtu_dual")
+    meta, opt, sdf, rad, ren, views, picks = _scene(g)
+    o = meta["optim"]
+    views.poses = torch.from_numpy(g["se3"]).to(DEV)            # the loop optimises the se(3) parameters
+    loop = stage.BALoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                        lr_color=o["lr_color"], lr_pose_r=o["lr_pose_r"], lr_pose_t=o["lr_pose_t"], max_iter=o["max_iter"],
+                        rand_rays=meta["rand_rays"])
+    logs = {k: v.cpu().numpy() for k, v in loop.run(picks=picks).items()}
+    print(f"[ba] loss {logs['all'][0]:.4f} -> {logs['all'][-1]:.4f} (reference {g['log/all'][0]:.4f} -> {g['log/all'][-1]:.4f}); "
+          f"reproj {logs['reproj_error'][0]:.4f} -> {logs['reproj_error'][-1]:.4f} (reference {g['log/reproj_error'][-1]:.4f})")
+    assert np.array_equal(10.0 ** g["log/w_reproj"], logs["w_reproj"]), "adaptive re-projection weight (BA.py:163-166)"
+    _close("loss.all", logs["all"], g["log/all"], 3e-3)
+    _close("PSNR", logs["PSNR"], g["log/PSNR"], 3e-3)
+    _close("reproj_error", logs["reproj_error"], g["log/reproj_error"], 1e-2)
+    # the render poses go through SE(3) -> se(3) -> SE(3) here (the loop owns se(3) parameters): last-bit differences of that
+    # round trip move the sample positions by ~1e-7, and the normal of a hash field amplifies a position change by the finest
+    # level's scale -- already at iteration 0 the eikonal term (a mean of | |n| - 1 | over ~70 rays x 24 samples) differs by
+    # ~1e-3 relative; it carries 10^2 of a total loss of ~480, which holds its 3e-3 bar above
+    _close("eikonal_loss", logs["eikonal_loss"], g["log/eikonal_loss"], 3e-2)
+    _close("sdf_surf", logs["sdf_surf"], g["log/sdf_surf"], 2e-2, atol=2e-4)
+    _close("tracing_loss", logs["tracing_loss"], g["log/tracing_loss"], 2e-2, atol=2e-4)
+    se3 = loop.poses_se3().cpu()
+    ref = torch.from_numpy(g["se3_final"])
+    assert float((se3 - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), "poses after 20 Adam steps"
+    xyz = loop.xyzs_all.cpu()
+    # 20 successive projections p <- p - n / |n| sdf(p) (a Newton step on a still noisy field) amplify last-bit differences for the
+    # points that sit where the field is rough (measured: most points agree to 1e-5, a handful drift by up to 2e-2): half of
+    # the points within 2e-3 of the scene scale, 90 % within 1e-2, every point within 5e-2
+    err = (xyz - torch.from_numpy(g["xyzs_final"])).norm(dim=-1)
+    scale = float(np.abs(g["xyzs_final"]).max())
+    assert float(err.median()) <= 2e-3 * scale and float(err.quantile(0.9)) <= 1e-2 * scale and float(err.max()) <= 5e-2 * scale, \
+        (float(err.median()), float(err.quantile(0.9)), float(err.max()))
+    assert torch.equal(views.xyzs.cpu(), torch.from_numpy(g["xyzs"])), "the point set itself does not move during the loop"
+    _dense_close(sdf, g, "sdf_final")
+    _dense_close(rad, g, "rad_final")
+
+
+def test_static_sphere_tracing_samples_have_the_reference_structure():
+    """`sampled_pts` of SDF.sphere_tracing (SDF.py:216-224) in the capturable form: fixed shape + device mask; the masked rows
+    are exactly what the synchronising form returns for the same draws' structure: track points of <= 4096 random rays (first K
+    columns), then one point per ray between near and min(1.5 t_end, far)."""
+    g = load_golden("stage_refine_eth3d_single")
+    meta, opt, sdf, rad, ren, views, picks = _scene(g)
+    centers, rays, _ = stage._pick_rays(views, views.poses, picks[0][0])
+    o, d = centers.reshape(1, -1, 3), rays.reshape(1, -1, 3)
+    n_rays, it = o.shape[1], int(sdf.iters_max)
+    d_a, last_a, samp, fin_a = sdf.sphere_tracing(o, d, sdf, static_trips=True, want_samples=True)
+    mask = sdf.last_sample_mask
+    k = int(sdf.last_trips.item())
+    assert samp.shape == (1, min(4096, n_rays) * it + n_rays, 3) and mask.shape == (samp.shape[1],)
+    assert int(mask.sum()) == min(4096, n_rays) * max(k, 1) + n_rays
+    d_b, last_b, samp_b, fin_b = sdf.sphere_tracing(o, d, sdf)
+    assert samp_b.shape[1] == int(mask.sum())                              # the reference's (K-dependent) shape
+    assert torch.allclose(d_a, d_b, rtol=1e-5, atol=1e-6) and torch.equal(fin_a, fin_b)
+    # the along-ray samples lie on their rays, inside [near, far]
+    from ls2fm import fused
+    near, far, _, _, _ = fused.sphere_trace(sdf, o[0], d[0], sync=False)
+    tail = samp[0, -n_rays:]
+    t = ((tail - o[0]) * d[0]).sum(-1) / (d[0] * d[0]).sum(-1)
+    hit = far > 0
+    assert bool(((t >= near - 1e-4) & (t <= far + 1e-4))[hit].all())
+    assert torch.allclose(o[0] + t[:, None] * d[0], tail, atol=1e-4 * float(far.abs().max() + 1))
+
+
+def test_geo_init_shaped_step_is_capturable():
+    """The step of `geo_init_nf` (pipelines/Registration.py:188-277) on this path -- sphere tracing of key-point rays, eikonal on
+    the tracing's sample points (`sdf_func.gradient(sample_pts).norm()`, :202), sdf_surf on the track ends, the tracing
+    distance to existing points -- as ONE hipGraph: eager steps and replays of the captured step walk the same trajectory."""
+    from ls2fm.graph import CapturedStep
+    from ls2fm.optim import FusedAdam
+    g = load_golden("stage_refine_dtu_dual")
+
+    def build():
+        meta, opt, sdf, rad, ren, views, picks = _scene(g)
+        c, r = stage.keypoint_rays(views.poses[0], views.intrinsic, views.kp_pad[0])
+        target = views.xyzs[views.id_pad[0]]
+        optim = FusedAdam(list(sdf.parameters()), lr=1e-3, scheduled_gamma=0.99)
+        gen_state = torch.cuda.get_rng_state()
+
+        def step():
+            for p in sdf.parameters():
+                p.grad = None
+            d, sdf_surf, samples, _ = sdf.sphere_tracing(c, r, sdf, static_trips=True, want_samples=True)
+            w = sdf.last_sample_mask.float()
+            grad_norm = sdf.gradient(samples[0].clone()).norm(dim=-1)
+            eik = ((grad_norm - 1).abs() * w).sum() / w.sum()
+            surface = c[0] + r[0] * d.reshape(-1, 1)
+            loss = 10.0 * (target - surface).norm(dim=-1).mean() + 100.0 * sdf_surf.abs().mean() + 100.0 * eik
+            loss.backward()
+            optim.step()
+            return loss.detach()
+        return sdf, optim, step, gen_state
+
+    sdf_a, _, step_a, _ = build()
+    torch.manual_seed(3)
+    eager = [float(step_a()) for _ in range(4)]
+    sdf_b, optim_b, step_b, _ = build()
+    snap = [p.detach().clone() for p in sdf_b.parameters()]
+    cap = CapturedStep(step_b, params=list(sdf_b.parameters()), warmup=2)
+    with torch.no_grad():                      # undo the warm-up / capture steps, restart the schedule
+        for p, q in zip(sdf_b.parameters(), snap):
+            p.copy_(q)
+        for st in optim_b.state.values():
+            st["step"] = 0; st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        for t in optim_b._sched.values():
+            t.copy_(torch.tensor([0.0, 1e-3, 0.99, 0.0], dtype=torch.float64))
+    torch.manual_seed(3)                       # a replay takes its Philox offsets from the generator's state, as an eager step does
+    replayed = [float(cap.replay()) for _ in range(4)]
+    print(f"[geo-init step] eager {eager} replayed {replayed}")
+    assert np.isfinite(replayed).all() and replayed[-1] < replayed[0]
+    # same seed, same number of draws per step: the replays see the eager run's sample points
+    np.testing.assert_allclose(replayed, eager, rtol=2e-3)
