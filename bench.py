@@ -120,6 +120,8 @@ def cpu_baseline(dataset, dual, n_samples, n_rays=1024, budget_s=25.0):
 
 # per-GPU workloads of BASELINE.json's configurations; weak scaling: every rank renders `rays` rays
 CONFIGS = {
+    "C1": dict(dataset="DTU", rays=256, samples=32, dual=False,
+               note="configs[0]: one synthetic view, 256 rays x 32 samples, single field (the reference's CPU-runnable case)"),
     "C2": dict(dataset="ETH3D", rays=1024, samples=128, dual=True,
                note="configs[1]: ETH3D two-view init, 1024 rays x 128 samples, hash-grid SDF + radiance"),
     "C3": dict(dataset="DTU", rays=8192, samples=128, dual=True,
@@ -157,6 +159,14 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce after the backward instead of the "
                     "level-group reductions issued from inside it")
     ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
+    ap.add_argument("--exchange", choices=("shard", "allreduce"), default="shard",
+                    help="N > 1: how the ranks exchange a step's gradients.  shard (default): reduce-scatter of the flat gradient "
+                         "buffer -> Adam on this rank's 1/N of the parameters (ls2fm.dist.ShardedAdam) -> all-gather of the updated "
+                         "shards; allreduce: sum all-reduce of the gradients, no update in the step (--no-shard)")
+    ap.add_argument("--no-shard", dest="exchange", action="store_const", const="allreduce")
+    ap.add_argument("--inference", action="store_true",
+                    help="time the forward-only render under no_grad (the eval path: Camera.render_img_by_slices renders an image "
+                         "in rand_rays chunks, pipelines/Camera.py:274-311) instead of the training step")
     args = ap.parse_args()
     preset = CONFIGS[args.config]
     args.rays = preset["rays"] if args.rays is None else args.rays
@@ -209,8 +219,16 @@ def main():
     center, ray = synthetic_rays(args.rays, s, dev, seed=rank)      # each rank: its own view's rays
     assert fused.can_render(ren, opt, center, ray, sdf, rad), "fused HIP path not taken"
     params = list(sdf.parameters()) + list(rad.parameters())
-    reducer = GradAllReducer(params) if multi else None
-    if multi and not args.no_overlap:
+    shard = multi and args.exchange == "shard" and not args.inference
+    reducer = GradAllReducer(params) if (multi and not shard and not args.inference) else None
+    sharded_opt = None
+    if shard:
+        # reduce-scatter -> Adam on this rank's shard -> all-gather: the same bytes on xGMI as the all-reduce, optimizer state
+        # and update traffic / world; the step then includes the (sharded) update
+        from ls2fm.dist import ShardedAdam
+        sharded_opt = ShardedAdam.for_fields(sdf, rad, lr=1e-4, lr_color=1e-4, scheduled_gamma=1.0)
+        params = list(sharded_opt.params)
+    if reducer is not None and not args.no_overlap:
         # the ~105 MB gradient exchange is as long as the step on 7 xGMI links and all of it comes out of the backward's last
         # kernels: scatter the levels in 4 groups and all-reduce a group's table slices while the next ones are scattered
         enable_table_overlap(sdf, rad, n_groups=args.overlap_groups)
@@ -227,6 +245,9 @@ def main():
 
     def render_step():
         """Renderer.forward -> loss head -> backward: every parameter's .grad is (re)written"""
+        if args.inference:
+            with torch.no_grad():
+                return ren.forward(opt, center, ray, sdf, rad)["rgb"]
         for p in params:
             p.grad = None
         if args.torch_loss:
@@ -241,6 +262,8 @@ def main():
     mode = "graph" if args.graph else args.launch
     if multi and mode != "graph":
         mode = "eager"                  # collectives are issued from inside the backward: keep them out of graph captures
+    if shard:
+        mode = "eager"                  # the step rewrites the parameters through collectives: not captured
     # every step -- eager or captured -- runs on ONE non-default stream: autograd's gradient accumulators stay tied to
     # the stream of their first backward, and mixing streams costs synchronisations (and breaks captures)
     s_main = torch.cuda.Stream(device=dev)
@@ -255,7 +278,10 @@ def main():
             render_step()
         if reducer is not None:
             reducer.all_reduce()
+        if sharded_opt is not None:
+            sharded_opt.step()
 
+    launch_probe = None
     if mode == "graph":
         captured = CapturedStep(render_step, params, stream=s_main)
         use_graph = True
@@ -275,6 +301,7 @@ def main():
         captured = CapturedStep(render_step, params, stream=s_main)
         t_graph = probe(True)
         use_graph = t_graph < 0.98 * t_eager
+        launch_probe = {"eager_ms_per_step": t_eager * 1e3, "graph_ms_per_step": t_graph * 1e3}
         if rank == 0:
             print(f"[bench] launch probe: eager {t_eager * 1e3:.3f} ms/step, hipGraph {t_graph * 1e3:.3f} ms/step", file=sys.stderr)
         if world > 1:                       # every rank must take the same path
@@ -335,13 +362,13 @@ def main():
         # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter summary of
         # this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is QUOTED when the workload
         # is the default one -- with the commit it was measured at, so a stale figure is recognisable
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
             doc = json.load(open(pmc))
             rec = doc.get(roofline["kernel"])
             if rec:
                 roofline["traffic"] = rec["fetch"] + rec["write"]
-                roofline["traffic_source"] = (f"quoted from profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                roofline["traffic_source"] = (f"quoted from profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                               f"passes at commit {doc.get('_commit', '?')}; FETCH_SIZE doubled per the guide)")
         if roofline:
             # SURVEY 8d's whole-step figures: algorithmic table bytes (gather + scatter, both grids) and dense FLOPs of one step
@@ -355,16 +382,19 @@ def main():
                         "unit": "GB/s", "frac": n_pts * bytes_per_pt / step_s / 1e9 / HBM_PEAK_GBS},
                 "mfma": {"flops_per_ray": flops_per_pt * args.samples, "achieved": n_pts * flops_per_pt / step_s / 1e12,
                          "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": n_pts * flops_per_pt / step_s / 1e12 / F32_PEAK_TFLOPS}}
+    if args.inference and roofline:
+        roofline.pop("whole_step", None)        # (the whole-step figures are the training step's)
     out = {
-        "metric": "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
+        "metric": "rendered rays/sec (forward only, no_grad)" if args.inference else "rendered rays/sec (fwd+bwd)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "timed_blocks": len(blocks), "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launch": ("hipGraph replay of the whole step" if use_graph else "eager") + (" (auto)" if mode == "auto" else ""),
         "eager_profiled_ms_per_step": dt_eager / args.steps * 1e3,
+        "launch_probe": launch_probe,           # untimed probe of both launch forms (auto mode): eager and hipGraph ms/step
         "config": {"workload": f"{args.config}: {args.dataset} bounds, {args.rays} rays x {args.samples} samples per GPU, "
                                f"{'dual' if dual else 'single'} field, L16/F2/T19 hash grid, fwd+loss+bwd"
-                               + (", RCCL grad all-reduce" if multi else ""),
+                               + ((", RCCL reduce-scatter + sharded Adam + all-gather" if shard else ", RCCL grad all-reduce") if multi else ""),
                    "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "dual_field": dual,
                    "parallelism": f"dp{world} (rays sharded by view)"},
         "roofline": roofline,

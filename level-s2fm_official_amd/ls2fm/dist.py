@@ -96,6 +96,7 @@ def global_max_int(value: int, device) -> int:
 # n groups (ls2fm_render_opts.n_level_groups), records an event per group, and issues that group's all-reduce of both tables'
 # slices on a communication stream right away: the exchange of the first groups runs beside the scatter of the later ones.
 _COMM_STREAMS = {}
+_PENDING = {}          # id(flat) -> (flat, [async work handles]): group reductions launched from inside a fused backward
 
 
 def comm_stream(device) -> torch.cuda.Stream:
@@ -164,6 +165,7 @@ def launch_group_reductions(flat, tables, level_offsets, events, n_levels):
         with torch.cuda.stream(comm):
             pending.extend(_all_reduce_together([t[lo:hi] for t in tables] + (rest if last else [])))
     flat._ls2fm_pending = pending
+    _PENDING[id(flat)] = (flat, pending)       # GradAllReducer.all_reduce waits for EVERY launched reduction, whatever it finds in .grad
 
 
 class GradAllReducer:
@@ -201,18 +203,34 @@ class GradAllReducer:
         if flat is None:
             return None
         covered = sum((p.grad.numel() + 3) // 4 * 4 for p in self.params)         # 16-byte segments
-        return flat if covered == flat.numel() else None     # nothing else lives in the buffer
+        padded = max(covered, int(getattr(self.params[0], "_ls2fm_flat_total", 0)))   # (zero tail for a sharded optimizer)
+        return flat if flat.numel() in (covered, padded) else None     # nothing else lives in the buffer
 
     def all_reduce(self) -> None:
         if not is_distributed():
             return
         world = dist.get_world_size()
         whole = self._all_in_flat()
-        pending = getattr(whole, "_ls2fm_pending", None) if whole is not None else None
-        if pending is not None:                            # everything is already on its way (enable_table_overlap)
-            whole._ls2fm_pending = None
-            for h in pending:
+        # Reductions a fused backward launched itself (enable_table_overlap) are ALWAYS waited for here -- also when this
+        # reducer does not recognise their buffer as its gradients -- so nothing is left reducing `flat` in place on the
+        # communication stream while later code reads or rewrites it.
+        launched = list(_PENDING.values())
+        _PENDING.clear()
+        for flat, handles in launched:
+            for h in handles:
                 h.wait()
+            flat._ls2fm_pending = None
+        if launched:
+            # The in-place group reductions are only valid when that backward was the SOLE producer of every gradient: a second
+            # node on the same parameters (a traced-depth / point-query node, gradient accumulation over several backwards)
+            # makes autograd add into -- or replace -- the buffer while RCCL is reducing it.  That cannot be repaired after the
+            # fact (what was read and what was reduced is undefined), so it is refused loudly.
+            if whole is None or len(launched) != 1 or launched[0][0] is not whole:
+                raise RuntimeError(
+                    "ls2fm.dist: enable_table_overlap() needs the fused render to be the only gradient producer of a step (its "
+                    "backward launches in-place reductions of its own gradient buffer); this step accumulated gradients from "
+                    "another node or an earlier backward.  Turn the overlap off (enable_table_overlap(..., n_groups=0)) for "
+                    "such steps -- the flat all-reduce handles them")
             if self.average:
                 whole.div_(world)
             return
@@ -248,3 +266,146 @@ class GradAllReducer:
             for p in self.params:
                 if p.grad is not None:
                     p.grad.div_(world)
+
+
+# ---- reduce-scatter -> sharded Adam -> all-gather ------------------------------------------------------------------------------
+# The all-reduce above leaves every rank with the full 105 MB gradient and has every rank run the full Adam update (16 B of
+# HBM traffic per parameter: 0.13 ms on one MI355X).  The sharded form moves the same bytes over xGMI but splits them around the
+# update: reduce-scatter (each rank receives the SUM of its 1/world of the flat gradient buffer), Adam on that shard only
+# (optimizer state and update traffic / world), all-gather of the updated parameter shards.  The all-gather half no longer
+# blocks the backward's consumers: with `async_gather=True` it runs on the communication stream and is only waited for by the
+# next step's first reader (`wait_params()`), i.e. beside that step's ray pick / sphere tracing launch work.
+class ShardedAdam:
+    """Adam (+ ExponentialLR on the device with `scheduled_gamma`) over parameters flattened into ONE buffer that is sharded
+    evenly over the ranks.
+
+        opt = ShardedAdam.for_fields(sdf, rad, lr=1e-3, lr_color=1e-3, scheduled_gamma=gamma)
+        loss.backward(); opt.step()            # reduce-scatter, update of this rank's shard, all-gather
+
+    The parameters' storage is re-pointed into the flat buffer (same values, same shapes, same Parameter objects), in the
+    order and with the 16-byte segment layout of `ls2fm.fused.flat_gradient_views`, so the fused backward's flat gradient
+    buffer IS the reduce-scatter's input -- no packing; gradients found elsewhere (composed form, accumulated over several
+    nodes) are packed first.  One process group = one replica set; world 1 degenerates to a plain fused Adam."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, scheduled_gamma=None, group_lrs=None,
+                 async_gather=False, update=None):
+        from . import fused as _fused
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("ShardedAdam: no parameters")
+        self.world = dist.get_world_size() if is_distributed() else 1
+        self.rank = dist.get_rank() if is_distributed() else 0
+        dev = self.params[0].device
+        offs, at = [], 0
+        for p in self.params:
+            offs.append(at)
+            at += (p.numel() + 3) // 4 * 4
+        self.offsets, self.used = offs, at
+        unit = 4 * self.world
+        self.total = (at + unit - 1) // unit * unit
+        self.shard = self.total // self.world
+        self.flat = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                if p.dtype != torch.float32:
+                    raise RuntimeError("ShardedAdam: fp32 parameters only")
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.detach())
+                p.data = view                                  # same Parameter object, storage now inside the flat buffer
+                p._ls2fm_flat_total = self.total               # fused.flat_gradient_views pads its buffer to this length
+        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        self.gshard = torch.zeros(self.shard, device=dev, dtype=torch.float32)
+        self._gpack = None
+        # this rank's shard as parameter-group slices: Parameters that VIEW the flat buffer, their .grad views of `gshard`
+        lrs = list(group_lrs) if group_lrs is not None else [lr] * len(self.params)
+        by_lr = {}
+        for p, o, plr in zip(self.params, offs, lrs):
+            a, b = max(o, lo), min(o + p.numel(), hi)
+            if a < b:
+                sl = torch.nn.Parameter(self.flat[a:b], requires_grad=True)
+                sl.grad = self.gshard[a - lo:b - lo]
+                by_lr.setdefault(float(plr), []).append(sl)
+        groups = [dict(params=v, lr=k) for k, v in by_lr.items()]
+        self._owns_any = bool(groups)
+        if update is not None:                 # tests on the CPU inject a torch Adam here; the product path is the HIP kernel
+            self.inner = update(groups if groups else [dict(params=[torch.nn.Parameter(torch.zeros(1, device=dev))], lr=lr)])
+        else:
+            from .optim import FusedAdam
+            self.inner = FusedAdam(groups if groups else [torch.nn.Parameter(torch.zeros(1, device=dev))], lr=lr, betas=betas,
+                                   eps=eps, weight_decay=weight_decay, scheduled_gamma=scheduled_gamma)
+        self.async_gather = bool(async_gather)
+        self._gather = None
+        self._fused = _fused
+
+    @classmethod
+    def for_fields(cls, sdf_field, rad_field, lr=1e-3, lr_color=None, **kw):
+        """both fields' parameters in the fused backward's order (ls2fm.fused.param_tensors); lr / lr_color as BA.py:79-83"""
+        from . import fused as _fused
+        ts, _ = _fused.param_tensors(sdf_field, rad_field)
+        own_sdf = {id(p) for p in sdf_field.parameters()}
+        lrs = [lr if (id(p) in own_sdf or lr_color is None) else lr_color for p in ts]
+        return cls(ts, lr=lr, group_lrs=lrs, **kw)
+
+    @property
+    def param_groups(self):
+        return self.inner.param_groups
+
+    def wait_params(self):
+        """the all-gather of the last step (async_gather): call before anything reads the parameters"""
+        if self._gather is not None:
+            self._gather.wait()
+            self._gather = None
+
+    def _flat_gradient(self):
+        """the flat gradient buffer the fused backward wrote (every .grad a view at this optimizer's offsets), else a packed copy"""
+        flat = getattr(self.params[0], "_ls2fm_grad_flat", None)
+        ok = flat is not None and flat.numel() == self.total
+        if ok:
+            base = flat.data_ptr()
+            for p, o in zip(self.params, self.offsets):
+                g = p.grad
+                if g is None or getattr(p, "_ls2fm_grad_flat", None) is not flat or g.data_ptr() != base + 4 * o or not g.is_contiguous():
+                    ok = False
+                    break
+        if ok:
+            return flat
+        if self._gpack is None:
+            self._gpack = torch.zeros(self.total, device=self.flat.device, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            seg = self._gpack[o:o + p.numel()]
+            if p.grad is None:
+                seg.zero_()
+            else:
+                seg.copy_(p.grad.reshape(-1))
+        return self._gpack
+
+    @torch.no_grad()
+    def step(self):
+        self.wait_params()
+        # reductions a fused backward launched itself must not be in flight on the buffer that is scattered next
+        if _PENDING:
+            raise RuntimeError("ls2fm.dist.ShardedAdam: enable_table_overlap() launches all-reduces of the gradient buffer; use one "
+                               "exchange or the other")
+        flat_g = self._flat_gradient()
+        lo = self.rank * self.shard
+        if self.world > 1:
+            dist.reduce_scatter_tensor(self.gshard, flat_g)
+        else:
+            self.gshard.copy_(flat_g[lo:lo + self.shard])
+        if self._owns_any:
+            self.inner.step()
+        if self.world > 1:
+            mine = self.flat[lo:lo + self.shard]
+            if self.async_gather and self.flat.is_cuda:
+                comm = comm_stream(self.flat.device)
+                comm.wait_stream(torch.cuda.current_stream(self.flat.device))
+                with torch.cuda.stream(comm):
+                    self._gather = dist.all_gather_into_tensor(self.flat, mine, async_op=True)
+            else:
+                dist.all_gather_into_tensor(self.flat, mine)
+        for p in self.params:                                  # raw-pointer writes: tell autograd / version-keyed caches
+            torch.autograd.graph.increment_version(p)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None

@@ -236,7 +236,11 @@ def flat_gradient_views(ps):
     for p in ps:
         offs.append(at)
         at += (p.numel() + 3) // 4 * 4
-    flat = torch.empty(at, device=ps[0].device, dtype=torch.float32)
+    # a sharded optimizer (ls2fm.dist.ShardedAdam) reduce-scatters this buffer: it then has that optimizer's padded length
+    total = max(at, int(getattr(ps[0], "_ls2fm_flat_total", 0)))
+    flat = torch.empty(total, device=ps[0].device, dtype=torch.float32)
+    if total > at:
+        flat[at:].zero_()
     views = [flat[o:o + p.numel()] if p.dim() == 1 else flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, ps)]
     for p in ps:
         p._ls2fm_grad_flat = flat

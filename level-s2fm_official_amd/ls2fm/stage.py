@@ -91,14 +91,18 @@ class RenderStage:
     its inputs from tensors that are updated in place and must not synchronise."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
-                 eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None):
+                 eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None,
+                 sharded=False, async_gather=False):
         """lr / lr_color: the reference's two field groups (`[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(),
         lr_color}]`, BA.py:79-83; lr_color=None: one rate); extra_params: tensors (one more group at `lr`) or
         `{"params": [...], "lr": x}` dicts (the pose groups of BA.py:60-75).  ONE ExponentialLR factor for all groups,
         (lr_end / lr) ** (1 / max_iter), as the reference's scheduler (BA.py:87-88).
         reducer: an `ls2fm.dist.GradAllReducer` over the same parameters, called between backward and the update -- required
         when a process group is up (the fused loss head then divides by GLOBAL counts: without the reduction every rank would
-        apply 1/world of its local gradient and the replicas would drift apart)."""
+        apply 1/world of its local gradient and the replicas would drift apart) -- or sharded=True: the update is
+        `ls2fm.dist.ShardedAdam` (reduce-scatter of the flat gradient buffer, Adam on this rank's 1/world of the parameters,
+        all-gather of the updated shards; async_gather: the all-gather runs on the communication stream until the next step's
+        first parameter read).  Fields only: pose groups (extra_params) take the all-reduce form."""
         self.opt, self.renderer, self.sdf, self.rad = opt, renderer, sdf_field, rad_field
         dev = next(sdf_field.parameters()).device
         w = weights or {}
@@ -113,7 +117,16 @@ class RenderStage:
         groups = [g for g in groups if g["params"]]
         self.params = [p for g in groups for p in g["params"]]
         self.gamma = (lr_end / lr) ** (1.0 / max_iter)                        # BA.py:87-88
-        self.optim = FusedAdam(groups, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)
+        self.sharded = bool(sharded)
+        if self.sharded:
+            if len(groups) > 2 or capture:
+                raise NotImplementedError("ls2fm.stage.RenderStage(sharded=True): the two field groups only, eager steps only")
+            from .dist import ShardedAdam
+            self.optim = ShardedAdam.for_fields(sdf_field, rad_field, lr=lr, lr_color=lr_color, betas=betas, eps=eps,
+                                                scheduled_gamma=self.gamma, async_gather=async_gather)
+            self.params = list(self.optim.params)
+        else:
+            self.optim = FusedAdam(groups, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)
         self.capture = capture
         self.extra_loss = extra_loss
         self.eikonal_over = eikonal_over
@@ -123,7 +136,9 @@ class RenderStage:
 
     def _eager(self, centers, rays, rgbs_gt, static_trips):
         from . import dist as _dist
-        if _dist.is_distributed() and self.reducer is None:
+        if self.sharded:
+            self.optim.wait_params()               # the previous step's all-gather (async_gather) before anything reads a parameter
+        if _dist.is_distributed() and self.reducer is None and not self.sharded:
             raise RuntimeError("ls2fm.stage.RenderStage under torch.distributed needs reducer=GradAllReducer(stage.params): the loss "
                                "head normalises by global counts, the gradients must be summed over the ranks before the update")
         for p in self.params:

@@ -92,6 +92,99 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _sharded_worker(rank, world, port, out_dir):
+    """reduce-scatter -> Adam on this rank's shard -> all-gather == one process running Adam on the summed gradients"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ls2fm import fused
+        g = torch.Generator().manual_seed(0)
+        shapes = [(1000,), (64, 35), (64, 1), (64,), (17, 64), (1,), (1001,), (3, 64)]     # odd sizes: segments get padded
+        init = [torch.randn(sh, generator=g) for sh in shapes]
+        lrs = [1e-2 if k < 6 else 3e-3 for k in range(len(shapes))]                        # two rates, as lr_sdf / lr_color
+        params = [torch.nn.Parameter(t.clone()) for t in init]
+        ref = [torch.nn.Parameter(t.clone()) for t in init]
+        ref_opt = torch.optim.Adam([dict(params=[ref[k] for k in range(6)], lr=1e-2), dict(params=[ref[k] for k in range(6, 8)], lr=3e-3)])
+        opt = ldist.ShardedAdam(params, group_lrs=lrs, update=lambda groups: torch.optim.Adam(groups))
+        assert opt.total % (4 * world) == 0 and opt.shard * world == opt.total
+        for p, t in zip(params, init):                      # same values, storage now inside the flat buffer
+            assert torch.equal(p.detach(), t) and p.data_ptr() >= opt.flat.data_ptr()
+        for it in range(4):
+            per_rank = [[torch.randn(sh, generator=g) for sh in shapes] for _ in range(world)]
+            if it % 2 == 0:      # the fused backward's way: one flat buffer at this optimizer's offsets (padded to its length)
+                flat, views = fused.flat_gradient_views(params)
+                assert flat.numel() == opt.total
+                for v, t in zip(views, per_rank[rank]):
+                    v.copy_(t)
+                for p, v in zip(params, views):
+                    p.grad = v
+                assert opt._flat_gradient() is flat
+            else:                # loose gradients (composed form): packed
+                for p, t in zip(params, per_rank[rank]):
+                    p.grad = t.clone()
+                    p._ls2fm_grad_flat = None
+            opt.step()
+            for p, *gs in zip(ref, *per_rank):
+                p.grad = sum(gs)
+            ref_opt.step()
+            for k, (p, q) in enumerate(zip(params, ref)):
+                assert torch.allclose(p.detach(), q.detach(), rtol=0, atol=1e-6), (it, k, float((p - q).abs().max()))
+        # every rank holds only its shard of the optimizer state
+        n_state = sum(st["exp_avg"].numel() for st in opt.inner.state.values())
+        assert n_state <= opt.shard
+        with open(os.path.join(out_dir, f"shard_ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_adam_two_rank_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "shard_ok0").exists() and (tmp_path / "shard_ok1").exists()
+
+
+def _pending_worker(rank, world, port, out_dir):
+    """group reductions launched from inside a backward are always waited for, and refused when the step had a second producer"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ls2fm import fused
+        a, b = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(4))
+        flat, (ga, gb) = fused.flat_gradient_views([a, b])
+        flat.fill_(float(rank + 1))
+        h = dist.all_reduce(flat, async_op=True)              # what launch_group_reductions leaves behind
+        flat._ls2fm_pending = [h]
+        ldist._PENDING[id(flat)] = (flat, [h])
+        a.grad, b.grad = ga, gb
+        ldist.GradAllReducer([a, b]).all_reduce()             # sole producer: waits, nothing reduced twice
+        assert torch.equal(flat, torch.full_like(flat, 3.0)) and not ldist._PENDING
+        # a second producer replaced a gradient: the launched reduction is still waited for, then the step is refused
+        flat2, (ga2, gb2) = fused.flat_gradient_views([a, b])
+        flat2.fill_(1.0)
+        h2 = dist.all_reduce(flat2, async_op=True)
+        ldist._PENDING[id(flat2)] = (flat2, [h2])
+        a.grad, b.grad = ga2 + 1.0, gb2                       # autograd summed another node's gradient into a NEW tensor
+        try:
+            ldist.GradAllReducer([a, b]).all_reduce()
+            raised = False
+        except RuntimeError as e:
+            raised = "only gradient producer" in str(e)
+        assert raised and not ldist._PENDING and h2.is_completed()
+        with open(os.path.join(out_dir, f"pend_ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pending_group_reductions_are_always_waited(tmp_path):
+    port = _free_port()
+    mp.spawn(_pending_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "pend_ok0").exists() and (tmp_path / "pend_ok1").exists()
+
+
 def test_two_rank_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -1,8 +1,9 @@
 """bench.py's N > 1 wiring, end to end, on the one GPU a test box has: two ranks launched the way the driver launches them
 (torch.distributed.run, one process per rank) with LS2FM_BENCH_BACKEND=gloo -- RCCL refuses two ranks per device, gloo carries
 device tensors.  The figures of such a run mean nothing (both ranks share the GPU, the all-reduce goes through the host); what
-is tested is the control flow the 2/4/8-GPU runs take: process-group set-up, sharded rays, the overlapped table-gradient
-reduction issued from inside the backward, barriers, the block-count and max-over-ranks reductions, ONE JSON line on rank 0."""
+is tested is the control flow the 2/4/8-GPU runs take: process-group set-up, sharded rays, the gradient exchange -- the default
+reduce-scatter -> sharded Adam -> all-gather, and (--no-shard) the all-reduce, flat or overlapped from inside the backward --,
+barriers, the block-count and max-over-ranks reductions, ONE JSON line on rank 0."""
 import json
 import os
 import socket
@@ -21,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--no-shard"], ["--no-shard", "--no-overlap"]])
 def test_bench_two_ranks_one_gpu(extra):
     env = dict(os.environ, LS2FM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -35,3 +36,16 @@ def test_bench_two_ranks_one_gpu(extra):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["launch"] == "eager"
     assert d["config"]["parallelism"].startswith("dp2")
+    assert ("reduce-scatter" in d["config"]["workload"]) == ("--no-shard" not in extra)
+
+
+def test_bench_c1_and_inference_lines():
+    """--config C1 (BASELINE.json configs[0] at its own shape) and the forward-only line: one JSON line each"""
+    for extra, metric in ((["--config", "C1"], "rendered rays/sec (fwd+bwd)"), (["--inference", "--rays", "512", "--samples", "32"], "rendered rays/sec (forward only, no_grad)")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                              "--launch", "eager"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["metric"] == metric and d["value"] > 0 and d["roofline"] is not None
+        if "C1" in extra:
+            assert d["config"]["rays_per_gpu"] == 256 and d["config"]["samples_per_ray"] == 32 and d["config"]["dual_field"] is False
