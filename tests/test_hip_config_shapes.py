@@ -171,3 +171,39 @@ def test_full_shape_sparse_oracle_sample_and_properties(name):
     for name_, v in named_grads(sdf).items():
         ref = osd[name_].grad if osd[name_].grad is not None else torch.zeros_like(osd[name_])
         assert rel_err(v, ref) < 1e-4, name_
+
+
+def test_config1_whole_batch_vs_oracle():
+    """BASELINE.json configs[0] at ITS OWN shape -- one synthetic view, 256 rays x 32 samples, single field, full L16/F2/T19 grid,
+    the benchmark's synthetic inputs and loss (`bench.py --config C1`): small enough for the CPU oracle to
+    render WHOLE, so every output (2e-5) and every parameter gradient (1e-4; d beta against its exactly summed value) of the
+    fused HIP path is compared with the oracle on the full batch, not on a sample."""
+    import bench
+    opt = make_options("DTU", device=DEV, dual_field=False, sample_intvs=32)
+    sdf, rad, ren = _randomized(opt, 61)
+    s = float(opt.data.bound_max[0])
+    center, ray = bench.synthetic_rays(256, s, DEV, seed=0)
+    assert fused.can_render(ren, opt, center, ray, sdf, rad)
+    sdf.zero_grad(); rad.zero_grad()
+    ret = ren.forward(opt, center, ray, sdf, rad)
+    bench.loss_head(ret).backward()
+    got = _all_grads(sdf, rad)
+
+    cfg = OF.dataset_config("DTU", dual_field=False, sample_intvs=32)
+    osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sdf.state_dict().items()}
+    ord_ = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in rad.state_dict().items()}
+    oret = OF.render(cfg, center.cpu(), ray.cpu(), osd, ord_)
+    bench.loss_head(oret).backward()
+    for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
+        assert rel_err(ret[k].cpu(), oret[k]) < 2e-5, k
+    exact_beta = OF.beta_gradient_exact_sum(cfg, center.cpu(), ray.cpu(), {k: v.detach() for k, v in osd.items()},
+                                            {k: v.detach() for k, v in ord_.items()},
+                                            lambda out: bench.loss_head({k: v.double() if torch.is_tensor(v) else v for k, v in out.items()}))
+    for pre, st in (("s.", osd), ("r.", ord_)):
+        for k, v in st.items():
+            ref = v.grad if v.grad is not None else torch.zeros_like(v)
+            if pre + k == "s.beta":
+                _beta_ok(got[pre + k], ref, exact_beta)
+                continue
+            assert rel_err(got[pre + k], ref) < 1e-4, pre + k
+    assert torch.as_tensor(got["s.embed_fn.embedder_obj.params"]).abs().max() > 0

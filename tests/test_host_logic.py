@@ -242,3 +242,32 @@ def test_mesh_sweep_lattices_are_the_references():
         assert np.array_equal(pts.numpy(), g[f"{tag}/points"])
         part = plots.lattice_on_device(axes, "cpu", first=1234, count=777)           # chunks of the same lattice
         assert np.array_equal(part.numpy(), g[f"{tag}/points"][1234:1234 + 777])
+
+
+@pytest.mark.parametrize("dataset", ["DTU", "ETH3D", "BlendedMVS", "scannet"])
+def test_level_table_of_every_dataset_preset_matches_the_written_out_values(dataset):
+    """The per-level (scale, resolution, size, offset, hashed) table of the shipped L16 / F2 / T2^19 grid for each of the four
+    dataset presets against LITERAL values (tests/golden/level_tables.json, generated by make_level_tables.py with the
+    reference's per-level scale).  The table is tcnn's, restated (parity unpinned): the file also names the levels whose
+    resolution changes inside the error envelope of a device libm (log2f 1 ulp, exp2f 2 ulp) -- ETH3D 15 (10241 here, 10240
+    possible), BlendedMVS 15, ScanNet 5 / 10 / 15 -- so a cross-check against a real tinycudann build knows where to look."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from ls2fm.options import make_options
+    from ls2fm.models.SDF import SDF
+    ref = json.load(open(os.path.join(GOLDEN, "level_tables.json")))[dataset]
+    sdf = SDF(make_options(dataset, device="cpu"))
+    enc = sdf.embed_fn.embedder_obj
+    d = enc.desc
+    assert d.n_levels == 16 and enc.params.numel() == ref["n_params"]
+    sensitive = [lv["level"] for lv in ref["levels"] if lv["ulp_sensitive"]]
+    for lv in ref["levels"]:
+        l = lv["level"]
+        got = (float(d.scale[l]), int(d.resolution[l]), int(d.size[l]), int(d.offset[l]), bool(d.hashed[l]))
+        want = (lv["scale"], lv["resolution"], lv["size"], lv["offset"], lv["hashed"])
+        assert got == want, (f"{dataset} level {l}: {got} != {want}; levels whose resolution a 1-2 ulp different log2f / exp2f changes "
+                             f"(a real-tcnn table may differ THERE): {sensitive}, candidates {lv['resolutions_within_libm_envelope']}")
+    assert sensitive == {"DTU": [], "ETH3D": [15], "BlendedMVS": [15], "scannet": [5, 10, 15]}[dataset]
+    if dataset == "ETH3D":
+        assert ref["levels"][15]["resolutions_within_libm_envelope"] == [10240, 10241] and int(d.resolution[15]) == 10241

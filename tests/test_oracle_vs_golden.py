@@ -190,3 +190,24 @@ def test_render_full_size_grid_vs_reference_checksums():
                 check_table_digest(got, g, f"table_grad/{pre}", tol=GTOL)
             else:
                 assert rel_err(got, g[f"render_grad/{pre}/{k}"]) < GTOL, (pre, k)
+
+
+@pytest.mark.parametrize("case", ["tracing_eth3d_inside_false", "tracing_scannet_inside_false"])
+def test_sphere_tracing_converging_field_inside_false(case):
+    """the `inside = False` datasets with the cameras inside the surface (tests/golden/make_golden_tracing.py): the root-find
+    converges, the oracle lands on the reference's depths, masks, trip count and gradients"""
+    import json
+    g = load_golden(case)
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    cfg = golden_cfg(meta)
+    sd = golden_state(g, "sdf", requires_grad=True)
+    c = torch.from_numpy(g["center"]).view(1, -1, 3)
+    d = torch.from_numpy(g["ray"]).view(1, -1, 3)
+    d_pred, sdf_last, _, finish, trips = F.sphere_tracing(cfg, c, d, sd, rng=False)
+    assert trips == int(g["trips"])
+    assert rel_err(d_pred, g["d_pred"]) < 1e-5 and np.array_equal(finish.numpy(), g["finish"])
+    assert float((sdf_last.detach() - torch.from_numpy(g["sdf_last"])).abs().max()) < 1e-5
+    losses.tracing_loss(d_pred, sdf_last).backward()
+    for k, v in sd.items():
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert rel_err(got, g[f"grad/sdf/{k}"]) < 5e-5, k
