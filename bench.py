@@ -233,6 +233,10 @@ def main():
         # kernels: scatter the levels in 4 groups and all-reduce a group's table slices while the next ones are scattered
         enable_table_overlap(sdf, rad, n_groups=args.overlap_groups)
 
+    if sharded_opt is None:
+        # the timed loop never changes the tables (no optimizer in the step): a captured step needs no rebuild of the
+        # interleaved table copy inside the graph
+        fused.trust_mirror_in_capture(sdf, rad)
     from ls2fm.losses import RenderLossHead
     from ls2fm.graph import CapturedStep
     # same three terms and weights as loss_head().  N > 1: every rank holds the same number of rays and no masks, so the global
@@ -365,7 +369,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
             doc = json.load(open(pmc))
-            rec = doc.get(roofline["kernel"])
+            if roofline["kernel"].startswith("scatter_pair") and "scatter_fill" in doc and "slab_accumulate" in doc:
+                rec = {k: doc["scatter_fill"][k] + doc["slab_accumulate"][k] for k in ("fetch", "write")}
+            else:
+                rec = doc.get(roofline["kernel"])
             if rec:
                 roofline["traffic"] = rec["fetch"] + rec["write"]
                 roofline["traffic_source"] = (f"quoted from profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

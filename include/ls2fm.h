@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 3
+#define LS2FM_ABI_VERSION 4
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -366,6 +366,18 @@ int ls2fm_adam_step(int32_t n_tensors, float* const* params, const float* const*
 int ls2fm_adam_step_scheduled(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, const int64_t* numel, void* sched_state, float beta1, float beta2,
                               float eps, float weight_decay, void* stream);
+
+/* Either update above with a MIRROR list: mirrors[t] (HOST array of n_tensors device pointers, entries may be NULL; NULL array =
+ * none) is a second destination of tensor t's updated values in the entry-interleaved layout of ls2fm_interleave_tables /
+ * ls2fm_params.dual_table -- element k goes to mirrors[t][(k >> 1) * 4 + (k & 1)], i.e. pass dual_table for the SDF table and
+ * dual_table + 2 for the second field's table (8-byte aligned, even numel).  The render's gather pass reads that copy (one
+ * 16-byte gather per corner serves both grids); writing it here, in the optimizer's one pass over the tables, keeps it current
+ * without a rebuild per step.  sched_state NULL: the unscheduled form (lr and step from the arguments); otherwise the scheduled
+ * form (lr and step ignored).  No reference counterpart: the reference's tcnn grids are separate.
+ */
+int ls2fm_adam_step_mirrored(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numel, float* const* mirrors, void* sched_state, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).

@@ -19,6 +19,10 @@ struct AdamJobs {
     float* m[kAdamMaxTensors];
     float* v[kAdamMaxTensors];
     int64_t n[kAdamMaxTensors];
+    // optional second destination of the updated values: an ENTRY-INTERLEAVED copy of two hash tables ([entry][t0 f0 f1 | t1 f0 f1],
+    // what the render's gather pass reads: one 16-byte gather per corner serves both grids).  mirror[j] = the copy's base + 2 *
+    // slot (this tensor's half of every 16-byte entry) or null; element k of the tensor goes to mirror[(k >> 1) * 4 + (k & 1)]
+    float* mirror[kAdamMaxTensors];
     int first_block[kAdamMaxTensors + 1];
     int count;
 };
@@ -58,6 +62,7 @@ adam_kernel(AdamJobs jobs, AdamHyper h, const AdamSched* __restrict__ sched) {
     const float* __restrict__ g = jobs.g[j];
     float* __restrict__ m = jobs.m[j];
     float* __restrict__ v = jobs.v[j];
+    float* __restrict__ mir = jobs.mirror[j];
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
 #pragma unroll
@@ -70,11 +75,16 @@ adam_kernel(AdamJobs jobs, AdamHyper h, const AdamSched* __restrict__ sched) {
             adam_one(pp.x, gg.x, mm.x, vv.x, h); adam_one(pp.y, gg.y, mm.y, vv.y, h);
             adam_one(pp.z, gg.z, mm.z, vv.z, h); adam_one(pp.w, gg.w, mm.w, vv.w, h);
             *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+            if (mir) {                          // i is a multiple of 4: two whole entries
+                *reinterpret_cast<float2*>(mir + (i >> 1) * 4) = make_float2(pp.x, pp.y);
+                *reinterpret_cast<float2*>(mir + (i >> 1) * 4 + 4) = make_float2(pp.z, pp.w);
+            }
         } else {
             for (int64_t k = i; k < n && k < i + 4; ++k) {
                 float pp = p[k], mm = m[k], vv = v[k];
                 adam_one(pp, g[k], mm, vv, h);
                 p[k] = pp; m[k] = mm; v[k] = vv;
+                if (mir) mir[(k >> 1) * 4 + (k & 1)] = pp;
             }
         }
     }
@@ -83,7 +93,8 @@ adam_kernel(AdamJobs jobs, AdamHyper h, const AdamSched* __restrict__ sched) {
 }  // namespace
 
 static int adam_launch(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                       float* const* exp_avg_sq, const int64_t* numel, AdamHyper h, const AdamSched* sched, hipStream_t stream);
+                       float* const* exp_avg_sq, const int64_t* numel, AdamHyper h, const AdamSched* sched, hipStream_t stream,
+                       float* const* mirrors = nullptr);
 
 extern "C" int ls2fm_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                                float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
@@ -121,8 +132,39 @@ extern "C" int ls2fm_adam_step_scheduled(int32_t n_tensors, float* const* params
     return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, h, (const AdamSched*)sched_state, (hipStream_t)stream);
 }
 
+// The two entry points above with a mirror list: mirrors[t] (HOST array of device pointers, entries may be null) = where tensor
+// t's updated values are ALSO written, entry-interleaved (see AdamJobs::mirror); sched_state null = the unscheduled form (lr,
+// step from the arguments), else the scheduled form (lr, step ignored).
+extern "C" int ls2fm_adam_step_mirrored(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                                        float* const* exp_avg_sq, const int64_t* numel, float* const* mirrors, void* sched_state,
+                                        float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                        void* stream) {
+    LS2FM_CHECK_ARG(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)));
+    LS2FM_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && (sched_state || step >= 1));
+    if (mirrors)
+        for (int32_t t = 0; t < n_tensors; ++t)
+            LS2FM_CHECK_ARG(!mirrors[t] || ((reinterpret_cast<uintptr_t>(mirrors[t]) & 7u) == 0 && numel[t] % 2 == 0));
+    AdamHyper h;
+    h.step_size = 0.f;
+    h.bc2_sqrt = 1.f;
+    if (sched_state) {
+        adam_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>((AdamSched*)sched_state, (double)beta1, (double)beta2);
+    } else {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        h.step_size = (float)((double)lr / bc1);
+        h.bc2_sqrt = (float)sqrt(bc2);
+    }
+    h.w1 = (float)(1.0 - (double)beta1);
+    h.beta2 = beta2;
+    h.one_minus_beta2 = (float)(1.0 - (double)beta2);
+    h.eps = eps;
+    h.weight_decay = weight_decay;
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, h, (const AdamSched*)sched_state, (hipStream_t)stream, mirrors);
+}
+
 static int adam_launch(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                       float* const* exp_avg_sq, const int64_t* numel, AdamHyper h, const AdamSched* sched, hipStream_t stream) {
+                       float* const* exp_avg_sq, const int64_t* numel, AdamHyper h, const AdamSched* sched, hipStream_t stream,
+                       float* const* mirrors) {
     for (int32_t t = 0; t < n_tensors;) {
         AdamJobs jobs;
         jobs.count = 0;
@@ -132,6 +174,7 @@ static int adam_launch(int32_t n_tensors, float* const* params, const float* con
             LS2FM_CHECK_ARG(params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t]);
             const int j = jobs.count++;
             jobs.p[j] = params[t]; jobs.g[j] = grads[t]; jobs.m[j] = exp_avg[t]; jobs.v[j] = exp_avg_sq[t]; jobs.n[j] = numel[t];
+            jobs.mirror[j] = mirrors ? mirrors[t] : nullptr;
             jobs.first_block[j] = blocks;
             blocks += (int)((numel[t] + kAdamTile - 1) / kAdamTile);
         }

@@ -568,7 +568,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const int n_chunks = (int)((w.p + kEncThreads - 1) / kEncThreads);
     const bool interleaved = dual && params->dual_table;
     const bool pair = dual && !interleaved;      // both grids, one launch
-    const int enc_span = pair ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;
+    const int enc_span = dual ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;       // both grids in this launch (two tables or the interleaved copy)
     int most = 0;
     const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, prepare_bwd, &most);
     EncodeExtras ex;

@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -126,6 +126,7 @@ _SIGNATURES = {
                                       _P]),
     "ls2fm_adam_step": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "ls2fm_adam_step_scheduled": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P]),
+    "ls2fm_adam_step_mirrored": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "ls2fm_profile_enable": (c_int32, [c_int32]),
     "ls2fm_profile_reset": (c_int32, []),
     "ls2fm_profile_count": (c_int32, []),

@@ -313,6 +313,7 @@ class ShardedAdam:
                 view.copy_(p.detach())
                 p.data = view                                  # same Parameter object, storage now inside the flat buffer
                 p._ls2fm_flat_total = self.total               # fused.flat_gradient_views pads its buffer to this length
+                p._ls2fm_no_mirror = True                      # rewritten by collectives: no interleaved table copy (ls2fm.fused)
         lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
         self.gshard = torch.zeros(self.shard, device=dev, dtype=torch.float32)
         self._gpack = None

@@ -21,15 +21,36 @@ from ._lib import check, ptr, stream_ptr
 
 _DISABLE = os.environ.get("LS2FM_DISABLE_FUSED", "0") == "1"
 _POISON = os.environ.get("LS2FM_POISON_WS", "0") == "1"
-# dual field, opt-in: keep an entry-interleaved copy of the two hash tables so the forward gathers 16 B once per corner
-# instead of 8 B twice (encodes 161 -> 122 us at the benchmark).  The copy costs ~45 us to rebuild, so it only pays when
-# the tables change less often than they are rendered (evaluation renders, frozen fields); a training loop that steps the
-# tables after every backward is faster without it -- hence "off" by default.  "version": refreshed when either parameter's
-# version counter or storage changed (optimizer steps, load_state_dict, any in-place op on the parameter); "always":
-# refreshed on every forward (for code that writes the tables behind autograd's back, e.g. through `.data`).
-_DUAL_TABLE = os.environ.get("LS2FM_DUAL_TABLE", "off")
+# Dual field: the render gathers from an ENTRY-INTERLEAVED copy of the two hash tables ([entry][sdf f0 f1 | rad f0 f1]): one
+# 16-byte gather per corner serves both grids -- the gather pass is bound by the L2 -> L1 line rate, not by bytes, and this halves
+# its requests.  The two nn.Parameters stay what the reference has (flat fp32 vectors, state_dict keys of SURVEY App. E); the
+# copy is a derived buffer that is kept current in one of two ways:
+#   * `ls2fm.optim.FusedAdam` writes every updated table value into it in its own pass over the tables (the Parameters carry a
+#     `_ls2fm_mirror` record; ls2fm_adam_step_mirrored) -- a training loop pays no rebuild;
+#   * anything else that changes a table (another optimizer, load_state_dict, an in-place op: all bump Tensor._version)
+#     makes the next render rebuild it (ls2fm_interleave_tables, ~45 us).
+# LS2FM_DUAL_TABLE: "version" (default) as above; "always": rebuilt on every forward (for code that writes the tables behind
+# autograd's back, e.g. through `.data`); "off": gather from the two tables (8 bytes twice per corner).
+_DUAL_TABLE = os.environ.get("LS2FM_DUAL_TABLE", "version")
 if _DUAL_TABLE not in ("version", "always", "off"):
     raise RuntimeError(f"LS2FM_DUAL_TABLE={_DUAL_TABLE!r}: expected version, always or off")
+
+
+class TableMirror:
+    """the interleaved copy of one (SDF table, second table) pair and the versions of the two Parameters it reflects"""
+    __slots__ = ("table", "versions", "ptrs", "by_optimizer")
+
+    def __init__(self):
+        self.table, self.versions, self.ptrs, self.by_optimizer = None, [None, None], [None, None], False
+
+    def fresh(self, sdf_table, rad_table) -> bool:
+        return (self.table is not None and self.ptrs == [sdf_table.data_ptr(), rad_table.data_ptr()]
+                and self.versions == [sdf_table._version, rad_table._version])
+
+    def written_by_optimizer(self, slot, p):
+        """FusedAdam just wrote `p`'s updated values into the copy (and bumped p's version)"""
+        self.versions[slot] = p._version
+        self.by_optimizer = True
 
 
 # ------------------------------------------------------------------------------------------------ gating
@@ -255,22 +276,67 @@ _RAD_TABLE_AT = 8        # param_tensors(): sdf table, 2 x (v, g, b), beta, rad 
 
 
 def _refresh_dual_table(lib, plan, sdf_table, rad_table):
-    """(re)build the interleaved copy of the two tables when they changed (see _DUAL_TABLE)"""
-    key = (sdf_table.data_ptr(), rad_table.data_ptr(), sdf_table._version, rad_table._version)
-    capturing = torch.cuda.is_current_stream_capturing()
-    if capturing:
-        key = None          # a captured step cannot re-check versions at replay: the refresh becomes part of the graph
-    elif plan.dual_key == key and _DUAL_TABLE != "always":
+    """make the interleaved copy current (see _DUAL_TABLE) and point the parameter struct at it"""
+    if getattr(sdf_table, "_ls2fm_no_mirror", False) or getattr(rad_table, "_ls2fm_no_mirror", False):
+        plan.pstruct.dual_table = None          # tables rewritten by something that cannot keep a copy current (sharded optimizer)
         return
     if not (sdf_table.dim() == 1 and rad_table.dim() == 1 and sdf_table.numel() == rad_table.numel()):
         raise RuntimeError("ls2fm: dual-field tables of different size")
-    if plan.dual_table is None or plan.dual_table.numel() != 2 * sdf_table.numel() or \
-            plan.dual_table.device != sdf_table.device:
-        plan.dual_table = torch.empty(2 * sdf_table.numel(), device=sdf_table.device, dtype=torch.float32)
-    check(lib.ls2fm_interleave_tables(ptr(sdf_table), ptr(rad_table), sdf_table.numel() // 2, ptr(plan.dual_table),
-                                      stream_ptr()), "ls2fm_interleave_tables")
-    plan.pstruct.dual_table = ptr(plan.dual_table)
-    plan.dual_key = key
+    mir = getattr(sdf_table, "_ls2fm_mirror", None)
+    mir = mir[0] if mir is not None else None
+    if mir is None or getattr(rad_table, "_ls2fm_mirror", (None, 1))[0] is not mir:
+        mir = TableMirror()
+        sdf_table._ls2fm_mirror = (mir, 0)      # (record, which half of every 16-byte entry)
+        rad_table._ls2fm_mirror = (mir, 1)
+    if mir.table is None or mir.table.numel() != 2 * sdf_table.numel() or mir.table.device != sdf_table.device:
+        mir.table = torch.empty(2 * sdf_table.numel(), device=sdf_table.device, dtype=torch.float32)
+        mir.versions = [None, None]
+    capturing = torch.cuda.is_current_stream_capturing()
+    # A captured step cannot re-check versions at replay, so by default the rebuild is recorded into the graph (every replay
+    # then renders the CURRENT tables whoever changed them).  The owner of a captured loop whose only table writer is the
+    # mirrored optimizer INSIDE the captured step -- or that never changes the tables -- says so with trust_mirror_in_capture():
+    # the copy is then current at every replay by construction and the graph holds no rebuild.
+    trusted = getattr(sdf_table, "_ls2fm_mirror_trusted", False) and getattr(rad_table, "_ls2fm_mirror_trusted", False)
+    keep = mir.fresh(sdf_table, rad_table) and _DUAL_TABLE != "always" and (not capturing or trusted)
+    if not keep:
+        check(lib.ls2fm_interleave_tables(ptr(sdf_table), ptr(rad_table), sdf_table.numel() // 2, ptr(mir.table), stream_ptr()),
+              "ls2fm_interleave_tables")
+        mir.ptrs = [sdf_table.data_ptr(), rad_table.data_ptr()]
+        mir.versions = [sdf_table._version, rad_table._version]
+    plan.dual_table = mir.table
+    plan.pstruct.dual_table = ptr(mir.table)
+
+
+def table_params(sdf_field, rad_field):
+    """the two hash-table Parameters of a dual-field pair, or None"""
+    if rad_field is None or not hasattr(rad_field, "embed_fn"):
+        return None
+    return sdf_field.embed_fn.embedder_obj.params, rad_field.embed_fn.embedder_obj.params
+
+
+def trust_mirror_in_capture(sdf_field, rad_field, on=True):
+    """Promise for hipGraph captures of steps over these fields: between replays the hash tables are only ever changed by a
+    FusedAdam update that is part of the captured step itself (or not at all), so the interleaved copy needs no rebuild inside
+    the graph.  After changing the tables by other means (load_state_dict, a restore), call sync_mirror()."""
+    tabs = table_params(sdf_field, rad_field)
+    if tabs is not None:
+        for t in tabs:
+            t._ls2fm_mirror_trusted = bool(on)
+
+
+def sync_mirror(sdf_field, rad_field):
+    """rebuild the interleaved copy of the two tables now (after a table was rewritten behind a captured step's back)"""
+    tabs = table_params(sdf_field, rad_field)
+    if tabs is None or _DUAL_TABLE == "off":
+        return
+    rec = getattr(tabs[0], "_ls2fm_mirror", None)
+    if rec is None or rec[0].table is None or getattr(tabs[1], "_ls2fm_mirror", (None,))[0] is not rec[0]:
+        return
+    mir = rec[0]
+    check(_lib.load().ls2fm_interleave_tables(ptr(tabs[0]), ptr(tabs[1]), tabs[0].numel() // 2, ptr(mir.table), stream_ptr()),
+          "ls2fm_interleave_tables")
+    mir.ptrs = [tabs[0].data_ptr(), tabs[1].data_ptr()]
+    mir.versions = [tabs[0]._version, tabs[1]._version]
 
 
 class FusedLoss:

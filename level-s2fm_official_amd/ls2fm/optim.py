@@ -59,33 +59,43 @@ class FusedAdam(torch.optim.Optimizer):
                     self._sched[gi] = torch.tensor([float(first), float(group["lr"]), self.scheduled_gamma, 0.0], device=dev,
                                                    dtype=torch.float64)
                 for step, items in by_step.items():
-                    n = len(items)
-                    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
-                    numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
-                    _lib.check(lib.ls2fm_adam_step_scheduled(n, ptrs([p for p, _, _ in items]), ptrs([g for _, g, _ in items]),
-                                                             ptrs([s["exp_avg"] for _, _, s in items]),
-                                                             ptrs([s["exp_avg_sq"] for _, _, s in items]), numel,
-                                                             _lib.ptr(self._sched[gi]), float(group["betas"][0]),
-                                                             float(group["betas"][1]), float(group["eps"]),
-                                                             float(group["weight_decay"]), _lib.stream_ptr()),
-                               "ls2fm_adam_step_scheduled")
-                    for p, _, _ in items:
-                        torch.autograd.graph.increment_version(p)
+                    self._launch(lib, items, group, 0, _lib.ptr(self._sched[gi]))
                 group["lr"] = float(group["lr"]) * self.scheduled_gamma        # host mirror of the device schedule
                 continue
             for step, items in by_step.items():
-                n = len(items)
-                ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
-                numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
-                _lib.check(lib.ls2fm_adam_step(n, ptrs([p for p, _, _ in items]), ptrs([g for _, g, _ in items]),
-                                               ptrs([s["exp_avg"] for _, _, s in items]),
-                                               ptrs([s["exp_avg_sq"] for _, _, s in items]), numel, float(group["lr"]),
-                                               float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
-                                               float(group["weight_decay"]), int(step), _lib.stream_ptr()),
-                           "ls2fm_adam_step")
-                for p, _, _ in items:       # the kernel wrote through raw pointers: tell autograd (and every cache keyed
-                    torch.autograd.graph.increment_version(p)       # on Tensor._version, e.g. the interleaved tables)
+                self._launch(lib, items, group, int(step), None)
         return loss
+
+    @staticmethod
+    def _mirror_of(p):
+        """(record, destination pointer) when `p` is a hash table whose entry-interleaved copy the render reads (ls2fm.fused)"""
+        rec = getattr(p, "_ls2fm_mirror", None)
+        if rec is None or rec[0].table is None or rec[0].table.numel() != 2 * p.numel() or rec[0].ptrs[rec[1]] != p.data_ptr():
+            return None, None
+        return rec, rec[0].table.data_ptr() + 8 * rec[1]
+
+    def _launch(self, lib, items, group, step, sched_ptr):
+        """one kernel launch for `items` = [(param, grad, state)]: the scheduled form when sched_ptr is given"""
+        n = len(items)
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+        numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
+        mirrors = [self._mirror_of(p) for p, _, _ in items]
+        args = (n, ptrs([p for p, _, _ in items]), ptrs([g for _, g, _ in items]), ptrs([s["exp_avg"] for _, _, s in items]),
+                ptrs([s["exp_avg_sq"] for _, _, s in items]), numel)
+        hyper = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]))
+        if any(m[0] is not None for m in mirrors):
+            mir = (ctypes.c_void_p * n)(*[m[1] for m in mirrors])
+            _lib.check(lib.ls2fm_adam_step_mirrored(*args, mir, sched_ptr, float(group["lr"]), *hyper, max(int(step), 1),
+                                                    _lib.stream_ptr()), "ls2fm_adam_step_mirrored")
+        elif sched_ptr is not None:
+            _lib.check(lib.ls2fm_adam_step_scheduled(*args, sched_ptr, *hyper, _lib.stream_ptr()), "ls2fm_adam_step_scheduled")
+        else:
+            _lib.check(lib.ls2fm_adam_step(*args, float(group["lr"]), *hyper, int(step), _lib.stream_ptr()), "ls2fm_adam_step")
+        for (p, _, _), (rec, _) in zip(items, mirrors):
+            # the kernel wrote through raw pointers: tell autograd (and every cache keyed on Tensor._version) ...
+            torch.autograd.graph.increment_version(p)
+            if rec is not None:                 # ... and the interleaved copy, which already holds the new values
+                rec[0].written_by_optimizer(rec[1], p)
 
     def replayed(self, n=1):
         """a captured step containing this optimizer's update was replayed n times: advance the host mirrors (state['step'],
@@ -97,6 +107,9 @@ class FusedAdam(torch.optim.Optimizer):
                     # the captured kernel rewrote the parameter through its raw pointer: tell autograd and every cache
                     # keyed on Tensor._version (the interleaved table copy) -- as step() does
                     torch.autograd.graph.increment_version(p)
+                    rec, _ = self._mirror_of(p)
+                    if rec is not None:         # the captured mirrored update rewrote the interleaved copy as well
+                        rec[0].written_by_optimizer(rec[1], p)
             if self.scheduled_gamma is not None:
                 group["lr"] = float(group["lr"]) * self.scheduled_gamma ** n
 

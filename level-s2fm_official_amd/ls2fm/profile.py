@@ -77,8 +77,13 @@ def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float
     avg_us, launches, total_ms = times[name]
     grand = sum(t[2] for t in times.values())
     bound, amount = work.get(name, ("hbm", 0))
-    if name in ("scatter_fill", "slab_accumulate"):       # half of a two-pass transfer: priced against the pair's bytes
+    if name in ("scatter_fill", "slab_accumulate") and "scatter_fill" in times and "slab_accumulate" in times:
+        # one of the two passes of ONE algorithmic transfer (the table-gradient scatter): reported as the pair -- its bytes over
+        # the SUM of the two durations -- never one pass credited with the whole transfer
         bound, amount = work["scatter_pair"]
+        name = "scatter_pair (scatter_fill + slab_accumulate)"
+        avg_us = times["scatter_fill"][0] + times["slab_accumulate"][0]
+        total_ms = times["scatter_fill"][2] + times["slab_accumulate"][2]
     if bound == "hbm":
         achieved, peak, unit = amount / (avg_us * 1e-6) / 1e9, hbm_peak_gbs, "GB/s"
     else:

@@ -171,8 +171,12 @@ class RenderStage:
             # the capture warms the step up by running it for real: parameters, Adam state and the schedule are put back
             # afterwards (in place: the graph holds their addresses), so that this call, too, is exactly one step
             snap = self._snapshot()
+            # the captured step's own Adam keeps the interleaved table copy current (ls2fm.fused): no rebuild inside the graph
+            from . import fused as _fused
+            _fused.trust_mirror_in_capture(self.sdf, self.rad)
             self._graph = CapturedStep(lambda: self._eager(*self._in, static_trips=True), params=self.params)
             self._restore(snap)
+            _fused.sync_mirror(self.sdf, self.rad)          # the restore rewrote the tables behind the graph's back
             out = self._graph.replay()
             self.optim.replayed(1)
             return out

@@ -305,3 +305,57 @@ def test_interleaved_dual_table_is_bit_identical_and_tracks_updates(monkeypatch)
     back = run("version")
     same(back, run("off"))
     assert not torch.equal(moved[0]["rgb"], back[0]["rgb"])
+
+
+def test_fused_adam_keeps_the_interleaved_copy_current_without_rebuilds():
+    """dual field, default mode: the render reads the entry-interleaved copy of the two tables; FusedAdam (plain and scheduled)
+    writes the updated table values into that copy in its own pass (ls2fm_adam_step_mirrored), so a training loop triggers NO
+    rebuild (ls2fm_interleave_tables) after the first render -- and the copy equals the interleave of the Parameters bit for
+    bit after every step; a foreign writer (torch's Adam) makes the next render rebuild it."""
+    from ls2fm.optim import FusedAdam
+    assert fused._DUAL_TABLE == "version"
+    opt = make_options("ETH3D", device=DEV, dual_field=True, sample_intvs=32,
+                       hash_encoding=dict(n_levels=8, n_features_per_level=2, log2_hashmap_size=14, base_resolution=16))
+    sdf, rad, ren = _randomized(opt, 71)
+    center, ray = _rays(64, 5.0, 72)
+    tgt, nm = torch.rand(1, 64, 3, device=DEV), torch.tensor([0.1, 0.3, -0.2], device=DEV)
+    t1, t2 = sdf.embed_fn.embedder_obj.params, rad.embed_fn.embedder_obj.params
+    lib = fused._lib.load()
+    calls = {"n": 0}
+    real = lib.ls2fm_interleave_tables
+
+    class Counting:
+        def __getattr__(self, k):
+            return getattr(lib, k)
+
+        def ls2fm_interleave_tables(self, *a):
+            calls["n"] += 1
+            return real(*a)
+
+    def interleaved():
+        return torch.stack([t1.detach().view(-1, 2), t2.detach().view(-1, 2)], dim=1).reshape(-1)
+
+    def step(optim):
+        for p in params:
+            p.grad = None
+        losses.render_loss(ren.forward(opt, center, ray, sdf, rad), tgt, nm).backward()
+        optim.step()
+
+    params = [p for m in (sdf, rad) for p in m.parameters()]
+    import unittest.mock as mock
+    with mock.patch.object(fused._lib, "load", lambda: Counting()):
+        for kw in (dict(), dict(scheduled_gamma=0.9)):
+            optim = FusedAdam([dict(params=list(sdf.parameters()), lr=1e-2), dict(params=list(rad.parameters()), lr=3e-3)], **kw)
+            step(optim)
+            before = calls["n"]
+            for _ in range(3):
+                step(optim)
+                mir = t1._ls2fm_mirror[0]
+                assert mir is t2._ls2fm_mirror[0] and mir.fresh(t1, t2)
+                assert torch.equal(mir.table, interleaved())
+            assert calls["n"] == before, "a FusedAdam loop must not rebuild the interleaved copy"
+        torch.optim.Adam(params, lr=1e-2).step()                # a writer that knows nothing of the copy
+        assert not t1._ls2fm_mirror[0].fresh(t1, t2)
+        before = calls["n"]
+        ren.forward(opt, center, ray, sdf, rad)
+        assert calls["n"] == before + 1 and torch.equal(t1._ls2fm_mirror[0].table, interleaved())
