@@ -379,6 +379,19 @@ int ls2fm_adam_step_mirrored(int32_t n_tensors, float* const* params, const floa
                              float* const* exp_avg_sq, const int64_t* numel, float* const* mirrors, void* sched_state, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
 
+/* The general form (the three above are special cases of it): every parameter GROUP of an optimizer in one call.  Per tensor t a
+ * learning rate lrs[t] (HOST float array; with `step`, the unscheduled form) or a device-resident schedule sched_states[t] (HOST
+ * array of DEVICE pointers, entries or the whole array may be NULL; every distinct schedule is advanced once per call);
+ * mirrors as above or NULL.  Two tensors whose mirrors are the two halves of one interleaved copy (M and M + 2, equal length,
+ * 16-byte aligned) -- the SDF table and the second field's table -- are updated by ONE job that also writes the copy as whole
+ * 16-byte entries (full cache lines; two separate jobs would each write 8 bytes of every 16).  Replaces torch.optim.Adam.step()
+ * over `[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(), lr_color}]` (BA.py:79-83) + ExponentialLR.step().
+ */
+int ls2fm_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, float* const* mirrors, const float* lrs,
+                          void* const* sched_states, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                          void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the

@@ -35,8 +35,10 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        calls = {}                  # (betas, eps, weight_decay, step or None) -> [(param, grad, state, lr, schedule tensor or None)]
         for gi, group in enumerate(self.param_groups):
-            by_step = {}
+            steps = set()
+            items = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -49,21 +51,43 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = int(st["step"]) + 1
-                by_step.setdefault(st["step"], []).append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st))
+                steps.add(st["step"])
+                items.append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st))
+            sched = None
             if self.scheduled_gamma is not None:
-                if len(by_step) > 1:
+                if len(steps) > 1:
                     raise RuntimeError("ls2fm.optim.FusedAdam(scheduled_gamma=...): the parameters of a group must step together")
                 if gi not in self._sched:
-                    first = next(iter(by_step)) - 1 if by_step else 0
+                    first = next(iter(steps)) - 1 if steps else 0
                     dev = group["params"][0].device
                     self._sched[gi] = torch.tensor([float(first), float(group["lr"]), self.scheduled_gamma, 0.0], device=dev,
                                                    dtype=torch.float64)
-                for step, items in by_step.items():
-                    self._launch(lib, items, group, 0, _lib.ptr(self._sched[gi]))
+                sched = self._sched[gi]
+            for p, g, st in items:
+                key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]),
+                       None if sched is not None else int(st["step"]))
+                calls.setdefault(key, []).append((p, g, st, float(group["lr"]), sched))
+            if sched is not None and items:
                 group["lr"] = float(group["lr"]) * self.scheduled_gamma        # host mirror of the device schedule
-                continue
-            for step, items in by_step.items():
-                self._launch(lib, items, group, int(step), None)
+        # ONE launch per distinct (betas, eps, weight decay[, step]) -- normally one for the whole optimizer, whatever the number
+        # of parameter groups: per-tensor learning rates / schedules ride in the call (ls2fm_adam_step_multi)
+        for (b1, b2, eps, wd, step), items in calls.items():
+            n = len(items)
+            ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+            mirrors = [self._mirror_of(p) for p, _, _, _, _ in items]
+            any_mirror = any(m[0] is not None for m in mirrors)
+            _lib.check(lib.ls2fm_adam_step_multi(
+                n, ptrs([it[0] for it in items]), ptrs([it[1] for it in items]), ptrs([it[2]["exp_avg"] for it in items]),
+                ptrs([it[2]["exp_avg_sq"] for it in items]), (ctypes.c_int64 * n)(*[it[0].numel() for it in items]),
+                (ctypes.c_void_p * n)(*[m[1] for m in mirrors]) if any_mirror else None,
+                (ctypes.c_float * n)(*[it[3] for it in items]),
+                (ctypes.c_void_p * n)(*[None if it[4] is None else it[4].data_ptr() for it in items]) if step is None else None,
+                b1, b2, eps, wd, 0 if step is None else step, _lib.stream_ptr()), "ls2fm_adam_step_multi")
+            for (p, _, _, _, _), (rec, _) in zip(items, mirrors):
+                # the kernel wrote through raw pointers: tell autograd (and every cache keyed on Tensor._version) ...
+                torch.autograd.graph.increment_version(p)
+                if rec is not None:             # ... and the interleaved table copy, which already holds the new values
+                    rec[0].written_by_optimizer(rec[1], p)
         return loss
 
     @staticmethod
@@ -73,29 +97,6 @@ class FusedAdam(torch.optim.Optimizer):
         if rec is None or rec[0].table is None or rec[0].table.numel() != 2 * p.numel() or rec[0].ptrs[rec[1]] != p.data_ptr():
             return None, None
         return rec, rec[0].table.data_ptr() + 8 * rec[1]
-
-    def _launch(self, lib, items, group, step, sched_ptr):
-        """one kernel launch for `items` = [(param, grad, state)]: the scheduled form when sched_ptr is given"""
-        n = len(items)
-        ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
-        numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
-        mirrors = [self._mirror_of(p) for p, _, _ in items]
-        args = (n, ptrs([p for p, _, _ in items]), ptrs([g for _, g, _ in items]), ptrs([s["exp_avg"] for _, _, s in items]),
-                ptrs([s["exp_avg_sq"] for _, _, s in items]), numel)
-        hyper = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]))
-        if any(m[0] is not None for m in mirrors):
-            mir = (ctypes.c_void_p * n)(*[m[1] for m in mirrors])
-            _lib.check(lib.ls2fm_adam_step_mirrored(*args, mir, sched_ptr, float(group["lr"]), *hyper, max(int(step), 1),
-                                                    _lib.stream_ptr()), "ls2fm_adam_step_mirrored")
-        elif sched_ptr is not None:
-            _lib.check(lib.ls2fm_adam_step_scheduled(*args, sched_ptr, *hyper, _lib.stream_ptr()), "ls2fm_adam_step_scheduled")
-        else:
-            _lib.check(lib.ls2fm_adam_step(*args, float(group["lr"]), *hyper, int(step), _lib.stream_ptr()), "ls2fm_adam_step")
-        for (p, _, _), (rec, _) in zip(items, mirrors):
-            # the kernel wrote through raw pointers: tell autograd (and every cache keyed on Tensor._version) ...
-            torch.autograd.graph.increment_version(p)
-            if rec is not None:                 # ... and the interleaved copy, which already holds the new values
-                rec[0].written_by_optimizer(rec[1], p)
 
     def replayed(self, n=1):
         """a captured step containing this optimizer's update was replayed n times: advance the host mirrors (state['step'],
