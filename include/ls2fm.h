@@ -242,6 +242,26 @@ typedef struct ls2fm_loss_spec {
     float* d_depth_ref;           /* backward output: [n_rays] gradient w.r.t. depth_ref (overwritten), or NULL */
 } ls2fm_loss_spec;
 
+/* The backward of the sphere tracing that produced a render's depth_ref (ls2fm_trace_depth_bwd + ls2fm_sdf_points_bwd over
+ * the track points), run BY ls2fm_render_bwd on an internal stream of its own, forked behind its first kernel (which writes
+ * d_depth_ref) and joined at its end: the ~0.18 ms chain runs beside the render's table scatter and weight-gradient chain
+ * instead of behind them, inside one call (and one hipGraph branch).  Afterwards sum_into[0 .. sum_count) += sum_from[0 ..
+ * sum_count): the tracing's gradients of the SDF field's tensors, which live in the same flat layout, added into the render's --
+ * one gradient producer per parameter.  Replaces what autograd does for Camera.py:506-523's d_consistent term through
+ * SDF.sphere_tracing's differentiable tail (SDF.py:201-214): a second backward chain and seven accumulation kernels. */
+typedef struct ls2fm_depth_backward {
+    const float* points;          /* [n_rays * k_max, 3] the tracing's track points (ls2fm_sphere_trace) */
+    const int32_t* trips;         /* DEVICE int32[1] */
+    const uint8_t* gate;          /* [n_rays] from ls2fm_trace_depth_fwd */
+    int32_t k_max;
+    float* d_sdf;                 /* scratch [n_rays * k_max] */
+    const struct ls2fm_param_grads* grads;  /* the tracing's own gradient tensors (SDF table + SDF MLP; overwritten) */
+    void* workspace;              /* ls2fm_sdf_points_workspace_bytes(field, grid, n_rays * k_max) bytes */
+    float* sum_into;              /* or NULL: no sum */
+    const float* sum_from;
+    int64_t sum_count;
+} ls2fm_depth_backward;
+
 #define LS2FM_MAX_LEVEL_GROUPS 4
 typedef struct ls2fm_render_opts {
     int32_t inference_only;
@@ -252,6 +272,18 @@ typedef struct ls2fm_render_opts {
      * 0 / 1: one pass, no events. */
     int32_t n_level_groups;
     void* group_events[LS2FM_MAX_LEVEL_GROUPS];
+    /* forward with a loss head: hipEvent_t (or NULL) after which the loss spec's device inputs -- depth_ref and the masks, the
+     * outputs of the sphere tracing of the same rays -- are final.  The forward waits for it on `stream` only in front of the
+     * kernel that reads them, i.e. AFTER its gather pass: a caller that traces on another stream overlaps the tracing (latency
+     * bound, few workgroups) with the gather pass (L2 bound) instead of running it in front of the render. */
+    void* loss_inputs_ready;
+    /* backward with a loss head: hipEvent_t (or NULL) RECORDED on `stream` as soon as the backward's first kernel is enqueued --
+     * from then on d_depth_ref (the gradient w.r.t. the traced depth) is final in stream order.  A caller whose depth came from a
+     * differentiable sphere tracing starts that tracing's own backward on another stream behind this event, i.e. beside the
+     * table scatter and the weight-gradient chain of this call instead of behind them. */
+    void* depth_grad_ready;
+    /* backward with a loss head whose d_depth_ref is set: also run the tracing's backward (see ls2fm_depth_backward), or NULL */
+    const ls2fm_depth_backward* depth_bwd;
 } ls2fm_render_opts;
 
 int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
@@ -289,6 +321,17 @@ int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* gri
                        const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
                        int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
                        void* workspace, void* stream);
+
+/* The two halves of ls2fm_sphere_trace for a caller that overlaps the tracing with other work: ls2fm_sdf_prepare packs the SDF
+ * MLP's weights into `workspace` (weight-norm -> effective weights; one latency-bound workgroup, ~15 us) and zeroes *zero_word
+ * (the tracing's `trips`; may be NULL); ls2fm_sphere_trace_prepared is ls2fm_sphere_trace without those two steps -- on any
+ * stream ordered behind the prepare.  ls2fm.stage prepares on the step's stream and traces on another one beside the render's
+ * gather pass (a one-workgroup prepare launched BESIDE that pass is starved: 15 -> 90 us, measured). */
+int ls2fm_sdf_prepare(const ls2fm_grid_desc* grid, const ls2fm_params* params, void* workspace, int32_t* zero_word, void* stream);
+int ls2fm_sphere_trace_prepared(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
+                                int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
+                                void* workspace, void* stream);
 
 /* ls2fm_sdf_eval (sdf only) with the packed weights a preceding ls2fm_sdf_eval / ls2fm_sphere_trace call left in `workspace`
  * (same stream, same parameters): no weight preparation launch.  Used between a tracing call and the evaluation of its track. */

@@ -59,6 +59,16 @@ wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_
     }
 }
 
+__global__ void __launch_bounds__(256)
+add_into_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = dst[i];
+        const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+}
+
 }  // namespace
 
 // weight-norm backward of the SDF MLP alone (point queries, points.hip): tasks 0 and 1 of finalize_kernel
@@ -119,6 +129,35 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,
                            dual ? grads->rad_table : nullptr, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
+    if (opts && opts->depth_grad_ready && hipEventRecord((hipEvent_t)opts->depth_grad_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    // the tracing's own backward (ls2fm_depth_backward): a second internal branch, forked here -- d_depth_ref is final -- and
+    // joined in front of the final sum
+    const ls2fm_depth_backward* db = (opts && loss && loss->d_depth_ref) ? opts->depth_bwd : nullptr;
+    SideCtx sc2;
+    bool forked2 = false;
+    if (db) {
+        LS2FM_CHECK_ARG(db->points && db->trips && db->gate && db->d_sdf && db->grads && db->workspace && db->k_max >= 1);
+        LS2FM_CHECK_ARG(!db->sum_into || (db->sum_from && db->sum_count % 4 == 0 &&
+                                          ((reinterpret_cast<uintptr_t>(db->sum_into) | reinterpret_cast<uintptr_t>(db->sum_from)) & 15u) == 0));
+        SideCtx sc1;
+        // (a stream of its own: the side stream of THIS call's side stream)
+        forked2 = ls2fm_side_stream(&sc1, s) && ls2fm_side_stream(&sc2, sc1.side) && hipEventRecord(sc2.fork, s) == hipSuccess &&
+                  hipStreamWaitEvent(sc2.side, sc2.fork, 0) == hipSuccess;
+        hipStream_t ds = forked2 ? sc2.side : s;
+        int st = ls2fm_trace_depth_bwd(loss->d_depth_ref, nullptr, db->trips, db->gate, n_rays, db->k_max, db->d_sdf, ds);
+        if (st == LS2FM_OK)
+            st = ls2fm_sdf_points_bwd(field, sdf_grid, params, db->points, n_rays * (int64_t)db->k_max, db->d_sdf, nullptr, nullptr,
+                                      db->grads, nullptr, db->workspace, ds);
+        if (forked2 && hipEventRecord(sc2.join, sc2.side) != hipSuccess && st == LS2FM_OK) st = LS2FM_ERR_LAUNCH;
+        if (st != LS2FM_OK) {
+            if (forked2) (void)hipStreamWaitEvent(s, sc2.join, 0);
+            return st;
+        }
+    }
+    auto fail = [&](bool f1, const SideCtx& c1, int st) {       // error after the forks: every branch is joined back into `s`
+        if (forked2) (void)hipStreamWaitEvent(s, sc2.join, 0);
+        return ls2fm_join_on_error(f1, c1, s, st);
+    };
     if (want_pose) {
         ls2fm_prof_begin(LS2FM_PROF_POSE, s);
         ls2fm_launch_pose_grad(fc, sdf_grid, rad_grid, dual, w, pk, params, center, ray, n_rays, ws, d_center, d_ray, s);
@@ -139,7 +178,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
                                                                  reinterpret_cast<int*>(ws + w.wg + WgLayout::total));
     }
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
-    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
+    if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return fail(forked, sc, LS2FM_ERR_LAUNCH);
 
     // hash-table gradients: payloads sorted by slab (scatter_fill), then one streaming pass per LDS-owned slab
     // (slab_accumulate; bin_scatter.hip); tables overwritten in full; dual field: both grids share geometry, hence items.
@@ -156,16 +195,22 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
             int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
                                                ws + w.rpt, ws + w.smax, n_rays, dual, s, lo, hi);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
-            if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+            if (st != LS2FM_OK) return fail(forked, sc, st);
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
             st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s, lo, hi);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
-            if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
+            if (st != LS2FM_OK) return fail(forked, sc, st);
             if (opts && opts->n_level_groups > 1 && opts->group_events[gi] &&
                 hipEventRecord((hipEvent_t)opts->group_events[gi], s) != hipSuccess)
-                return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
+                return fail(forked, sc, LS2FM_ERR_LAUNCH);
         }
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
+    if (db) {
+        if (forked2 && hipStreamWaitEvent(s, sc2.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;
+        if (db->sum_into && db->sum_count > 0)
+            add_into_kernel<<<1024, 256, 0, s>>>(reinterpret_cast<float4*>(db->sum_into), reinterpret_cast<const float4*>(db->sum_from),
+                                                db->sum_count / 4);
+    }
     return ls2fm_launch_status();
 }

@@ -430,19 +430,53 @@ extern "C" int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_
     return ls2fm_launch_status();
 }
 
+namespace {
+__global__ void zero_word_kernel(int32_t* w) { *w = 0; }
+}
+
+extern "C" int ls2fm_sdf_prepare(const ls2fm_grid_desc* grid, const ls2fm_params* params, void* workspace, int32_t* zero_word,
+                                 void* stream) {
+    LS2FM_CHECK_ARG(grid_desc_ok(grid) && params && params->sdf_mlp[0].weight_v && params->sdf_mlp[1].weight_v);
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (zero_word) zero_word_kernel<<<1, 1, 0, s>>>(zero_word);
+    return ls2fm_launch_prep_sdf(params, grid->n_levels, (Packed*)workspace, s);
+}
+
+static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                             const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold, int32_t iters_max,
+                             float* near, float* far, float* track, float* t_end, int32_t* trips, void* workspace, void* stream,
+                             bool prepared);
+
 extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                                   const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
                                   int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
                                   void* workspace, void* stream) {
+    return sphere_trace_impl(field, grid, params, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far, track, t_end, trips,
+                             workspace, stream, false);
+}
+
+extern "C" int ls2fm_sphere_trace_prepared(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                           const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
+                                           int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
+                                           void* workspace, void* stream) {
+    return sphere_trace_impl(field, grid, params, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far, track, t_end, trips,
+                             workspace, stream, true);
+}
+
+static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                             const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold, int32_t iters_max,
+                             float* near, float* far, float* track, float* t_end, int32_t* trips, void* workspace, void* stream,
+                             bool prepared) {
     LS2FM_CHECK_ARG(field_ok(field, grid, params) && n_rays >= 0 && iters_max >= 0);
     LS2FM_CHECK_ARG(trips);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(trips, 0, sizeof(int32_t), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    if (!prepared && hipMemsetAsync(trips, 0, sizeof(int32_t), s) != hipSuccess) return LS2FM_ERR_LAUNCH;
     if (n_rays == 0) return LS2FM_OK;
     LS2FM_CHECK_ARG(ray0 && ray_dir && near && far && track && t_end);
     if (!workspace) return LS2FM_ERR_WORKSPACE;
     Packed* pk = (Packed*)workspace;
-    int st = ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
+    int st = prepared ? LS2FM_OK : ls2fm_launch_prep_sdf(params, grid->n_levels, pk, s);
     if (st != LS2FM_OK) return st;
     // latency-bound at stage-loop sizes (wide: 16 lanes per ray end; 8192 rays 0.26 ms per call against 0.52, 1024 rays 0.13
     // against 0.53), throughput-bound at tens of thousands of rays (one lane per ray end: no redundant lanes).  Both kernels

@@ -27,6 +27,18 @@ bool ls2fm_side_stream(SideCtx* out, hipStream_t caller) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(g_mu);
+    // depth of the fork tree: main -> side -> side-of-side and no further (a call running on a side-of-side stream launches
+    // serially) -- deeper trees inside a stream capture take hipStreamEndCapture down on ROCm 7.2
+    static const int max_depth = [] { const char* e = getenv("LS2FM_FORK_DEPTH"); return e ? atoi(e) : 2; }();
+    int depth = 0;
+    for (hipStream_t c = caller; depth <= max_depth;) {
+        bool is_side = false;
+        for (const auto& kv : g_ctx)
+            if (kv.first.first == dev && kv.second.side == c) { c = kv.first.second; is_side = true; break; }
+        if (!is_side) break;
+        ++depth;
+    }
+    if (depth >= max_depth) return false;
     auto it = g_ctx.find({dev, caller});
     if (it == g_ctx.end()) {
         if (g_ctx.size() >= kMaxContexts) return false;

@@ -84,9 +84,14 @@ class LossSpec(Structure):
                 ("d_terms", c_void_p), ("d_total", c_void_p), ("d_depth_ref", c_void_p)]
 
 
+class DepthBackward(Structure):
+    _fields_ = [("points", c_void_p), ("trips", c_void_p), ("gate", c_void_p), ("k_max", c_int32), ("d_sdf", c_void_p),
+                ("grads", c_void_p), ("workspace", c_void_p), ("sum_into", c_void_p), ("sum_from", c_void_p), ("sum_count", c_int64)]
+
+
 class RenderOpts(Structure):
     _fields_ = [("inference_only", c_int32), ("loss", POINTER(LossSpec)), ("n_level_groups", c_int32),
-                ("group_events", c_void_p * 4)]
+                ("group_events", c_void_p * 4), ("loss_inputs_ready", c_void_p), ("depth_grad_ready", c_void_p), ("depth_bwd", POINTER(DepthBackward))]
 
 
 _P = c_void_p
@@ -116,6 +121,9 @@ _SIGNATURES = {
     "ls2fm_loss_terms_from_sums": (c_int32, [_P, _P, _P, _P]),
     "ls2fm_sphere_trace": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
                                      c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ls2fm_sphere_trace_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
+                                              c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ls2fm_sdf_prepare": (c_int32, [POINTER(GridDesc), POINTER(Params), _P, _P, _P]),
     "ls2fm_sdf_eval_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P]),
     "ls2fm_trace_depth_fwd": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_float, _P, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                         _P]),

@@ -247,7 +247,7 @@ def _params_struct(ts, dual, beta_speed, with_rad=True, cls=_lib.Params):
 
 
 # ------------------------------------------------------------------------------------------------ render
-def flat_gradient_views(ps):
+def flat_gradient_views(ps, attach=True):
     """One flat fp32 buffer holding a gradient for each tensor of `ps`, every segment starting on a 16-byte boundary
     (the table scatter stores float4: csrc/bin_scatter.hip) -> (flat, [views shaped like ps]).  A multi-GPU run
     all-reduces `flat` as a single message without packing kernels: each tensor of `ps` gets the buffer attached as
@@ -263,8 +263,9 @@ def flat_gradient_views(ps):
     if total > at:
         flat[at:].zero_()
     views = [flat[o:o + p.numel()] if p.dim() == 1 else flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, ps)]
-    for p in ps:
-        p._ls2fm_grad_flat = flat
+    if attach:
+        for p in ps:
+            p._ls2fm_grad_flat = flat
     return flat, views
 
 
@@ -341,13 +342,16 @@ def sync_mirror(sdf_field, rad_field):
 
 class FusedLoss:
     """What the fused loss head of one render needs (ls2fm_loss_spec): built by ls2fm.losses.RenderLossHead.spec()."""
-    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts", "psnr")
+    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts", "psnr", "ready", "depth_node")
 
     def __init__(self, weights, rgb_gt, mask_eik=None, mask_dc=None, mask_mse=None, global_counts="allreduce"):
         self.weights, self.rgb_gt = weights, rgb_gt
         self.mask_eik, self.mask_dc, self.mask_mse = mask_eik, mask_dc, mask_mse
         self.global_counts = global_counts
         self.psnr = None                        # set by the render: terms[6] = -10 log10(mse)
+        self.ready = None                       # torch.cuda.Event: masks / traced depth final (produced on another stream)
+        self.depth_node = None                  # TracedDepthNode whose d_pred is this render's depth_ref: its backward is run BY
+                                                # the render's backward, on another stream, beside the scatter (see _Render.backward)
 
 
 def _loss_struct(fl, depth_ref, terms, sums, d_terms=None, d_total=None, d_depth_ref=None):
@@ -414,6 +418,8 @@ class _Render(torch.autograd.Function):
             sums = torch.empty(8, device=dev, dtype=torch.float64)
             lspec = _loss_struct(fl, dref, terms, sums)
             opts.loss = ctypes.pointer(lspec)
+            if fl.ready is not None:
+                opts.loss_inputs_ready = fl.ready.cuda_event
         check(lib.ls2fm_render_fwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), n_rays, ptr(rgb), ptr(sdfs), ptr(normals),
                                    ptr(depth), ptr(nmlp), ptr(ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_fwd")
@@ -472,15 +478,26 @@ class _Render(torch.autograd.Function):
             for gi, ev in enumerate(events):
                 opts.group_events[gi] = ev.cuda_event
             opts.n_level_groups = n_groups
+        node = fl.depth_node if fl is not None else None
+        keep = None
         if fl is not None and (d_terms is not None or d_total is not None):
-            if dref is not None and ctx.needs_input_grad[2]:
+            if dref is not None and (ctx.needs_input_grad[2] or node is not None):
                 d_dref = torch.empty_like(dref)
+            if node is not None and d_dref is not None:
+                # the traced depth's own backward (20 k track points through the point-query machinery: ~0.18 ms) runs INSIDE this
+                # call, on an internal branch beside the scatter and the weight-gradient chain (ls2fm_depth_backward); its
+                # gradients -- the SDF field's first seven tensors, same flat layout -- are added into this node's buffer at the
+                # end: autograd sees ONE producer per parameter and launches no accumulation kernels of its own
+                keep = node.prepare(flat)
+                opts.depth_bwd = ctypes.pointer(keep[0])
             lspec = _loss_struct(fl, dref, None, sums, d_terms, d_total, d_dref)
             opts.loss = ctypes.pointer(lspec)
         check(lib.ls2fm_render_bwd(ctypes.byref(fdesc), ctypes.byref(g1), ctypes.byref(g2) if dual else None,
                                    ctypes.byref(pstruct), ptr(c), ptr(d), ctx.n_rays, ptr(d_rgb), ptr(d_sdfs),
                                    ptr(d_normals), ptr(d_depth), ptr(d_nmlp), ctypes.byref(gstruct), ptr(d_center), ptr(d_ray),
                                    ptr(ctx.ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_bwd")
+        if keep is not None:
+            d_dref = None                              # consumed inside the call: the tracing node gets no gradient through autograd
         if events:
             tables = [grads[0]] + ([grads[_RAD_TABLE_AT]] if dual else [])
             _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels)
@@ -498,6 +515,12 @@ def render(renderer, opt, center, ray, sdf_field, rad_field, loss=None, d_points
     pl = plan if plan is not None else _plan(renderer, opt, sdf_field, rad_field)
     want_bwd = torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad or any(p.requires_grad for p in pl.ts)
                                             or (d_points is not None and d_points.requires_grad))
+    if loss is not None and loss.depth_node is not None and d_points is not None:
+        # the render's backward runs the tracing node's backward itself (beside its scatter): no autograd edge to d_points
+        if not (loss.depth_node.matches(pl.ts) and d_points.requires_grad):
+            loss.depth_node = None
+        else:
+            d_points = d_points.detach()
     out = _Render.apply(center, ray, d_points if loss is not None else None, pl.cfg, loss, want_bwd, *pl.ts)
     ret = {"rgb": out[0], "sdfs_volume": out[1], "normals": out[2], "depth_mlp": out[3], "normal_mlp": out[4]}
     if loss is not None:
@@ -620,7 +643,20 @@ class _TracedDepth(torch.autograd.Function):
     -> d_pred [R], sdf_last [R] (differentiable), finish, mask_bg, mask_dc (uint8 [R])"""
 
     @staticmethod
-    def forward(ctx, track, trips, near, far, rgb_gt, finish_thr, sdf_field, trace_ws, *params):
+    def forward(ctx, track, trips, near, far, rgb_gt, finish_thr, sdf_field, trace_ws, launch_stream, *params):
+        if launch_stream is not None:          # kernels on that stream (the caller orders it against the current one)
+            with torch.cuda.stream(launch_stream):
+                outs = _TracedDepth._forward(ctx, track, trips, near, far, rgb_gt, finish_thr, sdf_field, trace_ws, *params)
+            if not torch.cuda.is_current_stream_capturing():
+                cur = torch.cuda.current_stream(track.device)
+                for t in list(outs) + list(ctx.side_allocated):
+                    t.record_stream(cur)       # allocated on the launch stream, used (and freed) on the current one
+            ctx.side_allocated = None
+            return outs
+        return _TracedDepth._forward(ctx, track, trips, near, far, rgb_gt, finish_thr, sdf_field, trace_ws, *params)
+
+    @staticmethod
+    def _forward(ctx, track, trips, near, far, rgb_gt, finish_thr, sdf_field, trace_ws, *params):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         n_rays, k_max = track.shape[0], track.shape[1]
@@ -654,7 +690,9 @@ class _TracedDepth(torch.autograd.Function):
                                         0.95, ptr(d_pred), ptr(last), ptr(finish), ptr(mask_bg), ptr(mask_dc), ptr(gate),
                                         stream_ptr()), "ls2fm_trace_depth_fwd")
         ctx.meta = (fdesc, gdesc, float(sdf_field.beta_speed), n_rays, k_max)
+        ctx.side_allocated = [p, gate, sdf]
         ctx.save_for_backward(p, trips, gate, *params)
+        sdf_field.last_trace_node = TracedDepthNode(ctx.meta, p, trips, gate, params)
         outs = (d_pred, last, finish, mask_bg if mask_bg is not None else finish, mask_dc if mask_dc is not None else finish)
         ctx.mark_non_differentiable(*outs[2:])
         return outs
@@ -662,32 +700,72 @@ class _TracedDepth(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_dpred, d_last, *_):
-        lib = _lib.load()
-        fdesc, gdesc, beta_speed, n_rays, k_max = ctx.meta
         p, trips, gate, *ps = ctx.saved_tensors
-        n_in = 8
+        n_in = 9
         if d_dpred is None and d_last is None:
             return (None,) * (n_in + len(ps))
-        d_dpred = None if d_dpred is None else d_dpred.reshape(-1).float().contiguous()
-        d_last = None if d_last is None else d_last.reshape(-1).float().contiguous()
-        d_sdf = torch.empty(n_rays * k_max, device=p.device)
-        check(lib.ls2fm_trace_depth_bwd(ptr(d_dpred), ptr(d_last), ptr(trips), ptr(gate), n_rays, k_max, ptr(d_sdf), stream_ptr()),
-              "ls2fm_trace_depth_bwd")
-        flat, grads = flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
-        gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
-        pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
-        n = n_rays * k_max
-        ws_bytes = lib.ls2fm_sdf_points_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(gdesc), n)
-        if ws_bytes < 0:
-            check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
-        ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
-        check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
-                                       None, None, ctypes.byref(gstruct), None, ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
+        _, grads = _traced_depth_backward(ctx.meta, p, trips, gate, ps, d_dpred, d_last, attach=True)
         grads[7] = None                                # beta does not enter a point query
         return (None,) * n_in + tuple(grads)
 
 
-def traced_depth(sdf_field, track, trips, near, far, rgbs_gt=None, trace_ws=None):
+def _traced_depth_backward(meta, p, trips, gate, ps, d_dpred, d_last, attach):
+    """upstream of the traced depth / last SDF value -> the SDF field's parameter gradients, through the point-query backward
+    -> (flat buffer, views).  attach: register the buffer with the Parameters (the node is an autograd producer of its own)"""
+    lib = _lib.load()
+    fdesc, gdesc, beta_speed, n_rays, k_max = meta
+    d_dpred = None if d_dpred is None else d_dpred.reshape(-1).float().contiguous()
+    d_last = None if d_last is None else d_last.reshape(-1).float().contiguous()
+    d_sdf = torch.empty(n_rays * k_max, device=p.device)
+    check(lib.ls2fm_trace_depth_bwd(ptr(d_dpred), ptr(d_last), ptr(trips), ptr(gate), n_rays, k_max, ptr(d_sdf), stream_ptr()),
+          "ls2fm_trace_depth_bwd")
+    flat, grads = flat_gradient_views(ps, attach=attach)          # table, (v, g, b) x 2, beta
+    gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
+    pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
+    n = n_rays * k_max
+    ws_bytes = lib.ls2fm_sdf_points_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(gdesc), n)
+    if ws_bytes < 0:
+        check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
+    ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
+    check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
+                                   None, None, ctypes.byref(gstruct), None, ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
+    return flat, list(grads)
+
+
+class TracedDepthNode:
+    """What a render needs to run a traced depth's backward itself (FusedLoss.depth_node): the tensors `_TracedDepth` saved."""
+
+    def __init__(self, meta, p, trips, gate, params):
+        self.meta, self.p, self.trips, self.gate, self.params = meta, p, trips, gate, list(params)
+
+    def matches(self, render_params) -> bool:
+        """the tracing's parameters are the first tensors of the render's list (same flat-buffer offsets)"""
+        return len(render_params) >= len(self.params) and all(a is b for a, b in zip(self.params, render_params))
+
+    def prepare(self, render_flat):
+        """ls2fm_depth_backward for a render backward whose flat gradient buffer is `render_flat` -> (struct, tensors to keep
+        alive until the call has been enqueued)"""
+        lib = _lib.load()
+        fdesc, gdesc, beta_speed, n_rays, k_max = self.meta
+        dev = self.p.device
+        n = n_rays * k_max
+        flat2, grads2 = flat_gradient_views(self.params, attach=False)
+        gstruct = _params_struct(grads2, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
+        ws_bytes = lib.ls2fm_sdf_points_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(gdesc), n)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
+        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+        d_sdf = torch.empty(n, device=dev)
+        db = _lib.DepthBackward()
+        db.points, db.trips, db.gate, db.k_max = ptr(self.p), ptr(self.trips), ptr(self.gate), k_max
+        db.d_sdf, db.grads, db.workspace = ptr(d_sdf), ctypes.cast(ctypes.pointer(gstruct), ctypes.c_void_p), ptr(ws)
+        # everything in front of beta's segment: a point query has no beta gradient
+        db.sum_into, db.sum_from = ptr(render_flat), ptr(flat2)
+        db.sum_count = sum((t.numel() + 3) // 4 * 4 for t in self.params[:7])
+        return db, (flat2, gstruct, ws, d_sdf)
+
+
+def traced_depth(sdf_field, track, trips, near, far, rgbs_gt=None, trace_ws=None, launch_stream=None):
     """track [R, iters_max (+1), 3], trips int32[1] on the device, near / far [R] (what sphere_trace(sync=False) returns) ->
     d_pred [R], sdf_last [R] (graph attached), finish_mask [R] bool, and with rgbs_gt [R,3]: mask_bg, mask_finish & mask_bg as
     uint8 [R] (what the fused loss head takes) -- else None, None"""
@@ -695,7 +773,7 @@ def traced_depth(sdf_field, track, trips, near, far, rgbs_gt=None, trace_ws=None
     thr = _finish_threshold(sdf_field)
     ts, _ = param_tensors(sdf_field, None)
     d_pred, last, finish, mask_bg, mask_dc = _TracedDepth.apply(pts, trips, near.reshape(-1), far.reshape(-1), rgbs_gt, thr, sdf_field,
-                                                                trace_ws, *ts)
+                                                                trace_ws, launch_stream, *ts)
     if rgbs_gt is None:
         return d_pred, last, finish.view(torch.bool), None, None
     return d_pred, last, finish.view(torch.bool), mask_bg, mask_dc
@@ -732,7 +810,7 @@ def sdf_volume(sdf_field, n_side, step, origin, first=0, count=None, reference_i
     return out
 
 
-def sphere_trace(sdf_field, o, d, history=False, sync=True):
+def sphere_trace(sdf_field, o, d, history=False, sync=True, launch_stream=None):
     """the reference's root-find loop (SDF.py:149-200) in one kernel.
     o, d [R,3] -> near [R], far [R], pts_tracks [R,K,3], t_end [R] (far-end distance after K trips), K
     history=True: t_end comes back as [R,K+1], the far-end distance after every trip (parity tests)
@@ -748,18 +826,32 @@ def sphere_trace(sdf_field, o, d, history=False, sync=True):
     far = torch.empty(n, device=dev)
     track = torch.empty(n, it + 1, 3, device=dev)
     t_end = torch.empty(n, it + 1, device=dev)
-    trips = torch.zeros(1, device=dev, dtype=torch.int32)
+    trips = torch.empty(1, device=dev, dtype=torch.int32)            # zeroed by the call
     keep, pstruct = _sdf_only_params(sdf_field)
     fdesc = field_desc(sdf_field.opt)
+    gdesc = sdf_field.embed_fn.embedder_obj.desc
     ws = _sdf_workspace(dev)
-    check(lib.ls2fm_sphere_trace(ctypes.byref(fdesc), ctypes.byref(sdf_field.embed_fn.embedder_obj.desc),
-                                 ctypes.byref(pstruct), ptr(o), ptr(d), n, float(sdf_field.sdf_threshold), it, ptr(near),
-                                 ptr(far), ptr(track), ptr(t_end), ptr(trips), ptr(ws), stream_ptr()), "ls2fm_sphere_trace")
+    args = (ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(o), ptr(d), n, float(sdf_field.sdf_threshold), it,
+            ptr(near), ptr(far), ptr(track), ptr(t_end), ptr(trips), ptr(ws))
+    if launch_stream is None:
+        check(lib.ls2fm_sphere_trace(*args, stream_ptr()), "ls2fm_sphere_trace")
+    else:
+        # weight preparation (one latency-bound workgroup) on the CURRENT stream, the root-find on `launch_stream` behind it: the
+        # caller runs that stream beside other work of the current one (ls2fm.stage) and orders its readers itself
+        check(lib.ls2fm_sdf_prepare(ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(ws), ptr(trips), stream_ptr()), "ls2fm_sdf_prepare")
+        launch_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(launch_stream):
+            check(lib.ls2fm_sphere_trace_prepared(*args, stream_ptr()), "ls2fm_sphere_trace_prepared")
+        if not torch.cuda.is_current_stream_capturing():
+            for t in (near, far, track, t_end, trips, ws):
+                t.record_stream(launch_stream)
     from . import dist as _dist
     if not sync:
         if _dist.is_distributed():
             import torch.distributed as tdist
-            tdist.all_reduce(trips, op=tdist.ReduceOp.MAX)
+            import contextlib
+            with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
+                tdist.all_reduce(trips, op=tdist.ReduceOp.MAX)
         track._ls2fm_trace_ws = ws              # packed weights of these parameters: reused by traced_depth (no second prep)
         return near, far, track, t_end, trips
     k = int(trips.item())           # the reference syncs here too (its loop condition is a host-side .sum())

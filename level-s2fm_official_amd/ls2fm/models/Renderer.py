@@ -77,20 +77,26 @@ class Renderer(nn.Module):
         return self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
 
     def forward_with_loss(self, opt, center, ray, SDF_Field, Rad_Field, head, rgbs_gt, d_points=None, mask_finish=None,
-                          mask_eik=None, mask_bg=None):
+                          mask_eik=None, mask_bg=None, inputs_ready=None, depth_node=None):
         """`Renderer.forward` followed by the stage loops' loss head (ls2fm.losses.RenderLossHead: pipelines/Camera.py:
         515-537, BA.py:206-218) -> (ret, losses).  On the fused path the loss head runs INSIDE the render: partial sums in
         the forward's last kernel, the upstream of rgb / normals / depth formed in the backward's first -- no loss kernels and
         no [B,R,N,3] gradient tensor between forward and backward.  Same values and gradients as `head(self.forward(...),
-        rgbs_gt, ...)`, which is what runs when the configuration is served by the composed form."""
+        rgbs_gt, ...)`, which is what runs when the configuration is served by the composed form.
+        inputs_ready: a torch.cuda.Event recorded (on another stream) once d_points and the masks are final -- the fused forward
+        waits for it only behind its gather pass (ls2fm_render_opts.loss_inputs_ready), the composed form right away."""
         plan = fused.render_plan(self, opt, center, ray, SDF_Field, Rad_Field)
         if plan is not None:
             spec = head.spec(rgbs_gt, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg,
                              n_rays=center.shape[0] * center.shape[1])
+            spec.ready = inputs_ready
+            spec.depth_node = depth_node        # ls2fm.fused.TracedDepthNode: its backward runs beside this render's scatter
             ret = fused.render(self, opt, center, ray, SDF_Field, Rad_Field, loss=spec, d_points=d_points, plan=plan)
             losses = head.as_dict(ret.pop("loss_terms"), ret.pop("loss_total"))
             losses["PSNR"] = ret.pop("loss_psnr")          # -10 log10(mse), formed with the terms (no graph)
             return ret, losses
+        if inputs_ready is not None:
+            torch.cuda.current_stream(center.device).wait_event(inputs_ready)
         ret = self.forward_composed(opt, center, ray, SDF_Field, Rad_Field)
         return ret, head(ret, rgbs_gt, d_points=d_points, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg)
 

@@ -152,7 +152,7 @@ class SDF(nn.Module):
             track = [p_s]
         return torch.stack(track, dim=1), t_end[-1], trips
 
-    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None, want_samples=False):
+    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None, want_samples=False, launch_stream=None):
         """sphere_tracing without the host round trip for the trip count K (hipGraph-capturable, ls2fm.stage): the kernel leaves K
         on the device and runs every ray for iters_max trips anyway; the differentiable depth sums the first K track points
         through a device-side mask (K = 0: the single current point, SDF.py:201-202) -- one fused node, ls2fm.fused.traced_depth.
@@ -165,10 +165,14 @@ class SDF(nn.Module):
         (Camera.py:515-516) -> self.last_masks."""
         if not fused.available(self, o):
             raise RuntimeError("ls2fm: static_trips needs the fused tracing kernel (GPU tensors, reference layer sizes)")
+        # launch_stream: the kernels of this call (root-find, track evaluation, depth) are enqueued on that stream -- which the
+        # caller has made wait for the inputs and whose completion it waits for itself -- while the autograd node stays with the
+        # current stream (ls2fm.stage: tracing beside the render's gather pass)
         with torch.no_grad():
-            near, far, track, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach(), sync=False)
+            near, far, track, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach(), sync=False, launch_stream=launch_stream)
         d_pred, last, finish, mask_bg, mask_dc = fused.traced_depth(self, track, trips, near, far, rgbs_gt,
-                                                                    trace_ws=getattr(track, "_ls2fm_trace_ws", None))
+                                                                    trace_ws=getattr(track, "_ls2fm_trace_ws", None),
+                                                                    launch_stream=launch_stream)
         self.last_trips = trips
         self.last_masks = (mask_bg, mask_dc)             # uint8 [R] each (rgbs_gt given): what the fused loss head takes
         sampled = None
@@ -189,7 +193,7 @@ class SDF(nn.Module):
 
     def sphere_tracing(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129),
                        n_secant_steps=8, depth_range=(0.0, 2.4), max_points=3500000, rad=1.0, iter=0,
-                       impl="fused", static_trips=False, rgbs_gt=None, want_samples=False):
+                       impl="fused", static_trips=False, rgbs_gt=None, want_samples=False, launch_stream=None):
         """ray0, ray_direction [B,R,3] -> (d_pred [B,R], sdf_last [B*R], sampled_pts [1, <=4096+B*R, 3],
         finish_mask [B*R,1]).  `d_pred = near + sum_k sdf(track_k)` is differentiable w.r.t. the SDF
         parameters; the root-find itself runs without a graph.  Unused reference arguments are accepted."""
@@ -197,7 +201,7 @@ class SDF(nn.Module):
         o = ray0.reshape(-1, 3)
         d = ray_direction.reshape(-1, 3)
         if static_trips:
-            return self._sphere_tracing_static(o, d, shape2, rgbs_gt, want_samples=want_samples)
+            return self._sphere_tracing_static(o, d, shape2, rgbs_gt, want_samples=want_samples, launch_stream=launch_stream)
         with torch.no_grad():
             if impl == "fused" and fused.available(self, o):
                 near, far, pts_tracks, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach())

@@ -26,6 +26,17 @@ from .optim import FusedAdam
 from .utils import camera as _cam
 
 
+_TRACE_STREAMS = {}
+
+
+def _trace_stream(device):
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _TRACE_STREAMS:
+        _TRACE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _TRACE_STREAMS[idx]
+
+
 def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs_gt, static_trips=False, eikonal_over="bg"):
     """CameraSet.render(mode="train") after the ray pick + the render-side terms of compute_loss: -> the reference's `ret`
     keys (rgb, sdfs_volume, normals, depth_mlp, normal_mlp, mask_bg, rgb_loss, DC_loss, PSNR, tracing_loss) plus
@@ -35,12 +46,20 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
     eikonal_over: "bg" = over the rays of mask_bg (BA.py:193-194, Initialization.py:257-258), "all" = over every normal
     (rendering_refine.py:101-102)."""
     b, r = centers.shape[:2]
+    ready = None
     if static_trips:
         # one fused node forms the traced depth AND the two masks of Camera.py:515-516 (uint8, as the loss head takes them):
-        # as torch ops these lines were ~25 launch-bound elementwise kernels of the captured step
+        # as torch ops these lines were ~25 launch-bound elementwise kernels of the captured step.
+        # The tracing (one latency-bound kernel of few workgroups, then the track evaluation) is independent of the render up to
+        # the loss head inside shade_fwd: it runs on its own stream BESIDE the render's gather pass (L2-bound), and the forward
+        # waits for its event only in front of shade_fwd.  (The autograd node itself belongs to the current stream -- its
+        # backward runs there --; only the forward's kernels are launched on the other one.)
+        side = _trace_stream(centers.device)
         d_points, sdf_last, _, _ = sdf_field.sphere_tracing(centers.reshape(1, -1, 3), rays.reshape(1, -1, 3), sdf_field, iter=0,
-                                                            static_trips=True, rgbs_gt=rgbs_gt.reshape(-1, 3))
+                                                            static_trips=True, rgbs_gt=rgbs_gt.reshape(-1, 3), launch_stream=side)
         mask_bg8, mask_dc8 = sdf_field.last_masks
+        ready = torch.cuda.Event()
+        ready.record(side)
         mask_bg, mask_finish = mask_bg8.view(b, r), mask_dc8.view(b, r)
     else:
         d_points, sdf_last, _, mask_finish = sdf_field.sphere_tracing(centers.reshape(1, -1, 3), rays.reshape(1, -1, 3), sdf_field,
@@ -50,7 +69,10 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
         mask_finish = mask_finish.view(b, r) & mask_bg                        # Camera.py:516
     ret, losses = renderer.forward_with_loss(opt, centers, rays, sdf_field, rad_field, head, rgbs_gt, d_points=d_points.view(b, r),
                                              mask_finish=mask_finish, mask_eik=mask_bg if eikonal_over == "bg" else None,
-                                             mask_bg=mask_bg)
+                                             mask_bg=mask_bg, inputs_ready=ready,
+                                             depth_node=getattr(sdf_field, "last_trace_node", None) if static_trips else None)
+    if ready is not None:
+        torch.cuda.current_stream(centers.device).wait_event(ready)       # join: later readers of the traced outputs, the backward
     if static_trips:
         mask_bg, mask_finish = mask_bg.view(torch.bool), mask_finish.view(torch.bool)      # 0 / 1 bytes: same storage, no kernel
     ret = dict(ret)
