@@ -1,6 +1,6 @@
 #!/bin/bash
-# one gpurun call: kernel-trace stats + the two PMC passes + the default bench line  ->  gpurun_out/r02_*   (tag = $1, default r02)
-TAG=${1:-r02}
+# one gpurun call: kernel-trace stats + the two PMC passes + the default bench line  ->  gpurun_out/r03_*   (tag = $1, default r03)
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ARGS="bench.py --no-cpu-baseline --launch eager"
 LS2FM_SERIAL=1 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_kt -- python $ARGS --steps 100 --warmup 10 > gpurun_out/${TAG}_kt_bench.json 2>/dev/null
