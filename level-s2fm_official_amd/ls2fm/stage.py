@@ -366,6 +366,84 @@ class RefineLoop:
         return {("all" if k == "loss_all" else k): torch.stack(v) for k, v in logs.items()}
 
 
+class InitLoop:
+    """`Initializer.run` (pipelines/Initialization.py:139-226) for the two initial views with given poses (the essential-matrix
+    pose initialisation of `Initializer.__init__` is pycolmap's: caller side): per iteration the matched key points of each
+    view are sphere-traced onto the surface and projected into the OTHER view (`Camera.proj_cam_i`, Camera.py:168-178) --
+    reproj_error = mean ||uv_proj - key point||, sdf_surf = mean |SDF at the end of the tracks|, both over the 2 n tracks; the
+    gradient reaches the SDF field through the traced depth -- then the render with the cameras' poses, eikonal over EVERY
+    normal, rgb, depth consistency; one backward; Adam over the two fields (the poses are not in this optimizer,
+    Initialization.py:124-125); ExponentialLR.  `triangulate()` is the block after the loop (Initialization.py:182-213).
+
+    views: a two-view `TrackedViews` whose key points are the inlier matches, row j of view 0 <-> row j of view 1 (what
+    `kypts[mch_msks[..., 0]][inlier_msks]` and `cam_i.kypts[mch_msks[..., 1]][inlier_msks]` select); track_ids / xyzs unused."""
+
+    def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, max_iter, rand_rays,
+                 capture=False, static_trips=None, sdf_filter=True):
+        get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
+        if len(views.keypoints) != 2 or views.keypoints[0].shape != views.keypoints[1].shape:
+            raise ValueError("ls2fm.stage.InitLoop: two views with the same number of matched key points")
+        self.sdf, self.views, self.max_iter, self.rand_rays = sdf_field, views, int(max_iter), int(rand_rays)
+        self.sdf_filter = bool(sdf_filter)
+        self.poses = (views.poses if views.poses.shape[-1] == 4 else _cam.lie.se3_to_SE3(views.poses)).detach()
+        from . import fused as _fused
+        self.static = _fused.available(sdf_field, views.images) if static_trips is None else static_trips
+        self.w_reproj = 0.0 if get("reproj_error") is None else 10.0 ** float(get("reproj_error"))
+        self.w_surf = 0.0 if get("sdf_surf") is None else 10.0 ** float(get("sdf_surf"))
+        with torch.no_grad():              # the poses do not move during the loop: the key points' rays are formed once
+            self._kp_rays = [keypoint_rays(self.poses[v], views.intrinsic, views.keypoints[v]) for v in range(2)]
+        self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
+                                 lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="all")
+        self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "reproj_error")
+        self._surface = self._finish = None
+
+    def _extra(self, ret):
+        """the explicit-match terms (Initialization.py:154-160, 252-255), already weighted"""
+        errs, sdfs, surface, finish = [], [], [], []
+        for v in range(2):
+            center, ray = self._kp_rays[v]
+            d, sdf_last, _, fin = self.sdf.sphere_tracing(center, ray, self.sdf, static_trips=self.static)
+            pts = center + ray * d.reshape(1, -1, 1)                                             # Camera.py:136
+            o = 1 - v
+            uv = _cam.cam2img(_cam.world2cam(pts, self.poses[o:o + 1]), self.views.intrinsic.unsqueeze(0))
+            uv = (uv / (uv[..., 2:] + 1e-6))[..., :2]                                            # Camera.py:173
+            errs.append((uv[0] - self.views.keypoints[o]).norm(dim=-1))
+            sdfs.append(sdf_last.reshape(-1))
+            surface.append(pts[0].detach())
+            finish.append(fin.reshape(-1).bool())
+        ret["reproj_error"] = torch.cat(errs).mean()
+        ret["sdf_surf"] = torch.cat(sdfs).abs().mean()
+        self._surface, self._finish = torch.stack(surface), torch.stack(finish)
+        return self.w_reproj * ret["reproj_error"] + self.w_surf * ret["sdf_surf"]
+
+    def step(self, rays_idx=None):
+        if rays_idx is None:
+            rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // 2]
+        centers, rays, rgbs_gt = _pick_rays(self.views, self.poses, rays_idx)
+        return self.stage.step(centers, rays, rgbs_gt)
+
+    def run(self, n_iters=None, picks=None):
+        logs = {k: [] for k in self._keys}
+        for it in range(self.max_iter if n_iters is None else int(n_iters)):
+            ret = self.step(picks[it] if picks is not None else None)
+            for k in self._keys:
+                logs[k].append(ret[k].detach().reshape(()).clone())
+        return {("all" if k == "loss_all" else k): torch.stack(v) for k, v in logs.items()}
+
+    @torch.no_grad()
+    def triangulate(self):
+        """-> (points [n,3], kept [n] bool): the mean of the two views' traced surface points of the LAST iteration; kept =
+        within mean + 3 sigma of the two-view distance and (sdf_filter) finished in at least one view (Initialization.py:183-191).
+        The caller adds `points[kept]` to its point set with the feature tracks (view 0 key point j, view 1 key point j)."""
+        if self._surface is None:
+            raise RuntimeError("ls2fm.stage.InitLoop.triangulate: run at least one step first")
+        diff = (self._surface[0] - self._surface[1]).norm(dim=-1)
+        kept = diff < diff.mean() + 3 * diff.std()
+        if self.sdf_filter:
+            kept = kept & (self._finish[0] | self._finish[1])
+        return (self._surface[0] + self._surface[1]) / 2, kept
+
+
 class BALoop:
     """`BA` in mode "sfm_refine" with several cameras (pipelines/BA.py:24-218; optim_split: rotation / translation parameters
     with their own rates, BA.py:66-75): per iteration the POINT side -- tracked points projected onto the surface

@@ -9,6 +9,13 @@ reference's own `Camera` / `CameraSet` / `Point3DSet` objects, `torch.optim.Adam
              ray pick, multi-view tracing consistency of one random camera's key points (Camera.py:466-476), Renderer.forward,
              SDF.sphere_tracing, masks, rgb / DC losses, PSNR -- compute_loss / summarize_loss (eikonal over ALL normals,
              sdf_surf on the key-point tracks, 10^w weights), backward, Adam.step, ExponentialLR.step
+  init_*     `Initializer.run` (pipelines/Initialization.py:139-226), constructed with `cam_info_reloaded` (the two-view pose
+             initialisation of its __init__ is pycolmap's essential-matrix estimation: not part of the loop): per iteration the
+             matched key points of each view are traced onto the surface and projected into the other view (Camera.proj_cam_i),
+             CameraSet.render with the cameras' own poses, compute_loss (re-projection error, sdf_surf on the tracks, eikonal over
+             ALL normals), backward, Adam over the two fields; after the loop the two-view triangulation (mean of the two traced
+             points, 3-sigma + finish-mask filter).  `essential_2view` (a pycolmap cross-check whose result no loss reads) and the
+             image / pose-evaluation outputs after the loop are no-ops here.
   ba_*       `BA.run_ba`   (pipelines/BA.py:110-188), mode "sfm_refine", two cameras: the point side (get_surface_pts,
              infer_sdf, re-projection through the pose parameters, mask_surf), the render side, compute_loss (eikonal over
              mask_bg), the adaptive re-projection weight, backward, Adam over poses + both fields, the point update
@@ -34,13 +41,16 @@ CASES = [
     ("stage_refine_dtu_dual", "refine", "DTU", 8, 12, True, 24, 24, 32, 96, 40),
     ("stage_refine_eth3d_single", "refine", "ETH3D", 6, 11, False, 16, 20, 28, 80, 32),
     ("stage_ba_dtu_dual", "ba", "DTU", 8, 12, True, 24, 24, 32, 96, 64),
+    ("stage_init_dtu_dual", "init", "DTU", 8, 12, True, 24, 24, 32, 96, 48),
 ]
 OPTIM = dict(algo="Adam", algo_split="SGD", optim_split=True, use_grad_clip=False,
              sched=dict(type="ExponentialLR"),
+             init=dict(max_iter=K_ITERS, lr_sdf=1e-3, lr_sdf_end=1e-4, lr_color=1e-2, lr_color_end=1e-3),
              refine=dict(max_iter=K_ITERS, lr_sdf=1e-3, lr_sdf_end=5e-4, lr_color=1e-3, lr_color_end=5e-4),
              ba=dict(max_iter=K_ITERS, lr_sdf=1e-4, lr_sdf_end=5e-5, lr_pose=1e-2, lr_pose_end=5e-3, lr_color=1e-3,
                      lr_color_end=5e-4, lr_pose_r=5e-3, lr_pose_t=1e-2))                      # LevelS2fM.yaml:60-90
-WEIGHTS = dict(refine=dict(eikonal_loss=2, rgb=3, DC_Loss=0, tracing_loss=2, sdf_surf=2),
+WEIGHTS = dict(init=dict(reproj_error=0, eikonal_loss=2, sdf_surf=2, rgb=3, DC_Loss=0),
+               refine=dict(eikonal_loss=2, rgb=3, DC_Loss=0, tracing_loss=2, sdf_surf=2),
                ba=dict(reproj_error=0, eikonal_loss=2, sdf_surf=2, rgb=3, DC_Loss=0, tracing_loss=1))   # LevelS2fM.yaml:98-123
 
 
@@ -93,7 +103,10 @@ def main():
     from pipelines import Point3D as RefPoint3D
     import utils.camera as ref_camera
 
+    only = set(sys.argv[1:])                       # optional: case names to (re)generate
     for ci, (name, loop, dataset, L, log2_T, dual, N, H, W, rand_rays, n_kp) in enumerate(CASES):
+        if only and name not in only:
+            continue
         torch.manual_seed(9000 + ci)
         random.seed(9050 + ci)
         gen = torch.Generator().manual_seed(9100 + ci)
@@ -164,6 +177,28 @@ def main():
         if loop == "refine":
             stage = RefRefine.Refine(opt, cset, pset, sdf, rad)                 # consumes one ray permutation (rgbs_gt)
             wkey = "refine"
+        elif loop == "init":
+            # a fresh camera set / point set, filled by the Initializer itself from `var` (matches + inlier flags per view pair)
+            import tempfile
+            from pipelines import Initialization as RefInit
+            opt.Ablate_config.sdf_filter = True
+            opt.output_path = tempfile.mkdtemp(prefix="ls2fm_init_")
+            n_all = kp[0].shape[0]
+            n_out = max(2, n_all // 8)                                          # a few matches flagged as outliers
+            m01 = np.stack([np.arange(n_all), np.arange(n_all)], axis=-1).astype(np.int32)
+            inl = np.ones(n_all, bool); inl[np.arange(n_out) * 3 + 1] = False
+            var = MG.AttrDict(indx_init=[0, 1], imgs_init=images, poses_gt=poses, kypts_init=kp, intrs_init=[intr, intr],
+                              mchs_init=[[m01.copy()], [m01[:, ::-1].copy()]], inliers_init=[[inl.copy()], [inl.copy()]])
+            cset = RefCamera.CameraSet(opt)
+            pset = RefPoint3D.Point3DSet(opt)
+            stage = RefInit.Initializer(opt, cset, pset, sdf, rad, var,
+                                        cam_info_reloaded=dict(pose_para=se3, idx2d_to_3ds=[None, None]))
+            stage.essential_2view = lambda *a, **kw: None
+            cset.eval_poses = lambda *a, **kw: None
+            render_orig = cset.render
+            cset.render = render_logged
+            out["matches"], out["inliers"] = m01, inl
+            wkey = "init"
         else:
             stage = RefBA.BA(opt, cset, pset, sdf, rad, cam_pick_ids=None, mode="sfm_refine")
             wkey = "ba"
@@ -182,6 +217,8 @@ def main():
         with Recorder(H * W) as rec:
             if loop == "refine":
                 stage.run(sdf, rad, ren)
+            elif loop == "init":
+                stage.run(cset, pset, sdf, rad, ren)
             else:
                 stage.run_ba(sdf, rad, ren)
         assert len(rec.perms) == K_ITERS and len(log["all"]) == K_ITERS, (len(rec.perms), len(log["all"]))
@@ -193,6 +230,10 @@ def main():
                 out[f"log/{k}"] = np.asarray(v, np.float64)
         out.update(MG.sd_np(sdf, "sdf_final"))
         out.update(MG.sd_np(rad, "rad_final"))
+        if loop == "init":
+            idx0 = cset(0).idx2d_to_3d
+            out["tri_kept"] = (idx0 != -1)                                      # per key point of view 0: triangulated
+            out["tri_xyzs"] = torch.cat(pset.get_xyzs(idxs=list(idx0[idx0 != -1])), dim=0).numpy()
         if loop == "ba":
             out["se3_final"] = torch.cat([stage.r_paras(), stage.t_paras()], dim=1).detach().numpy()
             out["xyzs_final"] = stage.xyzs_all.detach().numpy()

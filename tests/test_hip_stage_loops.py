@@ -1,6 +1,6 @@
-"""The stage LOOPS (ls2fm.stage.RefineLoop / BALoop) against K = 20 consecutive iterations of the
-REFERENCE's own loops -- `Refine.run` (pipelines/rendering_refine.py:72-97) and `BA.run_ba` (pipelines/BA.py:110-188, mode
-"sfm_refine"), run through the reference's Camera / CameraSet / Point3DSet objects with torch.optim.Adam + ExponentialLR and
+"""The stage LOOPS (ls2fm.stage.InitLoop / RefineLoop / BALoop) against K = 20 consecutive iterations of the
+REFERENCE's own loops -- `Initializer.run` (pipelines/Initialization.py:139-226), `Refine.run`
+(pipelines/rendering_refine.py:72-97) and `BA.run_ba` (pipelines/BA.py:110-188, mode "sfm_refine"), run through the reference's Camera / CameraSet / Point3DSet objects with torch.optim.Adam + ExponentialLR and
 recorded by tests/golden/make_golden_stage.py: per-iteration loss terms and PSNR, the final parameters (fields, poses), the
 final points.  The RNG draws that pick a step's inputs (ray permutation head, the random view of the tracing consistency) are
 replayed from the recording; everything else is the product's: fused render with the loss head inside, fused tracing and
@@ -41,7 +41,8 @@ def _scene(g):
     ids = [torch.arange(k.shape[0], device=DEV) for k in kp]
     views = stage.TrackedViews(torch.from_numpy(g["poses"]).to(DEV), torch.from_numpy(g["intrinsic"]).to(DEV), images, kp, ids,
                                torch.from_numpy(g["xyzs"]).to(DEV).clone(), H, W)
-    picks = [(torch.from_numpy(g["rays_idx"][i]).to(DEV), int(g["cam_pick"][i])) for i in range(meta["iters"])]
+    cams = g["cam_pick"] if len(g["cam_pick"]) else np.zeros(meta["iters"], np.int32)      # the init loop draws no view
+    picks = [(torch.from_numpy(g["rays_idx"][i]).to(DEV), int(cams[i])) for i in range(meta["iters"])]
     return meta, opt, sdf, rad, ren, views, picks
 
 
@@ -119,6 +120,41 @@ def test_ba_loop_vs_reference_loop():
     assert torch.equal(views.xyzs.cpu(), torch.from_numpy(g["xyzs"])), "the point set itself does not move during the loop"
     _dense_close(sdf, g, "sdf_final")
     _dense_close(rad, g, "rad_final")
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_init_loop_vs_reference_loop(capture):
+    """`Initializer.run` (pipelines/Initialization.py:139-226), K = 20, and the two-view triangulation after it"""
+    g = load_golden("stage_init_dtu_dual")
+    meta, opt, sdf, rad, ren, views, picks = _scene(g)
+    o = meta["optim"]
+    inl = torch.from_numpy(g["inliers"]).to(DEV)
+    m = torch.from_numpy(g["matches"].astype(np.int64)).to(DEV)
+    kp = [views.keypoints[0][m[:, 0]][inl], views.keypoints[1][m[:, 1]][inl]]             # Camera.py:125, 176-177
+    two = stage.TrackedViews(views.poses, views.intrinsic, views.images, kp, [torch.arange(k.shape[0], device=DEV) for k in kp],
+                             torch.zeros(kp[0].shape[0], 3, device=DEV), views.H, views.W)
+    loop = stage.InitLoop(opt, ren, sdf, rad, two, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                          lr_color=o["lr_color"], max_iter=o["max_iter"], rand_rays=meta["rand_rays"], capture=capture)
+    logs = {k: v.cpu().numpy() for k, v in loop.run(picks=[p[0] for p in picks]).items()}
+    print(f"[init capture={capture}] loss {logs['all'][0]:.4f} -> {logs['all'][-1]:.4f} (reference {g['log/all'][0]:.4f} -> "
+          f"{g['log/all'][-1]:.4f}); reproj {logs['reproj_error'][-1]:.4f} vs {g['log/reproj_error'][-1]:.4f}")
+    _close("loss.all", logs["all"], g["log/all"], 3e-3)
+    _close("PSNR", logs["PSNR"], g["log/PSNR"], 3e-3)
+    _close("rgb_loss", logs["rgb_loss"], g["log/rgb_loss"], 3e-3)
+    _close("eikonal_loss", logs["eikonal_loss"], g["log/eikonal_loss"], 1e-2)
+    _close("reproj_error", logs["reproj_error"], g["log/reproj_error"], 1e-2)
+    _close("sdf_surf", logs["sdf_surf"], g["log/sdf_surf"], 2e-2, atol=2e-4)
+    _close("DC_loss", logs["DC_loss"], g["log/DC_loss"], 5e-2, atol=5e-4)
+    _dense_close(sdf, g, "sdf_final")
+    _dense_close(rad, g, "rad_final")
+    # the triangulation block (Initialization.py:182-213): which matches become 3-D points, and where
+    pts, kept = loop.triangulate()
+    ref_kept = torch.from_numpy(g["tri_kept"])[m[:, 0].cpu()][inl.cpu()]
+    assert torch.equal(kept.cpu(), ref_kept), (kept.cpu().tolist(), ref_kept.tolist())
+    ref_pts = torch.from_numpy(g["tri_xyzs"])
+    err = (pts[kept].cpu() - ref_pts).norm(dim=-1)
+    scale = float(ref_pts.abs().max())
+    assert float(err.max()) <= 2e-3 * scale, (float(err.max()), scale)
 
 
 def test_static_sphere_tracing_samples_have_the_reference_structure():
