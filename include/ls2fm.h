@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 4
+#define LS2FM_ABI_VERSION 5
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -240,7 +240,13 @@ typedef struct ls2fm_loss_spec {
     const float* d_terms;         /* backward: DEVICE float[5] upstream of terms[0..4], or NULL = zeros */
     const float* d_total;         /* backward: DEVICE float[1] additional upstream of the weighted total, or NULL */
     float* d_depth_ref;           /* backward output: [n_rays] gradient w.r.t. depth_ref (overwritten), or NULL */
+    uint32_t flags;               /* LS2FM_LOSS_*_FROM_GT */
 } ls2fm_loss_spec;
+/* mask_eik / mask_mse := CameraSet.render's mask_bg, 0.05 < mean(rgb_gt[r]) < 0.95 (Camera.py:515), evaluated in the kernels
+ * from rgb_gt; the pointer of the same name is ignored.  With these the loss head's only inputs that come out of a sphere
+ * tracing are depth_ref and mask_dc (see ls2fm_render_opts.loss_inputs_ready). */
+#define LS2FM_LOSS_EIK_FROM_GT 1u
+#define LS2FM_LOSS_MSE_FROM_GT 2u
 
 /* The backward of the sphere tracing that produced a render's depth_ref (ls2fm_trace_depth_bwd + ls2fm_sdf_points_bwd over
  * the track points), run BY ls2fm_render_bwd on an internal stream of its own, forked behind its first kernel (which writes
@@ -272,10 +278,11 @@ typedef struct ls2fm_render_opts {
      * 0 / 1: one pass, no events. */
     int32_t n_level_groups;
     void* group_events[LS2FM_MAX_LEVEL_GROUPS];
-    /* forward with a loss head: hipEvent_t (or NULL) after which the loss spec's device inputs -- depth_ref and the masks, the
-     * outputs of the sphere tracing of the same rays -- are final.  The forward waits for it on `stream` only in front of the
-     * kernel that reads them, i.e. AFTER its gather pass: a caller that traces on another stream overlaps the tracing (latency
-     * bound, few workgroups) with the gather pass (L2 bound) instead of running it in front of the render. */
+    /* forward with a loss head: hipEvent_t (or NULL) after which depth_ref and mask_dc -- the outputs of the sphere tracing of
+     * the same rays -- are final (mask_eik / mask_mse, when given as pointers, must be final in stream order at the call).  The
+     * forward waits for it on `stream` only in front of the kernel that reads them, the loss reduction BEHIND its gather pass
+     * and its shading kernel (which leaves the ray's depth for the reduction to form the depth-consistency term): a caller that
+     * traces on another stream overlaps the whole tracing chain (latency bound, few workgroups) with both. */
     void* loss_inputs_ready;
     /* backward with a loss head: hipEvent_t (or NULL) RECORDED on `stream` as soon as the backward's first kernel is enqueued --
      * from then on d_depth_ref (the gradient w.r.t. the traced depth) is final in stream order.  A caller whose depth came from a
@@ -314,13 +321,16 @@ int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_g
  * distance; `trips` receives the GLOBAL trip count K of the reference's loop (min(iters_max, the
  * trip at which no start ray is unfinished)), which the caller uses to truncate the track.
  * Outputs: near, far [n_rays]; track [n_rays, iters_max+1, 3]; t_end [n_rays, iters_max+1];
- * trips int32[1].  The differentiable re-evaluation of the track (SDF.py:203-214) is done by the
- * caller through the autograd-capable ops above.
+ * trips int32[1]; track_sdf [n_rays, iters_max+1] or NULL: the field's value at every track point
+ * -- what the re-evaluation of the track (SDF.py:203) returns, bit for bit (the loop has it for the
+ * points it evaluated; a finished start end that still moves with its stale step is evaluated for
+ * this output only).  The differentiable use of the track (SDF.py:203-214) is the caller's, through
+ * the autograd-capable ops above.
  */
 int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                        const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
-                       int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
-                       void* workspace, void* stream);
+                       int32_t iters_max, float* near, float* far, float* track, float* t_end, float* track_sdf,
+                       int32_t* trips, void* workspace, void* stream);
 
 /* The two halves of ls2fm_sphere_trace for a caller that overlaps the tracing with other work: ls2fm_sdf_prepare packs the SDF
  * MLP's weights into `workspace` (weight-norm -> effective weights; one latency-bound workgroup, ~15 us) and zeroes *zero_word
@@ -330,8 +340,8 @@ int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* gri
 int ls2fm_sdf_prepare(const ls2fm_grid_desc* grid, const ls2fm_params* params, void* workspace, int32_t* zero_word, void* stream);
 int ls2fm_sphere_trace_prepared(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                                 const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
-                                int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
-                                void* workspace, void* stream);
+                                int32_t iters_max, float* near, float* far, float* track, float* t_end, float* track_sdf,
+                                int32_t* trips, void* workspace, void* stream);
 
 /* ls2fm_sdf_eval (sdf only) with the packed weights a preceding ls2fm_sdf_eval / ls2fm_sphere_trace call left in `workspace`
  * (same stream, same parameters): no weight preparation launch.  Used between a tracing call and the evaluation of its track. */

@@ -175,9 +175,12 @@ post_shade_kernel(ls2fm_loss_spec loss, const float* __restrict__ lpart, int64_t
     for (int64_t r = tid; r < n_rays; r += kPostThreads) {
         s[0] += (double)lpart[0 * r_pad + r];
         s[1] += 3.0;
-        if (loss.mask_eik == nullptr || loss.mask_eik[r]) { s[2] += (double)lpart[1 * r_pad + r]; s[3] += (double)n_samples; }
-        if (loss.depth_ref != nullptr && (loss.mask_dc == nullptr || loss.mask_dc[r])) { s[4] += (double)lpart[2 * r_pad + r]; s[5] += 1.0; }
-        if (loss.mask_mse == nullptr || loss.mask_mse[r]) { s[6] += (double)lpart[3 * r_pad + r]; s[7] += 3.0; }
+        if (ls2fm_in_eik(loss, r)) { s[2] += (double)lpart[1 * r_pad + r]; s[3] += (double)n_samples; }
+        if (loss.depth_ref != nullptr && (loss.mask_dc == nullptr || loss.mask_dc[r])) {      // lpart row 2: the ray's depth
+            s[4] += (double)ls2fm_smooth_l1(loss.depth_ref[r] - lpart[2 * r_pad + r]);
+            s[5] += 1.0;
+        }
+        if (ls2fm_in_mse(loss, r)) { s[6] += (double)lpart[3 * r_pad + r]; s[7] += 3.0; }
     }
 #pragma unroll
     for (int k = 0; k < kSums; ++k) {

@@ -123,7 +123,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp, LossUp{}};
     if (loss)
         up.loss = LossUp{loss->rgb_gt, loss->depth_ref, loss->mask_eik, loss->mask_dc, loss->mask_mse, loss->weights, loss->sums,
-                         loss->d_terms, loss->d_total, loss->d_depth_ref};
+                         loss->d_terms, loss->d_total, loss->d_depth_ref, loss->flags};
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
     // (leading workgroups of this launch zero the weight-gradient accumulators and the atomically flushed table ranges)
     ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,

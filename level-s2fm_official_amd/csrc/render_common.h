@@ -291,6 +291,7 @@ struct LossUp {
     const uint8_t* mask_eik; const uint8_t* mask_dc; const uint8_t* mask_mse;
     const float* weights; const double* sums; const float* d_terms; const float* d_total;
     float* d_depth_ref;            // [R] output or null
+    uint32_t flags;
 };
 
 struct Upstream {                  // dL/d(outputs of render_fwd); any pointer may be null (= zeros)
@@ -302,6 +303,19 @@ struct Upstream {                  // dL/d(outputs of render_fwd); any pointer m
     LossUp loss;
 };
 
+// CameraSet.render's mask_bg of a ray (Camera.py:515), as trace_depth_fwd_kernel forms it
+__device__ __forceinline__ bool ls2fm_bg_from_gt(const float* __restrict__ rgb_gt, int64_t r) {
+    const float gray = (rgb_gt[3 * r] + rgb_gt[3 * r + 1] + rgb_gt[3 * r + 2]) / 3.0f;
+    return gray < 0.95f && gray > 0.05f;
+}
+template <typename Spec>
+__device__ __forceinline__ bool ls2fm_in_eik(const Spec& lo, int64_t r) {
+    return (lo.flags & LS2FM_LOSS_EIK_FROM_GT) ? ls2fm_bg_from_gt(lo.rgb_gt, r) : (lo.mask_eik == nullptr || lo.mask_eik[r] != 0);
+}
+template <typename Spec>
+__device__ __forceinline__ bool ls2fm_in_mse(const Spec& lo, int64_t r) {
+    return (lo.flags & LS2FM_LOSS_MSE_FROM_GT) ? ls2fm_bg_from_gt(lo.rgb_gt, r) : (lo.mask_mse == nullptr || lo.mask_mse[r] != 0);
+}
 __device__ __forceinline__ float ls2fm_smooth_l1(float d) { const float a = fabsf(d); return a < 1.0f ? 0.5f * d * d : a - 0.5f; }
 __device__ __forceinline__ float ls2fm_smooth_l1_grad(float d) { return fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f); }
 __device__ __forceinline__ float ls2fm_sign(float d) { return d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f); }

@@ -597,13 +597,13 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
 
     // ---- shading, then ONE small launch: the fused loss head's reduction and the scans of the item counts side by side (no
     // stream fork anywhere in the forward: the main chain stays on one queue)
-    // the loss head's device inputs (traced depth, masks) may come from another stream: waited for here, behind the gather pass
-    if (loss && opts->loss_inputs_ready && hipStreamWaitEvent(s, (hipEvent_t)opts->loss_inputs_ready, 0) != hipSuccess)
-        return LS2FM_ERR_LAUNCH;
     ls2fm_prof_begin(LS2FM_PROF_SHADE_FWD, s);
     ls2fm_launch_shade_fwd(fc, dual, 2 * L1, 2 * L2, pk, center, ray, n_rays, w, ws, rgb, sdfs_volume, normals, depth_mlp,
                            normal_mlp, loss, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_FWD, s);
+    // the traced depth and its mask may come from another stream: waited for here, behind the gather pass AND the shading
+    if (loss && opts->loss_inputs_ready && hipStreamWaitEvent(s, (hipEvent_t)opts->loss_inputs_ready, 0) != hipSuccess)
+        return LS2FM_ERR_LAUNCH;
     ls2fm_prof_begin(LS2FM_PROF_BIN, s);
     const int st = ls2fm_launch_post_shade(loss, ws + w.lpart, n_rays, field->n_samples, prepare_bwd ? sdf_grid : nullptr, w.p,
                                            ws + w.bins, s);

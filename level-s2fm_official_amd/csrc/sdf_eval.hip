@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256)
 sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
                     const float* __restrict__ table, const float* __restrict__ ray0, const float* __restrict__ ray_dir,
                     int64_t n_rays, float thr, int iters_max, float* __restrict__ near_out, float* __restrict__ far_out,
-                    float* __restrict__ track, float* __restrict__ t_end, int* __restrict__ trips) {
+                    float* __restrict__ track, float* __restrict__ t_end, float* __restrict__ track_sdf, int* __restrict__ trips) {
     const int64_t tidg = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = tidg >> 1;
     const int side = (int)(tidg & 1);
@@ -156,6 +156,8 @@ sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pack
     encode_point(lv, fc, table, p, u);
     geometry_forward<false>(pk->sdf, u, f, dummy);
     float sdf_me = signed_sdf(fc, bg_sdf, bg_rad, f[0], p, &bg);
+    float raw_me = sdf_me;               // the field's value at the current point (sdf_me is zeroed / goes stale: (1), (6))
+    const bool want_raw = track_sdf != nullptr && side == 0;
     if (live && side == 0) { near_out[r] = g.t_near; far_out[r] = g.t_far; }
     if (live && side == 1) t_end[r * (iters_max + 1)] = t_me;
     bool unf = false;
@@ -170,15 +172,20 @@ sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pack
         if (live && side == 0) {                                          // (5) pre-update start point -> track
 #pragma unroll
             for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + k) * 3 + a] = p[a];
+            if (track_sdf) track_sdf[r * (iters_max + 1) + k] = raw_me;
         }
+        const float t_before = t_me;
         t_me = t_me + sdf_me;                                             // (4) both ends step with '+', clamp to far
         if (t_me > far) t_me = far;
 #pragma unroll
         for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
-        if (unf) {                                                        // (6) refresh only where unfinished
+        // (6) refresh only where unfinished; for the track's values also where a finished start end still moved (crossed
+        // ends keep stepping with their stale value: the reference evaluates those points afterwards, SDF.py:203)
+        if (unf || (want_raw && t_me != t_before)) {
             encode_point(lv, fc, table, p, u);
             geometry_forward<false>(pk->sdf, u, f, dummy);
-            sdf_me = signed_sdf(fc, bg_sdf, bg_rad, f[0], p, &bg);
+            raw_me = signed_sdf(fc, bg_sdf, bg_rad, f[0], p, &bg);
+            if (unf) sdf_me = raw_me;
         }
         const float t_other = __shfl_xor(t_me, 1, 64);
         const float t_s = side ? t_other : t_me, t_e = side ? t_me : t_other;
@@ -188,6 +195,7 @@ sphere_trace_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pack
     if (live && side == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + iters_max) * 3 + a] = p[a];
+        if (track_sdf) track_sdf[r * (iters_max + 1) + iters_max] = raw_me;
     }
     // global trip count = max over rays: one atomic per wave (same-address global atomics serialise: ~6 ns each)
     int kmax = (live && side == 0) ? (kfin < 0 ? iters_max : kfin) : 0;
@@ -288,7 +296,7 @@ __global__ void __launch_bounds__(256)
 sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
                          const float* __restrict__ table, const float* __restrict__ ray0, const float* __restrict__ ray_dir,
                          int64_t n_rays, float thr, int iters_max, float* __restrict__ near_out, float* __restrict__ far_out,
-                         float* __restrict__ track, float* __restrict__ t_end, int* __restrict__ trips) {
+                         float* __restrict__ track, float* __restrict__ t_end, float* __restrict__ track_sdf, int* __restrict__ trips) {
     __shared__ float s_w0[kHidden * kW0Stride];
     __shared__ float s_w1[kHidden];
     for (int q = threadIdx.x; q < kHidden * kW0Stride; q += 256) s_w0[q] = pk->sdf[(q / kW0Stride) * kRecStride + q % kW0Stride];
@@ -307,6 +315,8 @@ sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const
 #pragma unroll
     for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
     float sdf_me = group_sdf(lv, fc, bg_sdf, bg_rad, table, s_w0, s_w1, b1_0, p, jl, gbase);
+    float raw_me = sdf_me;               // the field's value at the current point (see sphere_trace_kernel)
+    const bool want_raw = track_sdf != nullptr && side == 0;
     const bool writer = live && jl == 0;
     if (writer && side == 0) { near_out[r] = g.t_near; far_out[r] = g.t_far; }
     if (writer && side == 1) t_end[r * (iters_max + 1)] = t_me;
@@ -322,12 +332,21 @@ sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const
         if (writer && side == 0) {                                        // (5) pre-update start point -> track
 #pragma unroll
             for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + k) * 3 + a] = p[a];
+            if (track_sdf) track_sdf[r * (iters_max + 1) + k] = raw_me;
         }
+        const float t_before = t_me;
         t_me = t_me + sdf_me;                                             // (4) both ends step with '+', clamp to far
         if (t_me > far) t_me = far;
 #pragma unroll
         for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
-        if (unf) sdf_me = group_sdf(lv, fc, bg_sdf, bg_rad, table, s_w0, s_w1, b1_0, p, jl, gbase);   // (6) group-uniform
+        if (unf || (want_raw && t_me != t_before)) {                      // (6) group-uniform
+            // compiler barrier: without it the 144 weight values a lane reads from LDS per evaluation are hoisted out of the
+            // trip loop into registers (256 VGPRs + 44 AGPRs, one wave per SIMD) -- and a kernel running BESIDE this one
+            // (ls2fm.stage: the render's gather pass) loses more than half of its waves on every SIMD this kernel sits on
+            __asm__ volatile("" ::: "memory");
+            raw_me = group_sdf(lv, fc, bg_sdf, bg_rad, table, s_w0, s_w1, b1_0, p, jl, gbase);
+            if (unf) sdf_me = raw_me;
+        }
         const float t_other = __shfl_xor(t_me, 16, 64);
         const float t_s = side ? t_other : t_me, t_e = side ? t_me : t_other;
         unf = unf && (t_s < t_e);                                         // (7) crossed ends drop out
@@ -336,6 +355,7 @@ sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const
     if (writer && side == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + iters_max) * 3 + a] = p[a];
+        if (track_sdf) track_sdf[r * (iters_max + 1) + iters_max] = raw_me;
     }
     int kmax = (writer && side == 0) ? (kfin < 0 ? iters_max : kfin) : 0;
 #pragma unroll
@@ -445,29 +465,29 @@ extern "C" int ls2fm_sdf_prepare(const ls2fm_grid_desc* grid, const ls2fm_params
 
 static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                              const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold, int32_t iters_max,
-                             float* near, float* far, float* track, float* t_end, int32_t* trips, void* workspace, void* stream,
-                             bool prepared);
+                             float* near, float* far, float* track, float* t_end, float* track_sdf, int32_t* trips, void* workspace,
+                             void* stream, bool prepared);
 
 extern "C" int ls2fm_sphere_trace(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                                   const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
-                                  int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
-                                  void* workspace, void* stream) {
-    return sphere_trace_impl(field, grid, params, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far, track, t_end, trips,
-                             workspace, stream, false);
+                                  int32_t iters_max, float* near, float* far, float* track, float* t_end, float* track_sdf,
+                                  int32_t* trips, void* workspace, void* stream) {
+    return sphere_trace_impl(field, grid, params, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far, track, t_end, track_sdf,
+                             trips, workspace, stream, false);
 }
 
 extern "C" int ls2fm_sphere_trace_prepared(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                                            const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold,
-                                           int32_t iters_max, float* near, float* far, float* track, float* t_end, int32_t* trips,
-                                           void* workspace, void* stream) {
-    return sphere_trace_impl(field, grid, params, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far, track, t_end, trips,
-                             workspace, stream, true);
+                                           int32_t iters_max, float* near, float* far, float* track, float* t_end,
+                                           float* track_sdf, int32_t* trips, void* workspace, void* stream) {
+    return sphere_trace_impl(field, grid, params, ray0, ray_dir, n_rays, sdf_threshold, iters_max, near, far, track, t_end, track_sdf,
+                             trips, workspace, stream, true);
 }
 
 static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                              const float* ray0, const float* ray_dir, int64_t n_rays, float sdf_threshold, int32_t iters_max,
-                             float* near, float* far, float* track, float* t_end, int32_t* trips, void* workspace, void* stream,
-                             bool prepared) {
+                             float* near, float* far, float* track, float* t_end, float* track_sdf, int32_t* trips, void* workspace,
+                             void* stream, bool prepared) {
     LS2FM_CHECK_ARG(field_ok(field, grid, params) && n_rays >= 0 && iters_max >= 0);
     LS2FM_CHECK_ARG(trips);
     hipStream_t s = (hipStream_t)stream;
@@ -487,11 +507,11 @@ static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_des
     if (narrow)
         sphere_trace_kernel<<<(unsigned)((2 * n_rays + 255) / 256), 256, 0, s>>>(
             make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk, params->sdf_table, ray0, ray_dir, n_rays,
-            sdf_threshold, iters_max, near, far, track, t_end, trips);
+            sdf_threshold, iters_max, near, far, track, t_end, track_sdf, trips);
     else            // 8 rays per 256-thread workgroup
         sphere_trace_wide_kernel<<<(unsigned)((n_rays + 7) / 8), 256, 0, s>>>(
             make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk, params->sdf_table, ray0, ray_dir, n_rays,
-            sdf_threshold, iters_max, near, far, track, t_end, trips);
+            sdf_threshold, iters_max, near, far, track, t_end, track_sdf, trips);
     ls2fm_prof_end(LS2FM_PROF_SPHERE_TRACE, s);
     return ls2fm_launch_status();
 }

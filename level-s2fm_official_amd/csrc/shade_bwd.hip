@@ -115,9 +115,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             const float gl_rgb = fmaf(lo.weights[0], g_all, gt[0]) / (float)lo.sums[1];
             const float gl_dc = lo.sums[5] > 0.0 ? fmaf(lo.weights[2], g_all, gt[2]) / (float)lo.sums[5] : 0.f;
             const float gl_mse = gt[3] / (float)lo.sums[7];
-            if (lo.mask_eik == nullptr || lo.mask_eik[r] != 0) gl_eik = fmaf(lo.weights[1], g_all, gt[1]) / (float)lo.sums[3];
+            if (ls2fm_in_eik(lo, r)) gl_eik = fmaf(lo.weights[1], g_all, gt[1]) / (float)lo.sums[3];
             const float* __restrict__ rout = fws + w.rout;
-            const bool in_mse = lo.mask_mse == nullptr || lo.mask_mse[r] != 0;
+            const bool in_mse = ls2fm_in_mse(lo, r);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float d = rout[c * w.r_pad + r] - lo.rgb_gt[r * 3 + c];

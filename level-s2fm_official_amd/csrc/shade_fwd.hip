@@ -364,7 +364,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         if (lane == 0) s_part[wave][1 + q] = s;
     }
     // fused loss head: this ray's eikonal partial  sum_n | |n_n| - 1 |  (Initialization.py:257-258, BA.py:193-194)
-    const bool want_eik = loss.rgb_gt != nullptr && (loss.mask_eik == nullptr || loss.mask_eik[r] != 0);
+    const bool want_eik = loss.rgb_gt != nullptr && ls2fm_in_eik(loss, r);
     if (loss.rgb_gt != nullptr) {
         float e = 0.f;
         if (want_eik && live) e = fabsf(sqrtf(nrm_n[0] * nrm_n[0] + nrm_n[1] * nrm_n[1] + nrm_n[2] * nrm_n[2]) - 1.0f);
@@ -401,11 +401,11 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             ROUT[3 * r_pad + r] = depth_r;
             float eik = 0.f;
             for (int w = 0; w < n_waves; ++w) eik += s_part[w][9];
-            const bool dc = loss.depth_ref != nullptr && (loss.mask_dc == nullptr || loss.mask_dc[r] != 0);
             LPART[0 * r_pad + r] = l1;
             LPART[1 * r_pad + r] = eik;
-            LPART[2 * r_pad + r] = dc ? ls2fm_smooth_l1(loss.depth_ref[r] - depth_r) : 0.f;
-            LPART[3 * r_pad + r] = (loss.mask_mse == nullptr || loss.mask_mse[r] != 0) ? sq : 0.f;
+            LPART[2 * r_pad + r] = depth_r;        // the depth-consistency term is formed by the reduction: depth_ref may still be
+                                                   // on its way here (ls2fm_render_opts.loss_inputs_ready)
+            LPART[3 * r_pad + r] = ls2fm_in_mse(loss, r) ? sq : 0.f;
         }
     }
 }

@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -81,7 +81,10 @@ class LossSpec(Structure):
     """ls2fm_loss_spec: the loss head evaluated inside the render (forward epilogue / backward prologue)"""
     _fields_ = [("rgb_gt", c_void_p), ("depth_ref", c_void_p), ("mask_eik", c_void_p), ("mask_dc", c_void_p),
                 ("mask_mse", c_void_p), ("weights", c_void_p), ("terms", c_void_p), ("sums", c_void_p),
-                ("d_terms", c_void_p), ("d_total", c_void_p), ("d_depth_ref", c_void_p)]
+                ("d_terms", c_void_p), ("d_total", c_void_p), ("d_depth_ref", c_void_p), ("flags", c_uint32)]
+
+
+LOSS_EIK_FROM_GT, LOSS_MSE_FROM_GT = 1, 2
 
 
 class DepthBackward(Structure):
@@ -120,9 +123,9 @@ _SIGNATURES = {
                                    c_int64, _P, _P, _P, _P, _P, POINTER(ParamGrads), _P, _P, _P, POINTER(RenderOpts), _P]),
     "ls2fm_loss_terms_from_sums": (c_int32, [_P, _P, _P, _P]),
     "ls2fm_sphere_trace": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
-                                     c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+                                     c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls2fm_sphere_trace_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
-                                              c_float, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+                                              c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls2fm_sdf_prepare": (c_int32, [POINTER(GridDesc), POINTER(Params), _P, _P, _P]),
     "ls2fm_sdf_eval_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P]),
     "ls2fm_trace_depth_fwd": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_float, _P, c_float, c_float, _P, _P, _P, _P, _P, _P,

@@ -342,10 +342,15 @@ def sync_mirror(sdf_field, rad_field):
 
 class FusedLoss:
     """What the fused loss head of one render needs (ls2fm_loss_spec): built by ls2fm.losses.RenderLossHead.spec()."""
-    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts", "psnr", "ready", "depth_node")
+    __slots__ = ("weights", "rgb_gt", "mask_eik", "mask_dc", "mask_mse", "global_counts", "psnr", "ready", "depth_node", "flags")
 
     def __init__(self, weights, rgb_gt, mask_eik=None, mask_dc=None, mask_mse=None, global_counts="allreduce"):
+        """mask_eik / mask_mse: a uint8 [R] tensor, None (every ray) or "gt": CameraSet.render's mask_bg evaluated in the
+        kernels from rgb_gt (LS2FM_LOSS_*_FROM_GT) -- nothing but the traced depth and mask_dc then comes out of a tracing"""
         self.weights, self.rgb_gt = weights, rgb_gt
+        self.flags = (_lib.LOSS_EIK_FROM_GT if isinstance(mask_eik, str) else 0) | (_lib.LOSS_MSE_FROM_GT if isinstance(mask_mse, str) else 0)
+        mask_eik = None if isinstance(mask_eik, str) else mask_eik
+        mask_mse = None if isinstance(mask_mse, str) else mask_mse
         self.mask_eik, self.mask_dc, self.mask_mse = mask_eik, mask_dc, mask_mse
         self.global_counts = global_counts
         self.psnr = None                        # set by the render: terms[6] = -10 log10(mse)
@@ -360,6 +365,7 @@ def _loss_struct(fl, depth_ref, terms, sums, d_terms=None, d_total=None, d_depth
     s.mask_eik, s.mask_dc, s.mask_mse = ptr(fl.mask_eik), ptr(fl.mask_dc), ptr(fl.mask_mse)
     s.weights, s.terms, s.sums = ptr(fl.weights), ptr(terms), ptr(sums)
     s.d_terms, s.d_total, s.d_depth_ref = ptr(d_terms), ptr(d_total), ptr(d_depth_ref)
+    s.flags = fl.flags
     return s
 
 
@@ -668,11 +674,15 @@ class _TracedDepth(torch.autograd.Function):
             if not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
                 raise RuntimeError("ls2fm: fused point query needs contiguous fp32 GPU parameters")
         pstruct = _params_struct(list(params), False, float(sdf_field.beta_speed), with_rad=False)
-        sdf = torch.empty(n_rays * k_max, device=dev)
-        if trace_ws is not None:                # the tracing call's workspace: its packed weights are these parameters'
+        sdf = getattr(track, "_ls2fm_track_sdf", None)
+        if sdf is not None and sdf.numel() == n_rays * k_max:
+            sdf = sdf.reshape(-1)               # the tracing loop's own values at the track points
+        elif trace_ws is not None:              # the tracing call's workspace: its packed weights are these parameters'
+            sdf = torch.empty(n_rays * k_max, device=dev)
             check(lib.ls2fm_sdf_eval_prepared(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n_rays * k_max,
                                               ptr(sdf), ptr(trace_ws), stream_ptr()), "ls2fm_sdf_eval_prepared")
         else:
+            sdf = torch.empty(n_rays * k_max, device=dev)
             ws = _sdf_workspace(dev)
             check(lib.ls2fm_sdf_eval(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n_rays * k_max,
                                      ptr(sdf), None, None, ptr(ws), stream_ptr()), "ls2fm_sdf_eval")
@@ -692,7 +702,8 @@ class _TracedDepth(torch.autograd.Function):
         ctx.meta = (fdesc, gdesc, float(sdf_field.beta_speed), n_rays, k_max)
         ctx.side_allocated = [p, gate, sdf]
         ctx.save_for_backward(p, trips, gate, *params)
-        sdf_field.last_trace_node = TracedDepthNode(ctx.meta, p, trips, gate, params)
+        sdf_field.last_trace_node = TracedDepthNode(ctx.meta, p, trips, gate, params,
+                                                    keep=(track, getattr(track, "_ls2fm_keep", None), near, far, sdf, gt))
         outs = (d_pred, last, finish, mask_bg if mask_bg is not None else finish, mask_dc if mask_dc is not None else finish)
         ctx.mark_non_differentiable(*outs[2:])
         return outs
@@ -735,8 +746,13 @@ def _traced_depth_backward(meta, p, trips, gate, ps, d_dpred, d_last, attach):
 class TracedDepthNode:
     """What a render needs to run a traced depth's backward itself (FusedLoss.depth_node): the tensors `_TracedDepth` saved."""
 
-    def __init__(self, meta, p, trips, gate, params):
+    def __init__(self, meta, p, trips, gate, params, keep=None):
         self.meta, self.p, self.trips, self.gate, self.params = meta, p, trips, gate, list(params)
+        # every tensor the tracing's kernels touched on their launch stream: alive as long as this node is the field's last one,
+        # i.e. past the caller's join with that stream.  (Under hipGraph capture there is no record_stream: a block freed in
+        # Python while the other stream's kernels are still ahead of the join would be handed to the next allocation of the
+        # capturing stream -- measured: the render's outputs landing in the tracing's near / far / track values.)
+        self.keep = keep
 
     def matches(self, render_params) -> bool:
         """the tracing's parameters are the first tensors of the render's list (same flat-buffer offsets)"""
@@ -827,12 +843,15 @@ def sphere_trace(sdf_field, o, d, history=False, sync=True, launch_stream=None):
     track = torch.empty(n, it + 1, 3, device=dev)
     t_end = torch.empty(n, it + 1, device=dev)
     trips = torch.empty(1, device=dev, dtype=torch.int32)            # zeroed by the call
+    # the field's value at every track point, straight from the loop (what evaluating the track afterwards returns, bit for bit):
+    # the static form's depth node then needs no evaluation pass of its own
+    track_sdf = torch.empty(n, it + 1, device=dev) if not sync else None
     keep, pstruct = _sdf_only_params(sdf_field)
     fdesc = field_desc(sdf_field.opt)
     gdesc = sdf_field.embed_fn.embedder_obj.desc
     ws = _sdf_workspace(dev)
     args = (ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(o), ptr(d), n, float(sdf_field.sdf_threshold), it,
-            ptr(near), ptr(far), ptr(track), ptr(t_end), ptr(trips), ptr(ws))
+            ptr(near), ptr(far), ptr(track), ptr(t_end), ptr(track_sdf), ptr(trips), ptr(ws))
     if launch_stream is None:
         check(lib.ls2fm_sphere_trace(*args, stream_ptr()), "ls2fm_sphere_trace")
     else:
@@ -843,8 +862,9 @@ def sphere_trace(sdf_field, o, d, history=False, sync=True, launch_stream=None):
         with torch.cuda.stream(launch_stream):
             check(lib.ls2fm_sphere_trace_prepared(*args, stream_ptr()), "ls2fm_sphere_trace_prepared")
         if not torch.cuda.is_current_stream_capturing():
-            for t in (near, far, track, t_end, trips, ws):
-                t.record_stream(launch_stream)
+            for t in (near, far, track, t_end, trips, ws, track_sdf):
+                if t is not None:
+                    t.record_stream(launch_stream)
     from . import dist as _dist
     if not sync:
         if _dist.is_distributed():
@@ -853,6 +873,8 @@ def sphere_trace(sdf_field, o, d, history=False, sync=True, launch_stream=None):
             with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
                 tdist.all_reduce(trips, op=tdist.ReduceOp.MAX)
         track._ls2fm_trace_ws = ws              # packed weights of these parameters: reused by traced_depth (no second prep)
+        track._ls2fm_track_sdf = track_sdf
+        track._ls2fm_keep = (o, d, near, far, t_end, trips, track_sdf, ws)
         return near, far, track, t_end, trips
     k = int(trips.item())           # the reference syncs here too (its loop condition is a host-side .sum())
     k = _dist.global_max_int(k, dev)                  # sharded rays: keep K identical to the single-GPU run

@@ -30,9 +30,23 @@ def _workspace(dev):
     return ws
 
 
-def _mask(m, n_rays):
+def bg_mask(rgbs_gt):
+    """CameraSet.render's mask_bg (Camera.py:515)"""
+    gray = rgbs_gt.mean(dim=-1)
+    return (gray < 0.95) & (gray > 0.05)
+
+
+def _mask(m, n_rays, rgbs_gt=None):
+    """a per-ray mask as uint8 [n_rays]; None = every ray; "gt" = mask_bg of the ground-truth colours: kept as the string for
+    the fused loss head (evaluated in its kernels), formed here when `rgbs_gt` is given (the two-call form)"""
     if m is None:
         return None
+    if isinstance(m, str):
+        if m != "gt":
+            raise ValueError(f"ls2fm.losses: unknown mask {m!r}")
+        if rgbs_gt is None:
+            return m
+        m = bg_mask(rgbs_gt)
     m = m.reshape(-1)
     assert m.numel() == n_rays, "ray masks have one entry per ray"
     return (m if m.dtype == torch.uint8 else m.to(torch.uint8)).contiguous()
@@ -102,8 +116,8 @@ class RenderLossHead:
         select/zero-fill kernels)"""
         normals = ret["normals"]
         n_rays = normals.numel() // (3 * normals.shape[-2])
-        return _LossHead.apply(ret["rgb"], normals, ret["depth_mlp"], d_points, rgbs_gt, _mask(mask_eik, n_rays),
-                               _mask(mask_finish, n_rays), _mask(mask_bg, n_rays), self.weights,
+        return _LossHead.apply(ret["rgb"], normals, ret["depth_mlp"], d_points, rgbs_gt, _mask(mask_eik, n_rays, rgbs_gt),
+                               _mask(mask_finish, n_rays), _mask(mask_bg, n_rays, rgbs_gt), self.weights,
                                _workspace(normals.device), self.global_counts)
 
     def __call__(self, ret, rgbs_gt, **kw):

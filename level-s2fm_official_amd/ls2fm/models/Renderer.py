@@ -83,8 +83,10 @@ class Renderer(nn.Module):
         the forward's last kernel, the upstream of rgb / normals / depth formed in the backward's first -- no loss kernels and
         no [B,R,N,3] gradient tensor between forward and backward.  Same values and gradients as `head(self.forward(...),
         rgbs_gt, ...)`, which is what runs when the configuration is served by the composed form.
-        inputs_ready: a torch.cuda.Event recorded (on another stream) once d_points and the masks are final -- the fused forward
-        waits for it only behind its gather pass (ls2fm_render_opts.loss_inputs_ready), the composed form right away."""
+        mask_eik / mask_bg: per-ray masks, None (every ray) or "gt" = CameraSet.render's mask_bg, formed from rgbs_gt (inside the
+        fused kernels).  inputs_ready: a torch.cuda.Event recorded (on another stream) once d_points and mask_finish are final --
+        the fused forward waits for it only in front of its loss reduction, behind the gather pass and the shading
+        (ls2fm_render_opts.loss_inputs_ready; mask_eik / mask_bg tensors must then be final already), the composed form right away."""
         plan = fused.render_plan(self, opt, center, ray, SDF_Field, Rad_Field)
         if plan is not None:
             spec = head.spec(rgbs_gt, mask_finish=mask_finish, mask_eik=mask_eik, mask_bg=mask_bg,

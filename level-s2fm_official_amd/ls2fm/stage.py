@@ -61,15 +61,19 @@ def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs
         ready = torch.cuda.Event()
         ready.record(side)
         mask_bg, mask_finish = mask_bg8.view(b, r), mask_dc8.view(b, r)
+        # the render's loss head evaluates mask_bg itself from the colours ("gt"): only the traced depth and mask_finish come out
+        # of the tracing, and those are read by the loss REDUCTION behind the shading kernel -- the render waits for `ready` there
+        head_bg = "gt"
     else:
         d_points, sdf_last, _, mask_finish = sdf_field.sphere_tracing(centers.reshape(1, -1, 3), rays.reshape(1, -1, 3), sdf_field,
                                                                      iter=0)
         gray = rgbs_gt.mean(dim=-1)
         mask_bg = (gray < 0.95) & (gray > 0.05)                               # Camera.py:515
         mask_finish = mask_finish.view(b, r) & mask_bg                        # Camera.py:516
+        head_bg = mask_bg
     ret, losses = renderer.forward_with_loss(opt, centers, rays, sdf_field, rad_field, head, rgbs_gt, d_points=d_points.view(b, r),
-                                             mask_finish=mask_finish, mask_eik=mask_bg if eikonal_over == "bg" else None,
-                                             mask_bg=mask_bg, inputs_ready=ready,
+                                             mask_finish=mask_finish, mask_eik=head_bg if eikonal_over == "bg" else None,
+                                             mask_bg=head_bg, inputs_ready=ready,
                                              depth_node=getattr(sdf_field, "last_trace_node", None) if static_trips else None)
     if ready is not None:
         torch.cuda.current_stream(centers.device).wait_event(ready)       # join: later readers of the traced outputs, the backward

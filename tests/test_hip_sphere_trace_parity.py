@@ -126,6 +126,27 @@ def test_trace_free_running_vs_oracle_and_reference_goldens(case, manifest, reco
     assert tuple(sampled.shape) == tuple(g["st_sampled_shape"])
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES[:2])
+@pytest.mark.parametrize("kernel", ["wide", "narrow"])
+def test_track_values_from_the_loop_are_the_field_at_the_track_points(case, kernel, manifest):
+    """ls2fm_sphere_trace's track_sdf output -- what the static tracing path sums into the depth instead of evaluating the track
+    a second time -- is, bit for bit, the field at the track points: also for start ends that stopped being refreshed but kept
+    stepping with a stale value (crossed ends, SDF.py:176-183), and for converged ones (whose step is zeroed, not their value)"""
+    g = load_golden(case)
+    opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
+    cfg = golden_cfg(manifest[case])
+    s = (cfg.bound_max[0] - cfg.bound_min[0]) / 2
+    c, d = _rays(g, 1000 if kernel == "wide" else 20100, s, seed=23)
+    with torch.no_grad():
+        near, far, track, t_end, trips = fused.sphere_trace(sdf, c.to(DEV), d.to(DEV), sync=False)
+        vals = track._ls2fm_track_sdf
+        ref = sdf.infer_sdf(track.reshape(-1, 3).contiguous(), mode="ret_sdf").view(vals.shape)
+    assert vals.shape == (c.shape[0], cfg.iters_max_st + 1)
+    assert torch.equal(vals, ref), f"{int((vals != ref).sum())} of {vals.numel()} track values differ"
+    moved = (track[:, 1:] != track[:, :-1]).any(dim=-1)
+    assert bool(moved.any())
+
+
 @pytest.mark.parametrize("dataset,k_override", [("DTU", None), ("ETH3D", None), ("ETH3D", 0), ("BlendedMVS", 3)])
 def test_traced_depth_node_equals_torch_tail(dataset, k_override):
     """ls2fm.fused.traced_depth (ONE node: track evaluation, masked sum over the first K points, clamp at far, last value, finish

@@ -84,6 +84,24 @@ def test_refine_loop_vs_reference_loop(case, capture):
     _dense_close(rad, g, "rad_final")
 
 
+def test_captured_refine_loop_reproduces_the_eager_one_bit_for_bit():
+    """a race detector for the captured step: its kernels run on three streams (tracing beside the render's forward, the depth
+    branch and the weight-gradient chain beside the scatter) with the dependencies of a hipGraph only -- a missing edge or a
+    block recycled while another stream still uses it shows up as a run-to-run difference (it did: tensors of the tracing call
+    freed in Python ahead of the join)"""
+    g = load_golden("stage_refine_dtu_dual")
+    runs = []
+    for capture in (False, True, True):
+        meta, opt, sdf, rad, ren, views, picks = _scene(g)
+        o = meta["optim"]
+        loop = stage.RefineLoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                                lr_color=o["lr_color"], max_iter=o["max_iter"], rand_rays=meta["rand_rays"], capture=capture)
+        logs = loop.run(picks=picks)
+        runs.append({k: v.cpu() for k, v in logs.items()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[1][k], runs[2][k]), k
+
+
 def test_ba_loop_vs_reference_loop():
     g = load_golden("stage_ba_dtu_dual")
     meta, opt, sdf, rad, ren, views, picks = _scene(g)

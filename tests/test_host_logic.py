@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ls2fm.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared          # the python binding covers the whole header
-    assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == 5
     assert lib.ls2fm_status_string(-2) == b"unsupported configuration"
 
 
@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.Linear) == 24
     assert ctypes.sizeof(_lib.Params) == 8 + 48 + 8 + 8 + 8 + 48 + 72 + 8
     assert ctypes.sizeof(_lib.ParamGrads) == 8 + 48 + 8 + 8 + 48 + 72
-    assert ctypes.sizeof(_lib.LossSpec) == 11 * 8                      # ls2fm_loss_spec: eleven pointers
+    assert ctypes.sizeof(_lib.LossSpec) == 12 * 8 and _lib.LossSpec.flags.offset == 88    # ls2fm_loss_spec: eleven pointers, uint32 flags (+pad)
     assert ctypes.sizeof(_lib.RenderOpts) == 8 + 8 + 8 + 4 * 8 + 8 + 8 + 8     # int32 (+pad), pointer, int32 (+pad), void* [4], void* x 3
     assert _lib.RenderOpts.loss_inputs_ready.offset == 56 and _lib.RenderOpts.depth_grad_ready.offset == 64
     assert _lib.RenderOpts.depth_bwd.offset == 72 and ctypes.sizeof(_lib.DepthBackward) == 80 and _lib.DepthBackward.sum_count.offset == 72
