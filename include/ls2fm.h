@@ -248,24 +248,21 @@ typedef struct ls2fm_loss_spec {
 #define LS2FM_LOSS_EIK_FROM_GT 1u
 #define LS2FM_LOSS_MSE_FROM_GT 2u
 
-/* The backward of the sphere tracing that produced a render's depth_ref (ls2fm_trace_depth_bwd + ls2fm_sdf_points_bwd over
- * the track points), run BY ls2fm_render_bwd on an internal stream of its own, forked behind its first kernel (which writes
- * d_depth_ref) and joined at its end: the ~0.18 ms chain runs beside the render's table scatter and weight-gradient chain
- * instead of behind them, inside one call (and one hipGraph branch).  Afterwards sum_into[0 .. sum_count) += sum_from[0 ..
- * sum_count): the tracing's gradients of the SDF field's tensors, which live in the same flat layout, added into the render's --
- * one gradient producer per parameter.  Replaces what autograd does for Camera.py:506-523's d_consistent term through
- * SDF.sphere_tracing's differentiable tail (SDF.py:201-214): a second backward chain and seven accumulation kernels. */
+/* The backward of the sphere tracing that produced a render's depth_ref, run BY ls2fm_render_bwd and merged into its own
+ * chains.  On an internal stream of its own, forked behind the call's first kernel (which writes d_depth_ref): the masked
+ * upstream of the track points (ls2fm_trace_depth_bwd) and the front stages of ls2fm_sdf_points_bwd over them (gather pass,
+ * per-point backward, scans, payload sort).  Then the per-point rows are contracted by the render's own SDF weight-gradient
+ * kernel as extra tiles, and the points' table gradient is added into the render's sdf_table gradient behind its scatter: the
+ * render's `grads` come out as the SUM of both producers -- no second set of gradient tensors, no sum kernel.  Replaces what
+ * autograd does for Camera.py:506-523's d_consistent term through SDF.sphere_tracing's differentiable tail (SDF.py:201-214): a
+ * second backward chain and seven accumulation kernels.  Not combined with n_level_groups > 1 (LS2FM_ERR_UNSUPPORTED). */
 typedef struct ls2fm_depth_backward {
     const float* points;          /* [n_rays * k_max, 3] the tracing's track points (ls2fm_sphere_trace) */
     const int32_t* trips;         /* DEVICE int32[1] */
     const uint8_t* gate;          /* [n_rays] from ls2fm_trace_depth_fwd */
     int32_t k_max;
     float* d_sdf;                 /* scratch [n_rays * k_max] */
-    const struct ls2fm_param_grads* grads;  /* the tracing's own gradient tensors (SDF table + SDF MLP; overwritten) */
     void* workspace;              /* ls2fm_sdf_points_workspace_bytes(field, grid, n_rays * k_max) bytes */
-    float* sum_into;              /* or NULL: no sum */
-    const float* sum_from;
-    int64_t sum_count;
 } ls2fm_depth_backward;
 
 #define LS2FM_MAX_LEVEL_GROUPS 4

@@ -179,10 +179,11 @@ __device__ long long g_acc_stamps[8 * 4096];
 #define ACC_STAMP(k) do {} while (0)
 #endif
 
-template <bool DUAL>
+template <bool DUAL, bool ADD_INTO>
 __global__ void __launch_bounds__(kAccThreads)
 slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
                        float* __restrict__ dtable2, int block_base) {
+    constexpr bool add_into = ADD_INTO;
     constexpr int F = DUAL ? 4 : 2;
     __shared__ u64 acc[kAccSlots];
     const int tid = threadIdx.x;
@@ -202,6 +203,7 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
     const int n_items = bm.count[l * kBins + slab];
     const Item* __restrict__ list = bm.items + bm.start[l * kBins + slab];
     const int j_lo = (int)((int64_t)n_items * part / parts), j_hi = (int)((int64_t)n_items * (part + 1) / parts);
+    if (add_into && j_hi <= j_lo) return;                // nothing to add to the tables' current values
     uint4 q0 = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u), q1 = make_uint4(0u, 0u, 0u, 0u);
     if (j_lo + tid < j_hi) {
         q0 = reinterpret_cast<const uint4*>(list + j_lo + tid)[0];
@@ -252,7 +254,9 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
         const bool second = DUAL && f >= 2;
         float* dst = (second ? dst2 : dst1) + 2 * entry + (f & 1);
         const float v = (float)((double)(long long)acc[e] * (second ? to_float2 : to_float1));
-        if (parts == 1) *dst = v;                                 // sole owner of the entry
+        if (add_into) {                                           // a second producer of the same table: += (ordered behind the first)
+            if (acc[e] != 0ull) { if (parts == 1) *dst += v; else atomicAdd(dst, v); }
+        } else if (parts == 1) *dst = v;                          // sole owner of the entry
         else if (acc[e] != 0ull) atomicAdd(dst, v);               // point-split coarse level, zeroed by the host
     }
 #ifdef LS2FM_STAMPS
@@ -346,9 +350,10 @@ extern "C" int ls2fm_debug_acc_stamps(long long* host) {
 #endif
 
 // dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid; ls2fm_launch_scatter_zero must
-// have run on them before.
+// have run on them before.  add_into: the sums are ADDED to the tables' current values instead (entries without items untouched,
+// nothing zeroed beforehand): a second gradient producer, ordered behind the first one by the caller.
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo, int level_hi) {
+                                 hipStream_t stream, int level_lo, int level_hi, int add_into) {
     const bool dual = dtable2 != nullptr;
     const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
@@ -358,8 +363,10 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     const int base = h.plan.first[level_lo], blocks = h.plan.first[level_hi] - base;
     if (blocks <= 0) return LS2FM_OK;
     if (dual)
-        slab_accumulate_kernel<true><<<blocks, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, dtable2, base);
+        (add_into ? slab_accumulate_kernel<true, true> : slab_accumulate_kernel<true, false>)<<<blocks, kAccThreads, 0, stream>>>(
+            lv, h.plan, bm, sshift, dtable1, dtable2, base);
     else
-        slab_accumulate_kernel<false><<<blocks, kAccThreads, 0, stream>>>(lv, h.plan, bm, sshift, dtable1, nullptr, base);
+        (add_into ? slab_accumulate_kernel<false, true> : slab_accumulate_kernel<false, false>)<<<blocks, kAccThreads, 0, stream>>>(
+            lv, h.plan, bm, sshift, dtable1, nullptr, base);
     return ls2fm_launch_status();
 }

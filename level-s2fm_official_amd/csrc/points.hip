@@ -28,7 +28,7 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo = 0, int level_hi = -1);
+                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0);
 int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
                               const float* wg, hipStream_t stream);
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
@@ -204,6 +204,72 @@ extern "C" int64_t ls2fm_sdf_points_workspace_bytes(const ls2fm_field_desc* fiel
     return w.total * (int64_t)sizeof(float);
 }
 
+// ---- the stages of ls2fm_sdf_points_bwd, also driven by ls2fm_render_bwd for the backward of a traced depth (render_bwd.hip):
+// front = gather pass over the points (+ weight prep), points_bwd, the scans of the item counts; scatter = the table gradient.
+// zero_table: the table whose atomically flushed range the front's leading workgroups zero, or null (a caller that ADDS this
+// call's sums into a table another producer owns).
+int ls2fm_points_bwd_front(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params, const float* p,
+                           int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal, float* zero_table, bool want_dp,
+                           void* workspace, hipStream_t s, WsLayout* w_out, hipEvent_t rows_ready) {
+    const ls2fm_field_desc f1 = one_sample_field(field);
+    const FieldC fc = make_field_c(&f1);
+    const int L = grid->n_levels;
+    const WsLayout w = make_ws_layout(n, 1, L, L, 0);
+    float* ws = (float*)workspace;
+    const Packed* pk = (const Packed*)(ws + w.packed);
+    LevelScales lsc;
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L ? grid->scale[l] : 0.f;
+    // zero fills (leading workgroups of points_bwd): reduced weight-gradient accumulators; the atomically flushed (point-split
+    // coarse) levels of the table gradient
+    ZeroJob zero{};
+    zero.blocks = 16;
+    zero.a = reinterpret_cast<float4*>(ws + w.wg);
+    zero.na = (w.dbeta - w.wg) / 4;
+    if (zero_table) {
+        int64_t first = 0, count = 0;
+        ls2fm_scatter_zero_range(grid, w.p, false, &first, &count);
+        if (count > 0) { zero.b = reinterpret_cast<float4*>(zero_table + 2 * first); zero.nb = count / 2; }
+    }
+    ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
+    int st = ls2fm_launch_points_encode(&f1, grid, params, p, w, ws, s);
+    ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
+    if (st != LS2FM_OK) return st;
+    ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
+    points_bwd_kernel<<<(unsigned)((n + 255) / 256 + zero.blocks), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws,
+                                                                                want_dp, zero);
+    ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
+    // the per-point rows a weight-gradient kernel contracts are final here (the scans below only serve the table scatter)
+    if (rows_ready && hipEventRecord(rows_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+    ls2fm_prof_begin(LS2FM_PROF_BIN, s);
+    st = ls2fm_launch_post_shade(nullptr, nullptr, n, 1, grid, w.p, ws + w.bins, s);
+    ls2fm_prof_end(LS2FM_PROF_BIN, s);
+    if (w_out) *w_out = w;
+    return st;
+}
+
+// phase: 1 = sort the payloads (scatter_fill), 2 = sum them into `table` (slab_accumulate), 3 = both
+int ls2fm_points_bwd_scatter(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n, void* workspace, float* table,
+                             int add_into, hipStream_t s, int phase) {
+    const ls2fm_field_desc f1 = one_sample_field(field);
+    const FieldC fc = make_field_c(&f1);
+    const WsLayout w = make_ws_layout(n, 1, grid->n_levels, grid->n_levels, 0);
+    float* ws = (float*)workspace;
+    int st = LS2FM_OK;
+    if (phase & 1) {
+        ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
+        st = ls2fm_launch_scatter_fill(grid, fc, nullptr, nullptr, ws + w.bins, w.p, w.p_pad, ws + w.rec1, nullptr, ws + w.rpt, ws + w.smax,
+                                       n, 0, s);
+        ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
+        if (st != LS2FM_OK) return st;
+    }
+    if (phase & 2) {
+        ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
+        st = ls2fm_launch_slab_accumulate(grid, ws + w.bins, w.p, table, nullptr, s, 0, -1, add_into);
+        ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
+    }
+    return st;
+}
+
 extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                                     const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
                                     const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream) {
@@ -217,39 +283,15 @@ extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_g
     LS2FM_CHECK_ARG((reinterpret_cast<uintptr_t>(grads->sdf_table) & 15u) == 0);
     if (!workspace) return LS2FM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    WsLayout w;
+    int st = ls2fm_points_bwd_front(field, grid, params, p, n, d_sdf, d_feat, d_normal, grads->sdf_table, d_p != nullptr, workspace, s, &w,
+                                    nullptr);
+    if (st != LS2FM_OK) return st;
     const ls2fm_field_desc f1 = one_sample_field(field);
     const FieldC fc = make_field_c(&f1);
     const int L = grid->n_levels;
-    const WsLayout w = make_ws_layout(n, 1, L, L, 0);
     float* ws = (float*)workspace;
     const Packed* pk = (const Packed*)(ws + w.packed);
-    LevelScales lsc;
-    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L ? grid->scale[l] : 0.f;
-
-    // zero fills (leading workgroups of points_bwd): reduced weight-gradient accumulators; the atomically flushed (point-split
-    // coarse) levels of the table gradient
-    LS2FM_CHECK_ARG((reinterpret_cast<uintptr_t>(grads->sdf_table) & 15u) == 0);
-    ZeroJob zero{};
-    zero.blocks = 16;
-    zero.a = reinterpret_cast<float4*>(ws + w.wg);
-    zero.na = (w.dbeta - w.wg) / 4;
-    {
-        int64_t first = 0, count = 0;
-        ls2fm_scatter_zero_range(grid, w.p, false, &first, &count);
-        if (count > 0) { zero.b = reinterpret_cast<float4*>(grads->sdf_table + 2 * first); zero.nb = count / 2; }
-    }
-    ls2fm_prof_begin(LS2FM_PROF_ENCODE_SDF, s);
-    int st = ls2fm_launch_points_encode(&f1, grid, params, p, w, ws, s);
-    ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
-    if (st != LS2FM_OK) return st;
-    ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-    points_bwd_kernel<<<(unsigned)((n + 255) / 256 + zero.blocks), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws,
-                                                                                d_p != nullptr, zero);
-    ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
-    ls2fm_prof_begin(LS2FM_PROF_BIN, s);
-    st = ls2fm_launch_post_shade(nullptr, nullptr, n, 1, grid, w.p, ws + w.bins, s);
-    ls2fm_prof_end(LS2FM_PROF_BIN, s);
-    if (st != LS2FM_OK) return st;
 
     // fork: weight gradients (matrix cores) + weight-norm backward beside the table scatter
     SideCtx sc;
@@ -263,14 +305,7 @@ extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_g
     if (st == LS2FM_OK && forked && hipEventRecord(sc.join, sc.side) != hipSuccess) st = LS2FM_ERR_LAUNCH;
     if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
 
-    ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
-    st = ls2fm_launch_scatter_fill(grid, fc, nullptr, nullptr, ws + w.bins, w.p, w.p_pad, ws + w.rec1, nullptr, ws + w.rpt, ws + w.smax,
-                                   n, 0, s);
-    ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
-    if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
-    ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
-    st = ls2fm_launch_slab_accumulate(grid, ws + w.bins, w.p, grads->sdf_table, nullptr, s);
-    ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
+    st = ls2fm_points_bwd_scatter(field, grid, n, workspace, grads->sdf_table, 0, s, 3);
     if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
     if (d_p) {
         ls2fm_prof_begin(LS2FM_PROF_POSE, s);

@@ -59,16 +59,6 @@ wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_
     }
 }
 
-__global__ void __launch_bounds__(256)
-add_into_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 a = dst[i];
-        const float4 b = src[i];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        dst[i] = a;
-    }
-}
-
 }  // namespace
 
 // weight-norm backward of the SDF MLP alone (point queries, points.hip): tasks 0 and 1 of finalize_kernel
@@ -83,7 +73,9 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo = 0, int level_hi = -1);
+                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0);
+
+bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
 
 extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* sdf_grid,
                                 const ls2fm_grid_desc* rad_grid, const ls2fm_params* params, const float* center,
@@ -130,32 +122,40 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
                            dual ? grads->rad_table : nullptr, s);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
     if (opts && opts->depth_grad_ready && hipEventRecord((hipEvent_t)opts->depth_grad_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
-    // the tracing's own backward (ls2fm_depth_backward): a second internal branch, forked here -- d_depth_ref is final -- and
-    // joined in front of the final sum
+    // the tracing's own backward (ls2fm_depth_backward): a second internal branch, forked here -- d_depth_ref is final.  Its
+    // stages are those of ls2fm_sdf_points_bwd over the track points, MERGED into this call's own chains: the per-point rows it
+    // leaves (front: gather pass, points_bwd, scans) are contracted by this call's SDF weight-gradient kernel as extra tiles
+    // (no second wgrad_mlp / reduction / weight-norm backward -- whose 63 KB workgroups waited for a CU beside this call's), and
+    // its table gradient is ADDED into this call's table behind the main accumulate (no second table, no final sum kernel).
     const ls2fm_depth_backward* db = (opts && loss && loss->d_depth_ref) ? opts->depth_bwd : nullptr;
-    SideCtx sc2;
+    SideCtx sc1, sc2;
     bool forked2 = false;
+    Ls2fmWgradExtra extra{};
+    int64_t n_track = 0;
+    hipStream_t ds = s;
     if (db) {
-        LS2FM_CHECK_ARG(db->points && db->trips && db->gate && db->d_sdf && db->grads && db->workspace && db->k_max >= 1);
-        LS2FM_CHECK_ARG(!db->sum_into || (db->sum_from && db->sum_count % 4 == 0 &&
-                                          ((reinterpret_cast<uintptr_t>(db->sum_into) | reinterpret_cast<uintptr_t>(db->sum_from)) & 15u) == 0));
-        SideCtx sc1;
+        LS2FM_CHECK_ARG(db->points && db->trips && db->gate && db->d_sdf && db->workspace && db->k_max >= 1);
+        if (opts->n_level_groups > 1) return LS2FM_ERR_UNSUPPORTED;      // a group's slices would not be final at its event
+        n_track = n_rays * (int64_t)db->k_max;
+        if (n_track > LS2FM_MAX_RENDER_POINTS || !ls2fm_bins_levels_fit(sdf_grid, 0)) return LS2FM_ERR_UNSUPPORTED;
         // (a stream of its own: the side stream of THIS call's side stream)
         forked2 = ls2fm_side_stream(&sc1, s) && ls2fm_side_stream(&sc2, sc1.side) && hipEventRecord(sc2.fork, s) == hipSuccess &&
                   hipStreamWaitEvent(sc2.side, sc2.fork, 0) == hipSuccess;
-        hipStream_t ds = forked2 ? sc2.side : s;
+        ds = forked2 ? sc2.side : s;
         int st = ls2fm_trace_depth_bwd(loss->d_depth_ref, nullptr, db->trips, db->gate, n_rays, db->k_max, db->d_sdf, ds);
         if (st == LS2FM_OK)
-            st = ls2fm_sdf_points_bwd(field, sdf_grid, params, db->points, n_rays * (int64_t)db->k_max, db->d_sdf, nullptr, nullptr,
-                                      db->grads, nullptr, db->workspace, ds);
-        if (forked2 && hipEventRecord(sc2.join, sc2.side) != hipSuccess && st == LS2FM_OK) st = LS2FM_ERR_LAUNCH;
+            st = ls2fm_points_bwd_front(field, sdf_grid, params, db->points, n_track, db->d_sdf, nullptr, nullptr, nullptr, false,
+                                        db->workspace, ds, &extra.w, forked2 ? sc2.mid : nullptr);
+        extra.ws = (const float*)db->workspace;
+        if (forked2) extra.ready = sc2.mid;
+        if (st == LS2FM_OK) st = ls2fm_points_bwd_scatter(field, sdf_grid, n_track, db->workspace, nullptr, 0, ds, /*phase=*/1);
         if (st != LS2FM_OK) {
-            if (forked2) (void)hipStreamWaitEvent(s, sc2.join, 0);
+            if (forked2) { (void)hipEventRecord(sc2.join, sc2.side); (void)hipStreamWaitEvent(s, sc2.join, 0); }
             return st;
         }
     }
     auto fail = [&](bool f1, const SideCtx& c1, int st) {       // error after the forks: every branch is joined back into `s`
-        if (forked2) (void)hipStreamWaitEvent(s, sc2.join, 0);
+        if (forked2) { (void)hipEventRecord(sc2.join, sc2.side); (void)hipStreamWaitEvent(s, sc2.join, 0); }
         return ls2fm_join_on_error(f1, c1, s, st);
     };
     if (want_pose) {
@@ -168,7 +168,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
     Ls2fmWgradParts parts{};
-    ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts);
+    if (ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts, db ? &extra : nullptr) != LS2FM_OK)
+        return fail(forked, sc, LS2FM_ERR_LAUNCH);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     {   // sum of the partials + finalize tasks, one launch (the ticket word: slack of the reduced-gradient block, zeroed above)
         static_assert(WgLayout::total % 64 != 0 && (WgLayout::total + 63) / 64 * 64 - WgLayout::total >= 1, "ticket word in the block's slack");
@@ -205,12 +206,16 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
                 return fail(forked, sc, LS2FM_ERR_LAUNCH);
         }
     }
-    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     if (db) {
-        if (forked2 && hipStreamWaitEvent(s, sc2.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;
-        if (db->sum_into && db->sum_count > 0)
-            add_into_kernel<<<1024, 256, 0, s>>>(reinterpret_cast<float4*>(db->sum_into), reinterpret_cast<const float4*>(db->sum_from),
-                                                db->sum_count / 4);
+        // the tracing's table gradient, added into the table the scatter above has just written: behind it (an event when the
+        // branch has a stream of its own)
+        if (forked2 && (hipEventRecord(sc1.mid, s) != hipSuccess || hipStreamWaitEvent(ds, sc1.mid, 0) != hipSuccess))
+            return fail(forked, sc, LS2FM_ERR_LAUNCH);
+        const int st = ls2fm_points_bwd_scatter(field, sdf_grid, n_track, db->workspace, grads->sdf_table, 1, ds, /*phase=*/2);
+        if (st != LS2FM_OK) return fail(forked, sc, st);
+        if (forked2 && (hipEventRecord(sc2.join, sc2.side) != hipSuccess || hipStreamWaitEvent(s, sc2.join, 0) != hipSuccess))
+            return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
     }
+    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();
 }

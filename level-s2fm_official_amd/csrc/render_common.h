@@ -337,9 +337,19 @@ int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, co
 // wgrad_mlp.hip.  `defer`: leave the sum of the partials to the caller (render_bwd.hip runs it in the finalize launch) and
 // describe them here
 struct Ls2fmWgradParts { const float* sdf; const float* geo; const float* dec; int nb_mlp, nb_dec, dual; };
+// `extra`: a second set of per-sample rows (another workspace of the same layout family: the point-query backward of a traced
+// depth, points.hip) whose samples the SDF MLP's kernel contracts in the same launch, behind `ready` (event or null)
+struct Ls2fmWgradExtra { WsLayout w; const float* ws; void* ready; };
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
                            const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only = false,
-                           Ls2fmWgradParts* defer = nullptr);
+                           Ls2fmWgradParts* defer = nullptr, const Ls2fmWgradExtra* extra = nullptr);
+
+// points.hip: the stages of ls2fm_sdf_points_bwd (see there)
+int ls2fm_points_bwd_front(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params, const float* p,
+                           int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal, float* zero_table, bool want_dp,
+                           void* workspace, hipStream_t s, WsLayout* w_out, hipEvent_t rows_ready);
+int ls2fm_points_bwd_scatter(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n, void* workspace, float* table,
+                             int add_into, hipStream_t s, int phase);
 
 // shade_fwd.hip
 int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const Packed* pk, const float* center, const float* ray,

@@ -27,21 +27,22 @@ constexpr int kLd = 20;                          // floats per LDS tile row: 16 
 constexpr int kRowsU = 36, kRowsGf = 20;
 constexpr int kXRows = 2 * kRowsU + kRowsGf + 3 * 16;            // u, v, gf, da, gj, h
 
-template <bool GEO>
+// EXTRA: tiles beyond n_tiles come from a second set of rows (wb, wsb).  A template parameter, not a run-time branch: the
+// plain instantiation keeps the register allocation (234 / 144) the step's co-scheduling with the scatter was measured with --
+// with the selects compiled in for every launch the benchmark step took 0.562 instead of 0.541 ms (A/B on one box).
+template <bool GEO, bool EXTRA>
 __global__ void __launch_bounds__(kWmThreads, 2)
 wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, const float* __restrict__ center,
-                 const float* __restrict__ ray, const float* __restrict__ ws, float* __restrict__ part, int n_tiles) {
+                 const float* __restrict__ ray, const float* __restrict__ ws, float* __restrict__ part, int n_tiles,
+                 WsLayout wb, const float* __restrict__ wsb, int n_tiles_b) {
     constexpr int NT = GEO ? 4 : 5;
     constexpr int R = GEO ? kRegsGeo : kRegsSdf;
     __shared__ float s_w[4 * 9 * 64 + 4 * 5 * 64 + 4 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float s_x[kWmWaves][kXRows * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jl = lane & 15, g = lane >> 4;
-    const uint32_t P32 = (uint32_t)w.p_pad;
-    const float* __restrict__ f_e = ws + (GEO ? w.e2 : w.e1);
-    const float* __restrict__ f_v = ws + w.v;
-    const float* __restrict__ f_gf = ws + (GEO ? w.gf2 : w.gf);
-    const float* __restrict__ f_p3 = ws + w.p3;
+    // tiles [0, n_tiles) come from (w, ws), tiles [n_tiles, n_all) from the second set (wb, wsb) -- wave-uniform selects
+    const int n_all = EXTRA ? n_tiles + n_tiles_b : n_tiles;
     {
         const float* src = GEO ? &pk->bg.w0a[0][0][0] : &pk->bs.w0a[0][0][0];      // w0a then w1ta are contiguous
         constexpr int n01 = 4 * 9 * 64 + 4 * NT * 64;
@@ -78,8 +79,16 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
     // loaded while the current tile is being contracted: a wave is alone on its SIMD here (one workgroup per CU beside the
     // scatter kernels), so nothing else hides the ~2 us of a dependent global load
     auto load_tile = [&](int tile, float (&ub)[9], float (&vb)[9], float (&gfb)[5], float& gf0) {
-        const uint32_t i = (uint32_t)tile * 16u + (uint32_t)jl;
-        const bool live = tile < n_tiles && (int64_t)i < w.p;
+        const bool second = EXTRA && tile >= n_tiles;
+        // (field-by-field scalar selects: a selected struct reference would be copied to scratch)
+        const float* __restrict__ base = second ? wsb : ws;
+        const uint32_t P32 = (uint32_t)(second ? wb.p_pad : w.p_pad);
+        const float* __restrict__ f_e = base + (second ? (GEO ? wb.e2 : wb.e1) : (GEO ? w.e2 : w.e1));
+        const float* __restrict__ f_v = base + (second ? wb.v : w.v);
+        const float* __restrict__ f_gf = base + (second ? (GEO ? wb.gf2 : wb.gf) : (GEO ? w.gf2 : w.gf));
+        const float* __restrict__ f_p3 = base + (second ? wb.p3 : w.p3);
+        const uint32_t i = (uint32_t)(second ? tile - n_tiles : tile) * 16u + (uint32_t)jl;
+        const bool live = tile < n_all && (int64_t)i < (second ? wb.p : w.p);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int c = 4 * t + g;
@@ -105,7 +114,7 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
     float ub_n[9], vb_n[9], gfb_n[5], gf0_n;
     load_tile(blockIdx.x * kWmWaves + wave, ub_n, vb_n, gfb_n, gf0_n);
 #pragma unroll 1
-    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles; tile += tile_step) {
+    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_all; tile += tile_step) {
         float ub[9], vb[9], gfb[5];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { ub[t] = ub_n[t]; vb[t] = vb_n[t]; }
@@ -305,9 +314,11 @@ int64_t ls2fm_wgrad_mlp_part_floats(int dual) {
 
 // enqueue every weight-gradient kernel of the backward (+ the reduction of their partials) on `s`
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
-                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only, Ls2fmWgradParts* defer) {
+                           const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only, Ls2fmWgradParts* defer,
+                           const Ls2fmWgradExtra* extra) {
     const int n_tiles = (int)((w.p + 15) / 16);
-    int blocks = (n_tiles + kWmWaves - 1) / kWmWaves;
+    const int n_tiles_b = extra ? (int)((extra->w.p + 15) / 16) : 0;
+    int blocks = (n_tiles + n_tiles_b + kWmWaves - 1) / kWmWaves;
     if (blocks > kWgradMlpBlocks) blocks = kWgradMlpBlocks;
     const int dec_blocks = blocks;
     float* part1 = ws + w.mpart;
@@ -317,11 +328,16 @@ int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const W
     // on the other queue -- measured (A/B on one box, graph replay of the benchmark step) 0.579 vs 0.583 ms
     if (dual) {
         ls2fm_prof_begin(LS2FM_PROF_WGRAD_GEO, s);
-        wgrad_mlp_kernel<true><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles);
+        wgrad_mlp_kernel<true, false><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles, w, ws, 0);
         ls2fm_prof_end(LS2FM_PROF_WGRAD_GEO, s);
     }
+    // the second set's rows are written on another stream: its samples join this launch behind their event
+    if (extra && extra->ready && hipStreamWaitEvent(s, (hipEvent_t)extra->ready, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;
     ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, s);
-    wgrad_mlp_kernel<false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles);
+    if (extra)
+        wgrad_mlp_kernel<false, true><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles, extra->w, extra->ws, n_tiles_b);
+    else
+        wgrad_mlp_kernel<false, false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles, w, ws, 0);
     ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
     ls2fm_prof_begin(LS2FM_PROF_WGRAD_TAIL, s);
     if (sdf_only) {          // point queries: no decoder columns, the SDF MLP's partials only (blocks [0, kRegsSdf) of the reduction)

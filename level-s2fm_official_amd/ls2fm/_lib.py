@@ -89,7 +89,7 @@ LOSS_EIK_FROM_GT, LOSS_MSE_FROM_GT = 1, 2
 
 class DepthBackward(Structure):
     _fields_ = [("points", c_void_p), ("trips", c_void_p), ("gate", c_void_p), ("k_max", c_int32), ("d_sdf", c_void_p),
-                ("grads", c_void_p), ("workspace", c_void_p), ("sum_into", c_void_p), ("sum_from", c_void_p), ("sum_count", c_int64)]
+                ("workspace", c_void_p)]
 
 
 class RenderOpts(Structure):

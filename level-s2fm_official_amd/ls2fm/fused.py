@@ -490,11 +490,11 @@ class _Render(torch.autograd.Function):
             if dref is not None and (ctx.needs_input_grad[2] or node is not None):
                 d_dref = torch.empty_like(dref)
             if node is not None and d_dref is not None:
-                # the traced depth's own backward (20 k track points through the point-query machinery: ~0.18 ms) runs INSIDE this
-                # call, on an internal branch beside the scatter and the weight-gradient chain (ls2fm_depth_backward); its
-                # gradients -- the SDF field's first seven tensors, same flat layout -- are added into this node's buffer at the
-                # end: autograd sees ONE producer per parameter and launches no accumulation kernels of its own
-                keep = node.prepare(flat)
+                # the traced depth's own backward (20 k track points through the point-query machinery) runs INSIDE this call,
+                # merged into its chains (ls2fm_depth_backward): the points' rows join the SDF weight-gradient kernel as extra
+                # tiles, their table gradient is added into this node's table behind its scatter -- autograd sees ONE producer
+                # per parameter and launches no accumulation kernels of its own
+                keep = node.prepare()
                 opts.depth_bwd = ctypes.pointer(keep[0])
             lspec = _loss_struct(fl, dref, None, sums, d_terms, d_total, d_dref)
             opts.loss = ctypes.pointer(lspec)
@@ -523,7 +523,10 @@ def render(renderer, opt, center, ray, sdf_field, rad_field, loss=None, d_points
                                             or (d_points is not None and d_points.requires_grad))
     if loss is not None and loss.depth_node is not None and d_points is not None:
         # the render's backward runs the tracing node's backward itself (beside its scatter): no autograd edge to d_points
-        if not (loss.depth_node.matches(pl.ts) and d_points.requires_grad):
+        # (not with the level-group overlap of a multi-GPU run: a group's table slices must be final at its event)
+        from . import dist as _dist
+        grouped = _dist.is_distributed() and int(getattr(pl.ts[0], "_ls2fm_overlap_groups", 0)) > 1
+        if grouped or not (loss.depth_node.matches(pl.ts) and d_points.requires_grad):
             loss.depth_node = None
         else:
             d_points = d_points.detach()
@@ -758,15 +761,12 @@ class TracedDepthNode:
         """the tracing's parameters are the first tensors of the render's list (same flat-buffer offsets)"""
         return len(render_params) >= len(self.params) and all(a is b for a, b in zip(self.params, render_params))
 
-    def prepare(self, render_flat):
-        """ls2fm_depth_backward for a render backward whose flat gradient buffer is `render_flat` -> (struct, tensors to keep
-        alive until the call has been enqueued)"""
+    def prepare(self):
+        """ls2fm_depth_backward for a render backward -> (struct, tensors to keep alive until the call has been enqueued)"""
         lib = _lib.load()
         fdesc, gdesc, beta_speed, n_rays, k_max = self.meta
         dev = self.p.device
         n = n_rays * k_max
-        flat2, grads2 = flat_gradient_views(self.params, attach=False)
-        gstruct = _params_struct(grads2, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
         ws_bytes = lib.ls2fm_sdf_points_workspace_bytes(ctypes.byref(fdesc), ctypes.byref(gdesc), n)
         if ws_bytes < 0:
             check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
@@ -774,11 +774,8 @@ class TracedDepthNode:
         d_sdf = torch.empty(n, device=dev)
         db = _lib.DepthBackward()
         db.points, db.trips, db.gate, db.k_max = ptr(self.p), ptr(self.trips), ptr(self.gate), k_max
-        db.d_sdf, db.grads, db.workspace = ptr(d_sdf), ctypes.cast(ctypes.pointer(gstruct), ctypes.c_void_p), ptr(ws)
-        # everything in front of beta's segment: a point query has no beta gradient
-        db.sum_into, db.sum_from = ptr(render_flat), ptr(flat2)
-        db.sum_count = sum((t.numel() + 3) // 4 * 4 for t in self.params[:7])
-        return db, (flat2, gstruct, ws, d_sdf)
+        db.d_sdf, db.workspace = ptr(d_sdf), ptr(ws)
+        return db, (ws, d_sdf)
 
 
 def traced_depth(sdf_field, track, trips, near, far, rgbs_gt=None, trace_ws=None, launch_stream=None):
