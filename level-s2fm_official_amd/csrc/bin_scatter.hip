@@ -161,6 +161,32 @@ __device__ __forceinline__ void add_fixed(u64* slot, float v, float to_fixed) {
     atomicAdd(slot, (u64)__float2ll_rn(v * to_fixed));        // two's complement: integer sums are exact
 }
 
+// Two features in ONE 64-bit add: 32-bit two's complement halves, value = hi * 2^32 + lo.  The low half's borrows and carries
+// run into the high half; decoding undoes them (lo = sign-extended low word, hi = (total - lo) >> 32), which is exact as long
+// as each half's SUM fits 32 bits -- guaranteed by the quantum (packed_quantum_of).  Halves the LDS atomics of the sole-owner
+// levels (12 of 16 at the benchmark); the price is the resolution of a contribution: 2^-(30 - hits bits) of the level's bound
+// (>= 17 bits for the <= 8 k items of a slab) instead of exact -- still order-independent and deterministic.
+__device__ __forceinline__ void add_fixed2(u64* slot, float v0, float v1, float to_fixed) {
+    const int lo = __float2int_rn(v0 * to_fixed), hi = __float2int_rn(v1 * to_fixed);
+    atomicAdd(slot, ((u64)(uint32_t)hi << 32) + (u64)(long long)lo);
+}
+__device__ __forceinline__ void unpack_fixed2(u64 total, float to_float, float& v0, float& v1) {
+    const int lo = (int)(uint32_t)(total & 0xFFFFFFFFull);
+    const int hi = (int)(((long long)total - (long long)lo) >> 32);
+    v0 = (float)lo * to_float;
+    v1 = (float)hi * to_float;
+}
+// hits: an upper bound of the contributions to one entry (the items this workgroup streams)
+__device__ __forceinline__ void packed_quantum_of(float bound, int hits, float& to_fixed, float& to_float) {
+    int e_bound = 0;
+    if (bound > 0.f) (void)frexpf(bound, &e_bound);             // bound < 2^e_bound
+    const int hb = 32 - __clz(hits > 1 ? hits : 1);            // hits < 2^hb
+    int shift = 30 - hb - e_bound;                              // |sum| <= hits * bound < 2^(hb + e_bound) -> * 2^shift < 2^30
+    shift = shift > 126 ? 126 : (shift < -126 ? -126 : shift);
+    to_fixed = ldexpf(1.0f, shift);
+    to_float = ldexpf(1.0f, -shift);
+}
+
 __device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float& to_fixed, double& to_float) {
     // contributions are bounded by 2^e (e from the level's bound), sums by 2^(e + headroom): value * 2^shift fits in 62 bits
     int e_bound = 0;
@@ -177,6 +203,15 @@ __device__ long long g_acc_stamps[8 * 4096];
 #define ACC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
 #define ACC_STAMP(k) do {} while (0)
+#endif
+
+// -DLS2FM_PACKED_ACC=true: sole-owner slabs with short lists keep each feature PAIR in one 64-bit accumulator (add_fixed2).
+// Measured (C2): slab_accumulate alone 117.5 -> 95.7 us, the step unchanged (0.547 = 0.547 ms, A/B on one box: the
+// weight-gradient chain ends the backward, not the scatter); contributions below 2^-17 of the level's bound are lost (54 of
+// 265 884 non-zero entries of the full-size golden become zero, which Adam does not forgive: it turns ANY non-zero gradient
+// into a step of the learning rate), and lists of 16 k items or more (8192-ray batches) cannot use it.  Off.
+#ifndef LS2FM_PACKED_ACC
+#define LS2FM_PACKED_ACC false
 #endif
 
 template <bool DUAL, bool ADD_INTO>
@@ -209,13 +244,23 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
         q0 = reinterpret_cast<const uint4*>(list + j_lo + tid)[0];
         q1 = reinterpret_cast<const uint4*>(list + j_lo + tid)[1];
     }
-    const int n_slots = F * (int)(hi - lo);
+    // sole owner of its entries and a short list: the feature pairs share a 64-bit accumulator (add_fixed2)
+    constexpr bool packing = LS2FM_PACKED_ACC;
+    const bool packed = packing && parts == 1 && j_hi - j_lo < (1 << 14);
+    const int n_slots = (packed ? F / 2 : F) * (int)(hi - lo);
     for (int e = tid; e < n_slots; e += kAccThreads) acc[e] = 0ull;
     // bound of a single contribution on this level (reduced over the rays by scatter_fill); second grid: rows 16..31
     float to_fixed1, to_fixed2;
     double to_float1, to_float2;
-    quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
-    quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
+    float pk_float1 = 0.f, pk_float2 = 0.f;
+    if (packed) {
+        packed_quantum_of(bm.level_bound[l], j_hi - j_lo, to_fixed1, pk_float1);
+        packed_quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, j_hi - j_lo, to_fixed2, pk_float2);
+        to_float1 = to_float2 = 0.0;
+    } else {
+        quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
+        quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
+    }
     __syncthreads();
     ACC_STAMP(1);
 
@@ -231,6 +276,19 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
         const float b0 = __uint_as_float(q1.x), b1 = __uint_as_float(q1.y);
         const float c0 = __uint_as_float(q1.z), c1 = __uint_as_float(q1.w);
         const float px0 = 1.0f - wx;
+        if (packed) {
+            if (i0 != 0xFFFFu) {
+                u64* slot = acc + (F / 2) * i0;
+                add_fixed2(slot, fmaf(px0, a0, -b0), fmaf(px0, a1, -b1), to_fixed1);
+                if (DUAL) add_fixed2(slot + 1, px0 * c0, px0 * c1, to_fixed2);
+            }
+            if (i1 != 0xFFFFu) {
+                u64* slot = acc + (F / 2) * i1;
+                add_fixed2(slot, fmaf(wx, a0, b0), fmaf(wx, a1, b1), to_fixed1);
+                if (DUAL) add_fixed2(slot + 1, wx * c0, wx * c1, to_fixed2);
+            }
+            continue;
+        }
         if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
             u64* slot = acc + F * i0;
             add_fixed(slot + 0, fmaf(px0, a0, -b0), to_fixed1);
@@ -249,6 +307,19 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
     // ---- flush: fixed point -> fp32 (one rounding of the exact sum); slot e = F * entry + feature
     float* dst1 = dtable1 + 2ull * (lv.offset[l] + lo);
     float* dst2 = DUAL ? dtable2 + 2ull * (lv.offset[l] + lo) : nullptr;
+    if (packed) {                                        // slot e = (F / 2) * entry + grid: one float2 per slot (parts == 1)
+        for (int e = tid; e < n_slots; e += kAccThreads) {
+            const int entry = DUAL ? e >> 1 : e;
+            const bool second = DUAL && (e & 1);
+            float2 v;
+            unpack_fixed2(acc[e], second ? pk_float2 : pk_float1, v.x, v.y);
+            float2* dst = reinterpret_cast<float2*>((second ? dst2 : dst1) + 2 * entry);
+            if (add_into) {
+                if (acc[e] != 0ull) { float2 o = *dst; o.x += v.x; o.y += v.y; *dst = o; }
+            } else *dst = v;
+        }
+        return;
+    }
     for (int e = tid; e < n_slots; e += kAccThreads) {
         const int entry = e / F, f = e % F;
         const bool second = DUAL && f >= 2;

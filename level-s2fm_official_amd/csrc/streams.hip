@@ -43,7 +43,13 @@ bool ls2fm_side_stream(SideCtx* out, hipStream_t caller) {
     if (it == g_ctx.end()) {
         if (g_ctx.size() >= kMaxContexts) return false;
         StreamCtx c;
-        if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return false;
+        // LS2FM_SIDE_PRIORITY (experiment): -1 = the side chains on a high-priority queue, 1 = low
+        static const int prio = [] { const char* e = getenv("LS2FM_SIDE_PRIORITY"); return e ? atoi(e) : 0; }();
+        if (prio != 0) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least, hi = greatest priority (numerically smaller)
+            if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, prio < 0 ? hi : lo) != hipSuccess) return false;
+        } else if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c.mid, hipEventDisableTiming) != hipSuccess)
