@@ -436,7 +436,7 @@ extern "C" int ls2fm_interleave_tables(const float* sdf_table, const float* rad_
 
 // cost-balanced cut of the walking order [grid 1 levels .., grid 2 levels ..] x chunks into 8 XCD pieces
 static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid_desc* g2, int l2, int n_samples, int n_chunks,
-                             bool counting, int* most) {
+                             bool counting, int* most, bool interleaved = false) {
     double cost[2 * LS2FM_MAX_LEVELS], total = 0.0;
     // Relative cost of a pass-level = summed workgroup durations INSIDE a training step (tools/enc_xcd_instep.py: the launch
     // follows a backward, the L2s no longer hold the table slices; a fine hashed level of the second grid = 1): dense levels
@@ -445,22 +445,30 @@ static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid
     // the scatter's items: hashed levels +10 %, dense levels +50 % (their increments collide in the LDS histogram).  Two grids
     // (same geometry) alternate level by level in the walking order, so every XCD's piece holds both kinds (with "all of grid
     // 1, then all of grid 2" the XCDs owning grid 1 finished 20 us late).
-    static double cm[4] = {0.27, 1.5, 1.1, 0.45};
+    // ONE pass over the entry-interleaved table (16-byte gathers, a level slice is 8 MB: twice an XCD's L2): the coarse levels
+    // are relatively cheaper than in the two-table pass -- measured 0.20-0.30 (dense), 0.61, 0.90, then 1.0 -- with the
+    // two-table constants the XCD that owns them finished 21 us before the last one (86 vs 107 us).
+    static double cm2[6] = {0.27, 1.5, 1.1, 0.45, 0.45, 1.0};     // two tables:  dense, first_dense, first_hashed, slope, intercept, top
+    static double cmi[6] = {0.31, 1.0, 1.0, 1.0, -0.156, 1.0};    // interleaved
     static const bool cm_env = [] {
-        const char* e = getenv("LS2FM_CM");                      // experiments: "dense,first_dense,first_hashed,slope"
-        if (e) sscanf(e, "%lf,%lf,%lf,%lf", &cm[0], &cm[1], &cm[2], &cm[3]);
+        const char* e = getenv("LS2FM_CM");                      // experiments: "dense,first_dense,first_hashed,slope,intercept"
+        if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &cm2[0], &cm2[1], &cm2[2], &cm2[3], &cm2[4], &cm2[5]);
+        const char* e2 = getenv("LS2FM_CMI");
+        if (e2) sscanf(e2, "%lf,%lf,%lf,%lf,%lf,%lf", &cmi[0], &cmi[1], &cmi[2], &cmi[3], &cmi[4], &cmi[5]);
         return e != nullptr;
     }();
     (void)cm_env;
+    const double* cm = interleaved ? cmi : cm2;
     const int n_pl = l1 + l2;
     for (int pl = 0; pl < n_pl; ++pl) {
         const bool second = l2 > 0 && (pl & 1);
         const ls2fm_grid_desc* gd = second ? g2 : g1;
         const int l = l2 > 0 ? pl >> 1 : pl;
         const double rho = (double)gd->scale[l] / (double)n_samples;
-        const double h = 0.45 + cm[3] * log2(1.0 + rho);
-        cost[pl] = gd->hashed[l] ? (h > 1.0 ? 1.0 : h) : cm[0];
+        const double h = cm[4] + cm[3] * log2(1.0 + rho);
+        cost[pl] = gd->hashed[l] ? (h > 1.0 ? 1.0 : (h < 0.1 ? 0.1 : h)) : cm[0];
         if (!second) cost[pl] *= gd->hashed[l] ? (counting ? cm[2] : 1.05) : (counting ? cm[1] : 1.1);
+        if (l >= (l2 > 0 ? l2 : l1) - 2) cost[pl] *= cm[5];        // the two finest levels
         total += cost[pl];
     }
     XcdPlan plan;
@@ -570,7 +578,8 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     const bool pair = dual && !interleaved;      // both grids, one launch
     const int enc_span = dual ? LS2FM_PROF_ENCODE_PAIR : LS2FM_PROF_ENCODE_SDF;       // both grids in this launch (two tables or the interleaved copy)
     int most = 0;
-    const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, prepare_bwd, &most);
+    const XcdPlan plan = make_xcd_plan(sdf_grid, L1, pair ? rad_grid : nullptr, pair ? L2 : 0, field->n_samples, n_chunks, prepare_bwd, &most,
+                                       interleaved);
     EncodeExtras ex;
     ex.params = *params;
     ex.in_dim = 3 + 2 * L1; ex.in_dim2 = 3 + 2 * L2; ex.rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1); ex.dual = dual;

@@ -47,6 +47,11 @@ for _ in range(6):
         sums[pl] += buf[pl] / 100.0 / 6
 avg = [sum(e[x] for e in ends) / len(ends) for x in range(8)]
 print("per XCD end (us after the first start, mean of %d steps): %s  max %.1f" % (len(ends), [round(v, 1) for v in avg], max(avg)))
+if not any(sums[16:]):                          # one pass over the entry-interleaved table: 16 pass-levels
+    ref = sum(sums[10:16]) / 6
+    print("summed workgroup durations per level / fine hashed level (interleaved table):")
+    print("  ", [round(v / ref, 2) for v in sums[:16]])
+    sys.exit(0)
 ref = sum(sums[17::2][-6:]) / 6                 # fine hashed levels of the second grid
 print("summed workgroup durations per pass-level / fine hashed level of grid 2 (walking order: level 0 grid 1, level 0 grid 2, ...):")
 print("  grid 1:", [round(v / ref, 2) for v in sums[0::2]])
