@@ -193,7 +193,9 @@ __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2
 }
 
 __global__ void __launch_bounds__(256)
-prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad, Packed* __restrict__ out) {
+prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad, Packed* __restrict__ out,
+                    int32_t* __restrict__ zero_word) {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;        // e.g. a tracing call's trip counter: no launch of its own
     prep_weights_task(P, in_dim, in_dim2, rad_in, dual, with_rad, out, (int)blockIdx.x, (int)threadIdx.x, 256);
 }
 
@@ -494,9 +496,9 @@ static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid
 }
 
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
-int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream) {
+int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream, int32_t* zero_word) {
     ls2fm_prof_begin(LS2FM_PROF_PREP, stream);
-    prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out);      // task 0 only
+    prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out, zero_word);      // task 0 only
     ls2fm_prof_end(LS2FM_PROF_PREP, stream);
     return ls2fm_launch_status();
 }

@@ -11,7 +11,7 @@
 
 #include "render_common.h"
 
-int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream);
+int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream, int32_t* zero_word = nullptr);
 
 namespace {
 
@@ -450,17 +450,12 @@ extern "C" int ls2fm_sdf_volume(const ls2fm_field_desc* field, const ls2fm_grid_
     return ls2fm_launch_status();
 }
 
-namespace {
-__global__ void zero_word_kernel(int32_t* w) { *w = 0; }
-}
-
 extern "C" int ls2fm_sdf_prepare(const ls2fm_grid_desc* grid, const ls2fm_params* params, void* workspace, int32_t* zero_word,
                                  void* stream) {
     LS2FM_CHECK_ARG(grid_desc_ok(grid) && params && params->sdf_mlp[0].weight_v && params->sdf_mlp[1].weight_v);
     if (!workspace) return LS2FM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (zero_word) zero_word_kernel<<<1, 1, 0, s>>>(zero_word);
-    return ls2fm_launch_prep_sdf(params, grid->n_levels, (Packed*)workspace, s);
+    return ls2fm_launch_prep_sdf(params, grid->n_levels, (Packed*)workspace, s, zero_word);     // the word is zeroed by the same launch
 }
 
 static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,

@@ -206,10 +206,11 @@ class RenderStage:
             out = self._graph.replay()
             self.optim.replayed(1)
             return out
-        for dst, src in zip(self._in, (centers, rays, rgbs_gt)):
+        srcs = (centers, rays, rgbs_gt)
+        for dst, src in zip(self._in, srcs):
             if dst.shape != src.shape:
                 raise RuntimeError("ls2fm.stage.RenderStage(capture=True): the batch shape is fixed by the first step")
-            dst.copy_(src)
+        torch._foreach_copy_(list(self._in), [s.detach() for s in srcs])         # one launch for the three inputs
         out = self._graph.replay()
         self.optim.replayed(1)
         return out
