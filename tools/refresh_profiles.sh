@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for c in C3 C4 C5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/r03_bench_$c.json 2>/dev/null; done
+for c in C1 C3 C4 C5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/r03_bench_$c.json 2>/dev/null; done
+python bench.py --inference --rays 8192 --no-cpu-baseline > gpurun_out/r03_bench_inference_8192rays.json 2>/dev/null
 python bench.py --single-field --no-cpu-baseline > gpurun_out/r03_bench_single_field.json 2>/dev/null
 python bench.py --rays 4096 --no-cpu-baseline > gpurun_out/r03_bench_4096rays.json 2>/dev/null
 python bench.py --rays 16384 --no-cpu-baseline > gpurun_out/r03_bench_16384rays.json 2>/dev/null
