@@ -152,7 +152,7 @@ class SDF(nn.Module):
             track = [p_s]
         return torch.stack(track, dim=1), t_end[-1], trips
 
-    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None, want_samples=False, launch_stream=None):
+    def _sphere_tracing_static(self, o, d, shape2, rgbs_gt=None, want_samples=False, launch_stream=None, sample_u=None):
         """sphere_tracing without the host round trip for the trip count K (hipGraph-capturable, ls2fm.stage): the kernel leaves K
         on the device and runs every ray for iters_max trips anyway; the differentiable depth sums the first K track points
         through a device-side mask (K = 0: the single current point, SDF.py:201-202) -- one fused node, ls2fm.fused.traced_depth.
@@ -181,7 +181,8 @@ class SDF(nn.Module):
             with torch.no_grad():
                 n_rays, it = o.shape[0], int(self.iters_max)
                 k = trips.long().reshape(1)
-                u = torch.rand(n_rays, device=o.device)
+                # sample_u [R]: the draw of SDF.py:217 given by the caller (parity tests replay the reference's)
+                u = torch.rand(n_rays, device=o.device) if sample_u is None else sample_u.reshape(-1).to(o.device)
                 t_up = torch.minimum(1.5 * t_end.gather(1, k.expand(n_rays, 1))[:, 0], far)          # far end after K trips
                 along = o + ((1 - u) * t_up + u * near)[:, None] * d
                 pick = torch.randperm(n_rays, device=o.device)[:4096]
@@ -193,7 +194,7 @@ class SDF(nn.Module):
 
     def sphere_tracing(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129),
                        n_secant_steps=8, depth_range=(0.0, 2.4), max_points=3500000, rad=1.0, iter=0,
-                       impl="fused", static_trips=False, rgbs_gt=None, want_samples=False, launch_stream=None):
+                       impl="fused", static_trips=False, rgbs_gt=None, want_samples=False, launch_stream=None, sample_u=None):
         """ray0, ray_direction [B,R,3] -> (d_pred [B,R], sdf_last [B*R], sampled_pts [1, <=4096+B*R, 3],
         finish_mask [B*R,1]).  `d_pred = near + sum_k sdf(track_k)` is differentiable w.r.t. the SDF
         parameters; the root-find itself runs without a graph.  Unused reference arguments are accepted."""
@@ -201,7 +202,8 @@ class SDF(nn.Module):
         o = ray0.reshape(-1, 3)
         d = ray_direction.reshape(-1, 3)
         if static_trips:
-            return self._sphere_tracing_static(o, d, shape2, rgbs_gt, want_samples=want_samples, launch_stream=launch_stream)
+            return self._sphere_tracing_static(o, d, shape2, rgbs_gt, want_samples=want_samples, launch_stream=launch_stream,
+                                               sample_u=sample_u)
         with torch.no_grad():
             if impl == "fused" and fused.available(self, o):
                 near, far, pts_tracks, t_end, trips = fused.sphere_trace(self, o.detach(), d.detach())
@@ -217,7 +219,7 @@ class SDF(nn.Module):
         extent = self.bound_max.reshape(-1)[0] - self.bound_min.reshape(-1)[0]
         finish_mask = sdf_tracks[:, -1, :].abs() < extent / 10 / self.opt.Res
         # random eikonal sample points (RNG stays on the host side in torch, same call order as the reference)
-        u = torch.rand_like(d_pred)
+        u = torch.rand_like(d_pred) if sample_u is None else sample_u.reshape(d_pred.shape).to(d_pred.device)
         t_up = 1.5 * t_end.view(*shape2)
         t_up = torch.where(t_up > far2, far2, t_up)
         t_rand = (1 - u) * t_up + u * near.view(*shape2)

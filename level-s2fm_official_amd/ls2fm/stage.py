@@ -449,6 +449,123 @@ class InitLoop:
         return (self._surface[0] + self._surface[1]) / 2, kept
 
 
+class GeoInitLoop:
+    """`Registration.geo_init_nf` (pipelines/Registration.py:133-296): a NEW view against registered ones, SDF field only, no
+    render.  Per iteration ONE sphere tracing over the matched key points of every (new, registered) pair from both sides; for
+    the matches without a 3-D point the two traced points are re-projected into the other view -- outliers by the finish flags
+    and the 1x / 2x / 4x `reproj_max` bounds, as device-side masks (the reference's `(~mask).sum() > 0` is a select here) --,
+    for the matches that have one the traced point is compared with it; sdf_surf over the tracks' last values and the existing
+    points near the surface; eikonal over the existing points, the track points and the random along-ray points of
+    `sphere_tracing` (fixed shape + mask, ls2fm.models.SDF); one backward; Adam over the SDF field; ExponentialLR with the
+    reference's factor (lr_end / lr) ** (1 / max_iter) over its 5 * max_iter iterations.  `triangulate()` is the block after
+    the loop.
+
+    pairs: per registered view a dict  view (index into poses), kp_new [n,2], kp_src [n,2] (row j <-> row j: the inlier
+    matches), point_id [n] long (index into xyzs of the 3-D point the new view's key point already has, -1: none)."""
+
+    def __init__(self, opt, sdf_field, poses, intrinsic, new_view, pairs, xyzs, weights, lr_sdf, lr_sdf_end, max_iter, reproj_max=15.0):
+        get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
+        w = lambda k: 0.0 if get(k) is None else 10.0 ** float(get(k))
+        self.w_reproj, self.w_tracing, self.w_surf, self.w_eik = w("reproj_error"), w("tracing_loss"), w("sdf_surf"), w("eikonal_loss")
+        self.sdf, self.intrinsic, self.xyzs = sdf_field, intrinsic, xyzs
+        self.poses = (poses if poses.shape[-1] == 4 else _cam.lie.se3_to_SE3(poses)).detach()
+        self.new_view, self.reproj_max = int(new_view), float(reproj_max)
+        self.n_iters = 5 * int(max_iter)                                          # Registration.py:140
+        self.pairs = []
+        centers, rays = [[], []], [[], []]
+        at = 0
+        with torch.no_grad():
+            for pr in pairs:
+                n = pr["kp_new"].shape[0]
+                c0, r0 = keypoint_rays(self.poses[self.new_view], intrinsic, pr["kp_new"])        # the new view's side (ret0)
+                c1, r1 = keypoint_rays(self.poses[int(pr["view"])], intrinsic, pr["kp_src"])     # the registered view's side (ret1)
+                centers[0].append(c0); rays[0].append(r0); centers[1].append(c1); rays[1].append(r1)
+                pid = pr["point_id"].long()
+                self.pairs.append(dict(view=int(pr["view"]), lo=at, hi=at + n, kp_new=pr["kp_new"], kp_src=pr["kp_src"], has=pid >= 0,
+                                       target=xyzs[pid.clamp_min(0)], n_has=int((pid >= 0).sum())))
+                at += n
+            self.center = torch.cat([torch.cat(centers[0], dim=1), torch.cat(centers[1], dim=1)], dim=0)     # [2, sum n, 3]
+            self.ray = torch.cat([torch.cat(rays[0], dim=1), torch.cat(rays[1], dim=1)], dim=0)
+        self.n_frames = sum(1 for p in self.pairs if p["n_has"] > 0)
+        self.params = [p for p in sdf_field.parameters() if p.requires_grad]
+        self.optim = FusedAdam([dict(params=self.params, lr=lr_sdf)], lr=lr_sdf,
+                               scheduled_gamma=(lr_sdf_end / lr_sdf) ** (1.0 / int(max_iter)))       # Registration.py:33
+        self._one = torch.ones((), device=xyzs.device)
+        self._last = None
+        self._keys = ("loss_all", "reproj_error", "tracing_loss", "sdf_surf", "eikonal_loss")
+
+    def _project(self, pts, view):
+        uv = _cam.cam2img(_cam.world2cam(pts.unsqueeze(0), self.poses[view:view + 1]), self.intrinsic.unsqueeze(0))[0]
+        return (uv / (uv[..., 2:] + 1e-6))[..., :2]
+
+    def step(self, sample_u=None):
+        for p in self.params:
+            p.grad = None
+        sdf = self.sdf
+        d, sdf_last, sampled, fin = sdf.sphere_tracing(self.center, self.ray, sdf, static_trips=True, want_samples=True, sample_u=sample_u)
+        pts = self.center + self.ray * d.reshape(2, -1, 1)                                         # Registration.py:190
+        fin = fin.reshape(2, -1).bool()
+        zero = torch.zeros((), device=pts.device)
+        reproj, n_reproj, tracing, last = zero, zero, zero, []
+        rmax = self.reproj_max
+        for pr in self.pairs:
+            p0, p1 = pts[0, pr["lo"]:pr["hi"]], pts[1, pr["lo"]:pr["hi"]]
+            f0, f1 = fin[0, pr["lo"]:pr["hi"]], fin[1, pr["lo"]:pr["hi"]]
+            e0 = (self._project(p0, pr["view"]) - pr["kp_src"]).norm(dim=-1)                      # new view's point in the registered view
+            e1 = (self._project(p1, self.new_view) - pr["kp_new"]).norm(dim=-1)
+            bad = ((f0 & (e0 > rmax)) & (f1 & (e1 > rmax))) | ((e0 > 2 * rmax) & (e1 > 2 * rmax)) | (e0 > 4 * rmax) | (e1 > 4 * rmax)
+            keep = (~pr["has"]) & ~bad
+            cnt = keep.sum()
+            some = cnt > 0
+            pair_err = ((e0 * keep).sum() + (e1 * keep).sum()) / (2 * cnt.clamp_min(1))
+            reproj = reproj + torch.where(some, pair_err, zero)
+            n_reproj = n_reproj + some
+            dist = (pr["target"] - p0).norm(dim=-1)
+            if pr["n_has"] > 0:
+                tracing = tracing + (dist * pr["has"]).sum() / pr["n_has"]
+            last.append((p0.detach(), p1.detach(), f0, f1, keep, dist.detach()))
+        # the existing points: near-surface ones enter sdf_surf, all of them the eikonal term (Registration.py:257-262)
+        sdf_exist = sdf.infer_sdf(self.xyzs).reshape(-1)
+        near = sdf_exist.detach().abs() < float(sdf.sdf_threshold)
+        grad_exist = sdf.gradient(self.xyzs).norm(dim=-1).reshape(-1)
+        sdf_surf = ((sdf_exist.abs() * near).sum() + sdf_last.reshape(-1).abs().sum()) / (near.sum() + sdf_last.numel())
+        live = sdf.last_sample_mask.reshape(-1)
+        grad_sampled = sdf.gradient(sampled.reshape(-1, 3)).norm(dim=-1).reshape(-1)
+        eik = ((grad_exist - 1).abs().sum() + ((grad_sampled - 1).abs() * live).sum()) / (grad_exist.numel() + live.sum())
+        any_reproj = n_reproj > 0
+        ret = dict(reproj_error=torch.where(any_reproj, reproj / n_reproj.clamp_min(1), zero),
+                   tracing_loss=tracing / max(self.n_frames, 1), sdf_surf=sdf_surf, eikonal_loss=eik)
+        ret["loss_all"] = (self.w_reproj * ret["reproj_error"] + self.w_tracing * ret["tracing_loss"] + self.w_surf * sdf_surf
+                           + self.w_eik * eik)
+        ret["loss_all"].backward(gradient=self._one)
+        self.optim.step()
+        self._last = last
+        return ret
+
+    def run(self, n_iters=None, draws=None):
+        logs = {k: [] for k in self._keys}
+        for it in range(self.n_iters if n_iters is None else int(n_iters)):
+            ret = self.step(draws[it] if draws is not None else None)
+            for k in self._keys:
+                logs[k].append(ret[k].detach().reshape(()).clone())
+        return {("all" if k == "loss_all" else k): torch.stack(v) for k, v in logs.items()}
+
+    @torch.no_grad()
+    def triangulate(self):
+        """-> per pair (points [n,3], kept [n] bool): the block after the loop (Registration.py:271-294) on the LAST iteration's
+        traced points -- a new match becomes a 3-D point (the mean of its two traced points) when the two agree within mean + std of
+        the existing matches' tracing distances, or both tracks finished"""
+        if self._last is None:
+            raise RuntimeError("ls2fm.stage.GeoInitLoop.triangulate: run at least one step first")
+        record = torch.cat([dist[pr["has"]] for pr, (_, _, _, _, _, dist) in zip(self.pairs, self._last)])
+        thr = record.mean() + record.std()
+        out = []
+        for p0, p1, f0, f1, keep, _ in self._last:
+            diff = (p0 - p1).norm(dim=-1)
+            out.append(((p0 + p1) / 2, keep & ((diff <= thr) | (f0 & f1))))
+        return out
+
+
 class BALoop:
     """`BA` in mode "sfm_refine" with several cameras (pipelines/BA.py:24-218; optim_split: rotation / translation parameters
     with their own rates, BA.py:66-75): per iteration the POINT side -- tracked points projected onto the surface
