@@ -52,8 +52,25 @@ def cam2img(X, cam_intr):
     return X @ cam_intr.transpose(-1, -2)
 
 
+def _inverse_intrinsic(cam_intr):
+    """K^-1, remembered ON the tensor that owns the matrix's storage (per version and view geometry): the loops call this
+    every iteration with the same constant matrix, and a 3 x 3 inverse is eight launch-bound solver kernels"""
+    if cam_intr.requires_grad:
+        return torch.linalg.inv(cam_intr)
+    owner = cam_intr._base if cam_intr._base is not None else cam_intr
+    key = (cam_intr._version, tuple(cam_intr.shape), tuple(cam_intr.stride()), cam_intr.storage_offset())
+    memo = getattr(owner, "_ls2fm_inverse", None)
+    if memo is None or memo[0] != key:
+        memo = (key, torch.linalg.inv(cam_intr))
+        try:
+            owner._ls2fm_inverse = memo
+        except Exception:
+            pass
+    return memo[1]
+
+
 def img2cam(X, cam_intr):
-    return X @ torch.linalg.inv(cam_intr).transpose(-1, -2)
+    return X @ _inverse_intrinsic(cam_intr).transpose(-1, -2)
 
 
 def mesh_grid(opt=None, H=None, W=None, device=None):
@@ -83,23 +100,43 @@ def get_center_and_ray(opt, pose, intr=None, rays_idx=None, xy_grid=None):
 
 
 # ------------------------------------------------------------------------------------------------ se(3)
-def _series(theta, first_denominator, step):
-    """sum_i (-1)^i theta^(2i) / d_i with d_0 = first_denominator and d_{i+1} = d_i step(i + 1) -- the Taylor series of A, B, C
-    (11 terms: exact to fp32 for |theta| < pi, and smooth through theta = 0 where the closed forms are 0 / 0)"""
-    total = torch.zeros_like(theta)
-    denom = float(first_denominator)
-    for i in range(11):
-        if i > 0:
-            denom *= step(i)
-        total = total + ((-1.0) ** i) * theta ** (2 * i) / denom
-    return total
+_N_TERMS = 11
+_SERIES = {}
+
+
+def _series_constants(device, dtype):
+    """exponents 2i [11], signs (-1)^i [11] and the denominators [3, 11] of the Taylor series of  A = sin(t) / t  (d_i = (2i + 1)!),
+    B = (1 - cos t) / t^2  ((2i + 2)!),  C = (t - sin t) / t^3  ((2i + 3)!), the denominators built by the running products the
+    reference's loops use (11 terms: exact to fp32 for |theta| < pi, and smooth through theta = 0 where the closed forms are 0 / 0)"""
+    key = (str(device), dtype)
+    if key not in _SERIES:
+        rows = []
+        for first, step in ((1.0, lambda i: (2 * i) * (2 * i + 1)), (2.0, lambda i: (2 * i + 1) * (2 * i + 2)),
+                            (6.0, lambda i: (2 * i + 2) * (2 * i + 3))):
+            denom, row = float(first), []
+            for i in range(_N_TERMS):
+                if i > 0:
+                    denom *= step(i)
+                row.append(denom)
+            rows.append(row)
+        _SERIES[key] = (torch.arange(_N_TERMS, device=device, dtype=dtype) * 2,
+                        torch.tensor([(-1.0) ** i for i in range(_N_TERMS)], device=device, dtype=dtype),
+                        torch.tensor(rows, dtype=torch.float64).to(device=device, dtype=dtype))
+    return _SERIES[key]
 
 
 def _abc(theta):
-    A = _series(theta, 1.0, lambda i: (2 * i) * (2 * i + 1))             # sin x / x
-    B = _series(theta, 2.0, lambda i: (2 * i + 1) * (2 * i + 2))         # (1 - cos x) / x^2
-    C = _series(theta, 6.0, lambda i: (2 * i + 2) * (2 * i + 3))         # (x - sin x) / x^3
-    return A, B, C
+    """theta [..., 1, 1] -> A, B, C of the same shape.  The reference evaluates each series term by term,
+    total += (-1)^i theta^(2i) / d_i; as a Python loop that is ~130 launch-bound elementwise kernels per call and as many again
+    in its backward -- a captured BA iteration spent more launches here than in the render.  Same terms, same left-to-right
+    order of the sum (the unstable trajectories of the loop goldens notice a re-associated sum), but the powers and quotients
+    of all three series are formed at once: 13 kernels."""
+    expo, sign, denom = _series_constants(theta.device, theta.dtype)
+    terms = (sign * theta.unsqueeze(-1) ** expo).unsqueeze(-2) / denom                    # [..., 1, 1, 3, 11]
+    total = terms[..., 0]
+    for i in range(1, _N_TERMS):
+        total = total + terms[..., i]
+    return total[..., 0], total[..., 1], total[..., 2]
 
 
 def skew(w):
