@@ -29,12 +29,39 @@ from .utils import camera as _cam
 _TRACE_STREAMS = {}
 
 
-def _trace_stream(device):
+def _trace_stream(device, slot=0):
+    """the stream(s) sphere tracings are launched on beside the render's forward: slot 0 the render rays', slots 1.. the key-point
+    tracings of a loop's extra terms (latency-bound kernels of a few workgroups each: they overlap each other almost for free)"""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    if idx not in _TRACE_STREAMS:
-        _TRACE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    return _TRACE_STREAMS[idx]
+    if (idx, slot) not in _TRACE_STREAMS:
+        _TRACE_STREAMS[(idx, slot)] = torch.cuda.Stream(device=idx)
+    return _TRACE_STREAMS[(idx, slot)]
+
+
+class _EarlyTrace:
+    """A key-point sphere tracing launched AHEAD of the render on a stream of its own (the render does not depend on it), its
+    results picked up where the loss term is formed.  Holds the call's autograd-node record until the next launch: that record
+    owns every tensor the other stream touches (no record_stream under hipGraph capture, see ls2fm.fused.TracedDepthNode)."""
+
+    def __init__(self, sdf_field, slot):
+        self.sdf, self.slot = sdf_field, slot
+        self.out = self.ready = self.node = None
+
+    def launch(self, center, ray):
+        side = _trace_stream(center.device, self.slot)
+        self.out = self.sdf.sphere_tracing(center, ray, self.sdf, static_trips=True, launch_stream=side)
+        self.node = getattr(self.sdf, "last_trace_node", None)
+        self.ready = torch.cuda.Event()
+        self.ready.record(side)
+
+    def take(self):
+        """-> the tracing's outputs (joined into the current stream), or None when nothing was launched"""
+        if self.out is None:
+            return None
+        torch.cuda.current_stream(self.out[0].device).wait_event(self.ready)
+        out, self.out = self.out, None
+        return out
 
 
 def render_losses(opt, renderer, sdf_field, rad_field, head, centers, rays, rgbs_gt, static_trips=False, eikonal_over="bg"):
@@ -118,7 +145,7 @@ class RenderStage:
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
                  eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None,
-                 sharded=False, async_gather=False):
+                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None):
         """lr / lr_color: the reference's two field groups (`[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(),
         lr_color}]`, BA.py:79-83; lr_color=None: one rate); extra_params: tensors (one more group at `lr`) or
         `{"params": [...], "lr": x}` dicts (the pose groups of BA.py:60-75).  ONE ExponentialLR factor for all groups,
@@ -155,6 +182,13 @@ class RenderStage:
             self.optim = FusedAdam(groups, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)
         self.capture = capture
         self.extra_loss = extra_loss
+        # called at the start of a step, before the render is enqueued: work of the extra terms that does not depend on the
+        # render (their key-point tracings) starts here, on streams of its own, and runs beside the render's forward
+        self.extra_prepare = extra_prepare
+        # `() -> (centers, rays, rgbs_gt)` evaluated INSIDE the step (and inside its capture): a loop's ray pick and pose algebra
+        # from device tensors it updates in place -- `step()` then takes no arguments and a captured iteration has no eager
+        # preamble (the loops' ~50 launch-bound kernels of camera arithmetic per iteration were half of their time)
+        self.input_fn = input_fn
         self.eikonal_over = eikonal_over
         self.reducer = reducer
         self._graph = None
@@ -169,6 +203,8 @@ class RenderStage:
                                "head normalises by global counts, the gradients must be summed over the ranks before the update")
         for p in self.params:
             p.grad = None
+        if self.extra_prepare is not None and static_trips:
+            self.extra_prepare()
         ret = render_losses(self.opt, self.renderer, self.sdf, self.rad, self.head, centers, rays, rgbs_gt, static_trips=static_trips,
                             eikonal_over=self.eikonal_over)
         if self.extra_loss is not None:
@@ -180,7 +216,18 @@ class RenderStage:
         self.optim.step()
         return ret
 
-    def step(self, centers, rays, rgbs_gt):
+    def step(self, centers=None, rays=None, rgbs_gt=None):
+        if centers is None:
+            if self.input_fn is None:
+                raise TypeError("ls2fm.stage.RenderStage.step(): centers, rays, rgbs_gt -- or construct the stage with input_fn")
+            if not self.capture:
+                centers, rays, rgbs_gt = self.input_fn()
+            elif self._graph is None:
+                return self._capture(lambda: self._eager(*self.input_fn(), static_trips=True))
+            else:
+                out = self._graph.replay()
+                self.optim.replayed(1)
+                return out
         if not self.capture:
             # the static form (trip count stays on the device, traced depth + masks as one fused node) whenever the fused tracing
             # kernel serves this field: no host round trip per step, ~40 fewer launches; else the reference-shaped form
@@ -188,29 +235,32 @@ class RenderStage:
             static = _fused.available(self.sdf, centers)
             return self._eager(centers, rays, rgbs_gt, static_trips=static)
         if self._graph is None:
-            from . import dist as _dist
-            if _dist.is_distributed():
-                raise NotImplementedError("ls2fm.stage.RenderStage(capture=True) under torch.distributed: the step's collectives "
-                                          "(loss counts, trip count, gradient exchange) are not replayed from a hipGraph; use capture=False")
-            from .graph import CapturedStep
             self._in = (centers.detach().clone(), rays.detach().clone(), rgbs_gt.detach().clone())
-            # the capture warms the step up by running it for real: parameters, Adam state and the schedule are put back
-            # afterwards (in place: the graph holds their addresses), so that this call, too, is exactly one step
-            snap = self._snapshot()
-            # the captured step's own Adam keeps the interleaved table copy current (ls2fm.fused): no rebuild inside the graph
-            from . import fused as _fused
-            _fused.trust_mirror_in_capture(self.sdf, self.rad)
-            self._graph = CapturedStep(lambda: self._eager(*self._in, static_trips=True), params=self.params)
-            self._restore(snap)
-            _fused.sync_mirror(self.sdf, self.rad)          # the restore rewrote the tables behind the graph's back
-            out = self._graph.replay()
-            self.optim.replayed(1)
-            return out
+            return self._capture(lambda: self._eager(*self._in, static_trips=True))
         srcs = (centers, rays, rgbs_gt)
         for dst, src in zip(self._in, srcs):
             if dst.shape != src.shape:
                 raise RuntimeError("ls2fm.stage.RenderStage(capture=True): the batch shape is fixed by the first step")
         torch._foreach_copy_(list(self._in), [s.detach() for s in srcs])         # one launch for the three inputs
+        out = self._graph.replay()
+        self.optim.replayed(1)
+        return out
+
+    def _capture(self, fn):
+        from . import dist as _dist
+        if _dist.is_distributed():
+            raise NotImplementedError("ls2fm.stage.RenderStage(capture=True) under torch.distributed: the step's collectives "
+                                      "(loss counts, trip count, gradient exchange) are not replayed from a hipGraph; use capture=False")
+        from .graph import CapturedStep
+        # the capture warms the step up by running it for real: parameters, Adam state and the schedule are put back
+        # afterwards (in place: the graph holds their addresses), so that this call, too, is exactly one step
+        snap = self._snapshot()
+        # the captured step's own Adam keeps the interleaved table copy current (ls2fm.fused): no rebuild inside the graph
+        from . import fused as _fused
+        _fused.trust_mirror_in_capture(self.sdf, self.rad)
+        self._graph = CapturedStep(fn, params=self.params)
+        self._restore(snap)
+        _fused.sync_mirror(self.sdf, self.rad)          # the restore rewrote the tables behind the graph's back
         out = self._graph.replay()
         self.optim.replayed(1)
         return out
@@ -304,16 +354,35 @@ class TracingConsistency:
         self.center, self.ray = torch.zeros(1, n, 3, device=dev), torch.zeros(1, n, 3, device=dev)
         self.target, self.live = torch.zeros(n, 3, device=dev), torch.zeros(n, device=dev)
         self.use_sdfs = True                   # False: `ret.sdfs` was set by the caller before the render (BA.py:122, Camera.py:474)
+        self._early = _EarlyTrace(sdf_field, slot=1)
+
+    def prepare(self):
+        """launch the tracing now (RenderStage(extra_prepare=...)): it runs beside the render's forward"""
+        if self.static:
+            self._early.launch(self.center, self.ray)
 
     @torch.no_grad()
-    def select(self, view, poses):
+    def select(self, view, poses, fixed=None):
+        """view: a Python int, or a DEVICE long tensor [1] (then nothing here touches the host: the selection can sit inside a
+        captured step and follow the tensor's value at every replay).  fixed: a `_FixedPoseRays` of these poses."""
+        if torch.is_tensor(view):
+            pick = lambda t: t.index_select(0, view)[0]
+            if fixed is not None:
+                c, r = fixed.kp_center.index_select(0, view), fixed.kp_ray.index_select(0, view)
+            else:
+                c, r = keypoint_rays(pick(poses), self.views.intrinsic, pick(self.views.kp_pad))
+            self.center.copy_(c); self.ray.copy_(r)
+            self.target.copy_(self.views.xyzs[pick(self.views.id_pad)])
+            self.live.copy_(pick(self.views.kp_live))
+            return
         c, r = keypoint_rays(poses[view], self.views.intrinsic, self.views.kp_pad[view])
         self.center.copy_(c); self.ray.copy_(r)
         self.target.copy_(self.views.xyzs[self.views.id_pad[view]])
         self.live.copy_(self.views.kp_live[view])
 
     def __call__(self, ret):
-        d, sdf_last, _, _ = self.sdf.sphere_tracing(self.center, self.ray, self.sdf, static_trips=self.static)
+        early = self._early.take()
+        d, sdf_last = early[:2] if early is not None else self.sdf.sphere_tracing(self.center, self.ray, self.sdf, static_trips=self.static)[:2]
         surface = self.center[0] + self.ray[0] * d.reshape(-1, 1)
         count = self.live.sum()
         ret["tracing_loss"] = ((self.target - surface).norm(dim=-1) * self.live).sum() / count
@@ -328,6 +397,23 @@ def _pick_rays(views, poses, rays_idx):
     """CameraSet.render's ray pick for given poses (Camera.py:457-463): the same pixels in every view"""
     centers, rays = _cam.get_center_and_ray(None, poses, intr=views.intrinsic.unsqueeze(0), rays_idx=rays_idx, xy_grid=views.grid)
     return centers, rays, views.images[:, rays_idx, :]
+
+
+class _FixedPoseRays:
+    """Loops whose poses do not move (Refine, Init): the rays of EVERY pixel and of every (padded) key point are formed once;
+    an iteration then only gathers its pick -- three index kernels instead of the ~40 launch-bound ones of the pinhole / pose
+    algebra (which cost a captured iteration 0.3 ms).  Same arithmetic as `_pick_rays` / `keypoint_rays`: a ray does not depend on
+    which other pixels are picked with it."""
+
+    def __init__(self, views, poses):
+        with torch.no_grad():
+            self.centers, self.rays = _cam.get_center_and_ray(None, poses, intr=views.intrinsic.unsqueeze(0), rays_idx=None, xy_grid=views.grid)
+            kc, kr = zip(*[keypoint_rays(poses[v], views.intrinsic, views.kp_pad[v]) for v in range(poses.shape[0])])
+            self.kp_center, self.kp_ray = torch.cat(kc, dim=0), torch.cat(kr, dim=0)              # [V, n_max, 3]
+        self.views = views
+
+    def pick(self, rays_idx):
+        return self.centers[:, rays_idx, :], self.rays[:, rays_idx, :], self.views.images[:, rays_idx, :]
 
 
 class RefineLoop:
@@ -349,18 +435,27 @@ class RefineLoop:
         static = _fused.available(sdf_field, views.images) if static_trips is None else static_trips
         self.extra = TracingConsistency(sdf_field, views, get("tracing_loss"), get("sdf_surf"), static_trips=static)
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
-                                 lr_color=lr_color, capture=capture, extra_loss=self.extra, eikonal_over="all")
+                                 lr_color=lr_color, capture=capture, extra_loss=self.extra, eikonal_over="all", extra_prepare=self.extra.prepare,
+                                 input_fn=self._inputs)
         self.poses = views.poses if views.poses.shape[-1] == 4 else _cam.lie.se3_to_SE3(views.poses)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss")
+        # an iteration's picks as device tensors, updated in place: the ray pick and the key-point rays are formed INSIDE the step
+        dev = self.poses.device
+        self._idx = torch.zeros(self.rand_rays // self.poses.shape[0], dtype=torch.long, device=dev)
+        self._view = torch.zeros(1, dtype=torch.long, device=dev)
+        self._fixed = _FixedPoseRays(views, self.poses)
+
+    def _inputs(self):
+        self.extra.select(self._view, self.poses, fixed=self._fixed)
+        return self._fixed.pick(self._idx)
 
     def step(self, rays_idx=None, view=None):
         V = self.poses.shape[0]
         if rays_idx is None:
             rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // V]
-        view = random.randint(0, V - 1) if view is None else int(view)
-        self.extra.select(view, self.poses)
-        centers, rays, rgbs_gt = _pick_rays(self.views, self.poses, rays_idx)
-        return self.stage.step(centers, rays, rgbs_gt)
+        self._idx.copy_(rays_idx)
+        self._view.fill_(random.randint(0, V - 1) if view is None else int(view))
+        return self.stage.step()
 
     def run(self, n_iters=None, picks=None):
         logs = {k: [] for k in self._keys}
@@ -398,16 +493,26 @@ class InitLoop:
         with torch.no_grad():              # the poses do not move during the loop: the key points' rays are formed once
             self._kp_rays = [keypoint_rays(self.poses[v], views.intrinsic, views.keypoints[v]) for v in range(2)]
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
-                                 lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="all")
+                                 lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="all", extra_prepare=self._prepare,
+                                 input_fn=lambda: self._fixed.pick(self._idx))
+        self._idx = torch.zeros(self.rand_rays // 2, dtype=torch.long, device=self.poses.device)
+        self._fixed = _FixedPoseRays(views, self.poses)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "reproj_error")
         self._surface = self._finish = None
+        self._early = [_EarlyTrace(sdf_field, slot=1), _EarlyTrace(sdf_field, slot=2)]
+
+    def _prepare(self):
+        if self.static:
+            for v in range(2):
+                self._early[v].launch(*self._kp_rays[v])
 
     def _extra(self, ret):
         """the explicit-match terms (Initialization.py:154-160, 252-255), already weighted"""
         errs, sdfs, surface, finish = [], [], [], []
         for v in range(2):
             center, ray = self._kp_rays[v]
-            d, sdf_last, _, fin = self.sdf.sphere_tracing(center, ray, self.sdf, static_trips=self.static)
+            early = self._early[v].take()
+            d, sdf_last, _, fin = early if early is not None else self.sdf.sphere_tracing(center, ray, self.sdf, static_trips=self.static)
             pts = center + ray * d.reshape(1, -1, 1)                                             # Camera.py:136
             o = 1 - v
             uv = _cam.cam2img(_cam.world2cam(pts, self.poses[o:o + 1]), self.views.intrinsic.unsqueeze(0))
@@ -424,8 +529,8 @@ class InitLoop:
     def step(self, rays_idx=None):
         if rays_idx is None:
             rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // 2]
-        centers, rays, rgbs_gt = _pick_rays(self.views, self.poses, rays_idx)
-        return self.stage.step(centers, rays, rgbs_gt)
+        self._idx.copy_(rays_idx)
+        return self.stage.step()
 
     def run(self, n_iters=None, picks=None):
         logs = {k: [] for k in self._keys}
@@ -600,12 +705,21 @@ class BALoop:
         self.tracing.use_sdfs = False
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="bg",
-                                 extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)])
+                                 extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)],
+                                 extra_prepare=self.tracing.prepare, input_fn=self._inputs)
+        self._idx = torch.zeros(self.rand_rays // se3.shape[0], dtype=torch.long, device=se3.device)
+        self._view = torch.zeros(1, dtype=torch.long, device=se3.device)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")
         self._render_poses = torch.zeros(se3.shape[0], 3, 4, device=se3.device)
         # the key-point rays of the tracing consistency come from the CAMERAS' own poses (Camera.get_pts3D -> get_pose,
         # Camera.py:131), which the loop only writes back after its last iteration (BA.py:184-185): fixed during the loop
         self._camera_poses = _cam.lie.se3_to_SE3(se3).detach()
+
+    def _inputs(self):
+        with torch.no_grad():
+            self._render_poses.copy_(_cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1)))      # detached (BA.py:150-151)
+        self.tracing.select(self._view, self._camera_poses)
+        return _pick_rays(self.views, self._render_poses, self._idx)
 
     def _extra(self, ret):
         """the terms BA.run_ba forms outside the render (BA.py:119-147) + the tracing consistency, already weighted"""
@@ -631,12 +745,9 @@ class BALoop:
         V = self.rot.shape[0]
         if rays_idx is None:
             rays_idx = torch.randperm(self.views.H * self.views.W, device=self.rot.device)[: self.rand_rays // V]
-        view = random.randint(0, V - 1) if view is None else int(view)
-        with torch.no_grad():
-            self._render_poses.copy_(_cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1)))      # detached (BA.py:150-151)
-        self.tracing.select(view, self._camera_poses)
-        centers, rays, rgbs_gt = _pick_rays(self.views, self._render_poses, rays_idx)
-        ret = self.stage.step(centers, rays, rgbs_gt)
+        self._idx.copy_(rays_idx)
+        self._view.fill_(random.randint(0, V - 1) if view is None else int(view))
+        ret = self.stage.step()
         with torch.no_grad():
             self.xyzs_all[self.obs_point] = self._new_points                                     # BA.py:181
         return ret

@@ -55,15 +55,19 @@ def timed(loop, k=60):
 W_REF = dict(eikonal_loss=2, rgb=3, DC_Loss=0, tracing_loss=2, sdf_surf=2)
 W_BA = dict(reproj_error=0, eikonal_loss=2, sdf_surf=2, rgb=3, DC_Loss=0, tracing_loss=1)
 W_INIT = dict(reproj_error=0, eikonal_loss=2, sdf_surf=2, rgb=3, DC_Loss=0)
+ONLY = os.environ.get("LS2FM_LOOPS", "Refine,Init,BA").split(",")       # e.g. LS2FM_LOOPS=Refine for tools/loop_timeline.py
 for capture in (False, True):
+  if "Refine" in ONLY:
     opt, sdf, rad, ren, views = scene()
     dt = timed(stage.RefineLoop(opt, ren, sdf, rad, views, weights=W_REF, lr_sdf=1e-3, lr_sdf_end=5e-4, lr_color=1e-3, max_iter=500,
                                 rand_rays=rays, capture=capture))
     print(f"RefineLoop  {'captured' if capture else 'eager   '} {dt * 1e3:7.3f} ms/iteration", flush=True)
+  if "Init" in ONLY:
     opt, sdf, rad, ren, views = scene()
     dt = timed(stage.InitLoop(opt, ren, sdf, rad, views, weights=W_INIT, lr_sdf=1e-3, lr_sdf_end=1e-4, lr_color=1e-2, max_iter=500,
                               rand_rays=rays, capture=capture))
     print(f"InitLoop    {'captured' if capture else 'eager   '} {dt * 1e3:7.3f} ms/iteration", flush=True)
+  if "BA" in ONLY:
     opt, sdf, rad, ren, views = scene()
     dt = timed(stage.BALoop(opt, ren, sdf, rad, views, weights=W_BA, lr_sdf=1e-4, lr_sdf_end=5e-5, lr_color=1e-3, lr_pose_r=5e-3, lr_pose_t=1e-2,
                             max_iter=500, rand_rays=rays, capture=capture))
