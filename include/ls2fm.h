@@ -362,6 +362,27 @@ int ls2fm_trace_depth_bwd(const float* d_dpred, const float* d_sdf_last, const i
                           int64_t n_rays, int32_t k_max, float* d_sdf_tracks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The re-projection term of a bundle-adjustment iteration and its gradient.
+ * Replaces: the per-observation block of BA.run_ba (pipelines/BA.py:126-147) -- world2cam / cam2img of the surface-projected
+ * tracked points through the live poses, the pixel error against their key points, the on-surface / finite mask, and the
+ * robust mean of BA.compute_loss (BA.py:199-202) -- ~100 launch-bound PyTorch kernels per iteration with their autograd.
+ *   points [n,3] (world); poses [n_views,3,4] world-to-camera (DEVICE); observations sorted by view: view v owns
+ *   [view_start[v], view_start[v+1]) (DEVICE int32 [n_views+1]); intrinsic: HOST float[9], row-major K; obs_uv [n,2];
+ *   sdf [n] or NULL: an observation counts when |sdf| < sdf_bound and its projection is not infinite.
+ *   fwd -> err [n] (0 where not counted), on uint8 [n], sums DEVICE double[4] = {sum robust, sum err, count, reproj} with
+ *   robust = 2 log(1 + err^2 / 4), reproj = 0.5 mean(robust) + 0.5 mean(err) over the counted ones (0 if none).
+ *   bwd: d_reproj DEVICE float[1] -> d_points [n,3], d_poses [n_views,3,4] (overwritten; fixed-order sums, no atomics).
+ *   workspace: ls2fm_reproject_workspace_bytes(n_views).
+ */
+int64_t ls2fm_reproject_workspace_bytes(int32_t n_views);
+int ls2fm_reproject_fwd(const float* points, const float* poses, const int32_t* view_start, int32_t n_views,
+                        const float* intrinsic, const float* obs_uv, const float* sdf, float sdf_bound, int64_t n,
+                        float* err, uint8_t* on, double* sums, void* workspace, void* stream);
+int ls2fm_reproject_bwd(const float* points, const float* poses, const int32_t* view_start, int32_t n_views,
+                        const float* intrinsic, const float* obs_uv, const float* sdf, float sdf_bound, int64_t n,
+                        const double* sums, const float* d_reproj, float* d_points, float* d_poses, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Loss head over the renderer's outputs: the scalar terms the reference's stages form
  * right after Renderer.forward, in one kernel each way instead of ~35 launch-bound PyTorch kernels.
  * Replaces: rgb L1 `l1_loss(rgb, rgbs_gt)` (pipelines/Camera.py:535); eikonal `l1_loss(norm(normals[mask]), 1)`

@@ -1,0 +1,164 @@
+// The re-projection term of a bundle-adjustment iteration (pipelines/BA.py:126-147, 199-202): tracked 3-D points, seen through the
+// LIVE poses, against their key points -- per observation
+//      x_c = R_v x + t_v ;  u = K x_c ;  uv = u_xy / (u_z + 1e-6) ;  err = || uv - key point ||
+//      counted when |sdf(x)| < bound and uv is not infinite ;  robust = 2 log(1 + err^2 / 4)
+//      reproj = 0.5 mean(robust) + 0.5 mean(err) over the counted observations (0 when there is none)
+// and its gradient w.r.t. the points and the poses.  As torch ops (gather of one pose per observation, two batched matrix
+// products, divisions, norm, log, three selects, four reductions -- and autograd's mirror of all of them) this was ~100 of the
+// ~450 launch-bound kernels of a captured BA iteration.  Observations are SORTED BY VIEW (view v owns [view_start[v],
+// view_start[v + 1])): one workgroup per view, fixed-order reductions -- the pose gradients are deterministic (no atomics).
+#include "render_common.h"
+
+namespace {
+
+constexpr int kRpThreads = 256;
+
+struct Camera3 { float k[9]; };
+
+struct Obs {                       // forward quantities of one observation
+    float xc[3], u[3], e[2], err, inv;
+    bool on;
+};
+
+__device__ __forceinline__ Obs project(const float* __restrict__ x, const float* __restrict__ pose, const Camera3& K,
+                                       const float* __restrict__ uv_obs, const float* __restrict__ sdf, float bound, int64_t i) {
+    Obs o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        o.xc[a] = fmaf(pose[4 * a + 2], x[3 * i + 2], fmaf(pose[4 * a + 1], x[3 * i + 1], pose[4 * a] * x[3 * i])) + pose[4 * a + 3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.u[a] = fmaf(K.k[3 * a + 2], o.xc[2], fmaf(K.k[3 * a + 1], o.xc[1], K.k[3 * a] * o.xc[0]));
+    o.inv = 1.0f / (o.u[2] + 1e-6f);
+    const float uv0 = o.u[0] * o.inv, uv1 = o.u[1] * o.inv;
+    o.e[0] = uv0 - uv_obs[2 * i];
+    o.e[1] = uv1 - uv_obs[2 * i + 1];
+    o.err = sqrtf(fmaf(o.e[1], o.e[1], o.e[0] * o.e[0]));
+    o.on = (sdf == nullptr || fabsf(sdf[i]) < bound) && !isinf(uv0) && !isinf(uv1);
+    return o;
+}
+
+// one workgroup per view: partial[v] = {sum robust, sum err, count} over its counted observations, in fp64, fixed order
+__global__ void __launch_bounds__(kRpThreads)
+reproject_fwd_kernel(const float* __restrict__ x, const float* __restrict__ poses, const int32_t* __restrict__ view_start, Camera3 K,
+                     const float* __restrict__ uv_obs, const float* __restrict__ sdf, float bound, float* __restrict__ err_out,
+                     uint8_t* __restrict__ on_out, double* __restrict__ partial) {
+    const int v = blockIdx.x, tid = threadIdx.x;
+    __shared__ float s_pose[12];
+    __shared__ double s_red[kRpThreads][3];
+    if (tid < 12) s_pose[tid] = poses[12 * v + tid];
+    __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = view_start[v] + tid; i < view_start[v + 1]; i += kRpThreads) {
+        const Obs o = project(x, s_pose, K, uv_obs, sdf, bound, i);
+        const float err = o.on ? o.err : 0.f;
+        err_out[i] = err;
+        on_out[i] = o.on ? 1 : 0;
+        if (o.on) {
+            acc[0] += (double)(2.0f * logf(1.0f + err * err / 4.0f));
+            acc[1] += (double)err;
+            acc[2] += 1.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s_red[tid][q] = acc[q];
+    __syncthreads();
+    if (tid < 3) {
+        double t = 0.0;
+        for (int k = 0; k < kRpThreads; ++k) t += s_red[k][tid];
+        partial[3 * v + tid] = t;
+    }
+}
+
+// sums = {sum robust, sum err, count, reproj}
+__global__ void reproject_finish_kernel(const double* __restrict__ partial, int n_views, double* __restrict__ sums) {
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int v = 0; v < n_views; ++v)
+        for (int q = 0; q < 3; ++q) t[q] += partial[3 * v + q];
+    sums[0] = t[0]; sums[1] = t[1]; sums[2] = t[2];
+    sums[3] = t[2] > 0.0 ? (double)(0.5f * (float)t[0] / (float)t[2] + 0.5f * (float)t[1] / (float)t[2]) : 0.0;
+}
+
+// one workgroup per view: d_points of its observations, d_pose[v] as a fixed-order sum over them
+__global__ void __launch_bounds__(kRpThreads)
+reproject_bwd_kernel(const float* __restrict__ x, const float* __restrict__ poses, const int32_t* __restrict__ view_start, Camera3 K,
+                     const float* __restrict__ uv_obs, const float* __restrict__ sdf, float bound, const double* __restrict__ sums,
+                     const float* __restrict__ d_reproj, float* __restrict__ d_x, float* __restrict__ d_poses) {
+    const int v = blockIdx.x, tid = threadIdx.x;
+    __shared__ float s_pose[12];
+    __shared__ float s_red[kRpThreads][12];
+    if (tid < 12) s_pose[tid] = poses[12 * v + tid];
+    __syncthreads();
+    const float count = (float)sums[2];
+    const float g = count > 0.f ? d_reproj[0] * 0.5f / count : 0.f;       // d reproj / d (sum robust) = d / d (sum err)
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.f;
+    for (int64_t i = view_start[v] + tid; i < view_start[v + 1]; i += kRpThreads) {
+        const Obs o = project(x, s_pose, K, uv_obs, sdf, bound, i);
+        float dx[3] = {0.f, 0.f, 0.f};
+        if (o.on && o.err > 0.f) {
+            // d err: 1 from the plain mean, err / (1 + err^2 / 4) from the robust one
+            const float d_err = g * (1.0f + o.err / (1.0f + o.err * o.err / 4.0f));
+            const float de0 = d_err * o.e[0] / o.err, de1 = d_err * o.e[1] / o.err;
+            const float du[3] = {de0 * o.inv, de1 * o.inv, -(de0 * o.u[0] + de1 * o.u[1]) * o.inv * o.inv};
+            float dxc[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dxc[b] = fmaf(K.k[6 + b], du[2], fmaf(K.k[3 + b], du[1], K.k[b] * du[0]));      // K^T du
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dx[b] = fmaf(s_pose[8 + b], dxc[2], fmaf(s_pose[4 + b], dxc[1], s_pose[b] * dxc[0]));   // R^T
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[4 * a + b] = fmaf(dxc[a], x[3 * i + b], acc[4 * a + b]);
+                acc[4 * a + 3] += dxc[a];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) d_x[3 * i + b] = dx[b];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) s_red[tid][q] = acc[q];
+    __syncthreads();
+    if (tid < 12) {
+        float t = 0.f;
+        for (int k = 0; k < kRpThreads; ++k) t += s_red[k][tid];
+        d_poses[12 * v + tid] = t;
+    }
+}
+
+bool load_intrinsic(const float* host_k, Camera3* out) {
+    if (!host_k) return false;
+    for (int q = 0; q < 9; ++q) out->k[q] = host_k[q];
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t ls2fm_reproject_workspace_bytes(int32_t n_views) { return (int64_t)sizeof(double) * 3 * (n_views > 0 ? n_views : 1); }
+
+extern "C" int ls2fm_reproject_fwd(const float* points, const float* poses, const int32_t* view_start, int32_t n_views,
+                                   const float* intrinsic_host, const float* obs_uv, const float* sdf, float sdf_bound, int64_t n,
+                                   float* err, uint8_t* on, double* sums, void* workspace, void* stream) {
+    LS2FM_CHECK_ARG(n >= 0 && n_views >= 1 && poses && view_start && sums);
+    Camera3 K;
+    LS2FM_CHECK_ARG(load_intrinsic(intrinsic_host, &K));
+    if (!workspace) return LS2FM_ERR_WORKSPACE;
+    LS2FM_CHECK_ARG(n == 0 || (points && obs_uv && err && on));
+    hipStream_t s = (hipStream_t)stream;
+    reproject_fwd_kernel<<<(unsigned)n_views, kRpThreads, 0, s>>>(points, poses, view_start, K, obs_uv, sdf, sdf_bound, err, on,
+                                                                  (double*)workspace);
+    reproject_finish_kernel<<<1, 1, 0, s>>>((const double*)workspace, n_views, sums);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_reproject_bwd(const float* points, const float* poses, const int32_t* view_start, int32_t n_views,
+                                   const float* intrinsic_host, const float* obs_uv, const float* sdf, float sdf_bound, int64_t n,
+                                   const double* sums, const float* d_reproj, float* d_points, float* d_poses, void* stream) {
+    LS2FM_CHECK_ARG(n >= 0 && n_views >= 1 && poses && view_start && sums && d_reproj && d_poses);
+    Camera3 K;
+    LS2FM_CHECK_ARG(load_intrinsic(intrinsic_host, &K));
+    LS2FM_CHECK_ARG(n == 0 || (points && obs_uv && d_points));
+    reproject_bwd_kernel<<<(unsigned)n_views, kRpThreads, 0, (hipStream_t)stream>>>(points, poses, view_start, K, obs_uv, sdf, sdf_bound,
+                                                                                 sums, d_reproj, d_points, d_poses);
+    return ls2fm_launch_status();
+}

@@ -127,6 +127,9 @@ _SIGNATURES = {
     "ls2fm_sphere_trace_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, _P, c_int64,
                                               c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls2fm_sdf_prepare": (c_int32, [POINTER(GridDesc), POINTER(Params), _P, _P, _P]),
+    "ls2fm_reproject_workspace_bytes": (c_int64, [c_int32]),
+    "ls2fm_reproject_fwd": (c_int32, [_P, _P, _P, c_int32, POINTER(c_float), _P, _P, c_float, c_int64, _P, _P, _P, _P, _P]),
+    "ls2fm_reproject_bwd": (c_int32, [_P, _P, _P, c_int32, POINTER(c_float), _P, _P, c_float, c_int64, _P, _P, _P, _P, _P]),
     "ls2fm_sdf_eval_prepared": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P]),
     "ls2fm_trace_depth_fwd": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_float, _P, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                         _P]),

@@ -671,6 +671,59 @@ class GeoInitLoop:
         return out
 
 
+class _Reproject(torch.autograd.Function):
+    """ls2fm_reproject_fwd / _bwd: the re-projection term of a BA iteration (BA.py:126-147, 199-202) as one node
+    -> (reproj scalar, counted bool [n])"""
+
+    @staticmethod
+    def forward(ctx, points, poses, view_start, k_host, obs_uv, sdf, bound):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        x, ps = points.detach().float().contiguous(), poses.detach().float().contiguous()
+        _lib.require_device(x)
+        n, n_views, dev = x.shape[0], ps.shape[0], x.device
+        err = torch.empty(n, device=dev)
+        on = torch.empty(n, device=dev, dtype=torch.uint8)
+        sums = torch.empty(4, device=dev, dtype=torch.float64)
+        ws = torch.empty(int(lib.ls2fm_reproject_workspace_bytes(n_views)) // 8, device=dev, dtype=torch.float64)
+        sdf_c = None if sdf is None else sdf.detach().float().contiguous().reshape(-1)
+        _lib.check(lib.ls2fm_reproject_fwd(_lib.ptr(x), _lib.ptr(ps), _lib.ptr(view_start), n_views, k_host, _lib.ptr(obs_uv), _lib.ptr(sdf_c),
+                                           float(bound), n, _lib.ptr(err), _lib.ptr(on), _lib.ptr(sums), _lib.ptr(ws),
+                                           _lib.stream_ptr()), "ls2fm_reproject_fwd")
+        ctx.save_for_backward(x, ps, view_start, obs_uv, sdf_c if sdf_c is not None else x.new_empty(0), sums)
+        ctx.k_host, ctx.bound, ctx.has_sdf = k_host, float(bound), sdf_c is not None
+        counted = on.view(torch.bool)
+        ctx.mark_non_differentiable(counted)
+        return sums[3].float(), counted
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_reproj, _):
+        from . import _lib
+        lib = _lib.load()
+        x, ps, view_start, obs_uv, sdf_c, sums = ctx.saved_tensors
+        d_x, d_ps = torch.empty_like(x), torch.empty_like(ps)
+        g = d_reproj.detach().float().reshape(1).contiguous()
+        _lib.check(lib.ls2fm_reproject_bwd(_lib.ptr(x), _lib.ptr(ps), _lib.ptr(view_start), ps.shape[0], ctx.k_host, _lib.ptr(obs_uv),
+                                           _lib.ptr(sdf_c) if ctx.has_sdf else None, ctx.bound, x.shape[0], _lib.ptr(sums), _lib.ptr(g),
+                                           _lib.ptr(d_x), _lib.ptr(d_ps), _lib.stream_ptr()), "ls2fm_reproject_bwd")
+        return d_x, d_ps, None, None, None, None, None
+
+
+def reprojection_term(points, poses, view_start, intrinsic_host, obs_uv, sdf=None, bound=float("inf")):
+    """points [n,3] (observations sorted by view: view v owns rows view_start[v] : view_start[v + 1], int32 [V + 1] on the device),
+    poses [V,3,4] world-to-camera, intrinsic_host: the 3 x 3 K as 9 host floats (`ctypes` array, see `host_intrinsic`), obs_uv
+    [n,2] -> (reproj, counted [n] bool): 0.5 mean(2 log(1 + err^2 / 4)) + 0.5 mean(err) over the observations with
+    |sdf| < bound and a finite projection (BA.py:126-147, 199-202); differentiable w.r.t. points and poses"""
+    return _Reproject.apply(points, poses, view_start, intrinsic_host, obs_uv.float().contiguous(), sdf, bound)
+
+
+def host_intrinsic(intrinsic):
+    import ctypes
+    return (ctypes.c_float * 9)(*[float(v) for v in intrinsic.detach().reshape(-1).cpu().tolist()])
+
+
 class BALoop:
     """`BA` in mode "sfm_refine" with several cameras (pipelines/BA.py:24-218; optim_split: rotation / translation parameters
     with their own rates, BA.py:66-75): per iteration the POINT side -- tracked points projected onto the surface
@@ -692,6 +745,9 @@ class BALoop:
         self.obs_view = torch.cat([torch.full((t.shape[0],), v, dtype=torch.long) for v, t in enumerate(views.track_ids)]).to(se3.device)
         self.obs_point = torch.cat(views.track_ids).to(se3.device)
         self.obs_uv = torch.cat(views.keypoints).to(se3.device)
+        counts = [0] + [t.shape[0] for t in views.track_ids]
+        self.view_start = torch.tensor(counts, dtype=torch.int32).cumsum(0).to(torch.int32).to(se3.device)       # observations are sorted by view
+        self._k_host = host_intrinsic(views.intrinsic)
         # the loop's OWN copy of the points (BA.py:77): it is what gets projected and replaced every iteration, while the
         # tracing consistency keeps comparing against the point set's coordinates, which do not move during the loop (and not
         # after it either: Point3DSet.update_xyzs never runs its lazy map, SURVEY C-13)
@@ -725,21 +781,28 @@ class BALoop:
         """the terms BA.run_ba forms outside the render (BA.py:119-147) + the tracing consistency, already weighted"""
         xyzs_new, _ = self.sdf.get_surface_pts(self.xyzs_all[self.obs_point])
         sdfs = self.sdf.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1)
-        se3 = torch.cat([self.rot, self.trans], dim=1)
-        poses = _cam.lie.se3_to_SE3(se3[self.obs_view])                                          # one pose per observation
-        in_cam = _cam.world2cam(xyzs_new.unsqueeze(1), poses)
+        poses = _cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1))                    # [V,3,4]: the live poses
+        if xyzs_new.is_cuda:
+            # one fused node each way for the per-observation block (projection, pixel error, on-surface / finite mask, robust mean)
+            reproj, _ = reprojection_term(xyzs_new, poses, self.view_start, self._k_host, self.obs_uv, sdfs, 2 * self.sdf_threshold)
+        else:
+            reproj = self._reproj_torch(xyzs_new, poses, sdfs)
+        w_reproj = torch.where(reproj.detach() > 10, 10.0, 1.0) * (1.0 if self.w_reproj_lo else 0.0)       # BA.py:163-166
+        ret["reproj_error"], ret["w_reproj"] = reproj, w_reproj
+        ret["sdf_surf"] = sdfs.abs().mean()
+        self._new_points = xyzs_new.detach()
+        return w_reproj * reproj + self.w_surf * ret["sdf_surf"] + self.tracing(ret)
+
+    def _reproj_torch(self, xyzs_new, poses, sdfs):
+        """the same term written with torch ops (the reference's lines: BA.py:126-147, 199-202)"""
+        in_cam = _cam.world2cam(xyzs_new.unsqueeze(1), poses[self.obs_view])
         uv = _cam.cam2img(in_cam, self.views.intrinsic.expand(in_cam.shape[0], 3, 3))
         uv = (uv / (uv[..., 2:] + 1e-6))[..., :2].squeeze(1)
         on_surface = (sdfs.abs() < 2 * self.sdf_threshold).squeeze(-1) & ~torch.isinf(uv).any(dim=-1)
         err = torch.where(on_surface, (uv - self.obs_uv).norm(dim=-1), torch.zeros((), device=uv.device))
         n = on_surface.sum()
         robust = torch.where(on_surface, 2 * torch.log(1 + err ** 2 / 4), torch.zeros((), device=uv.device))
-        reproj = torch.where(n > 0, 0.5 * robust.sum() / n.clamp_min(1) + 0.5 * err.sum() / n.clamp_min(1), torch.zeros((), device=uv.device))
-        w_reproj = torch.where(reproj.detach() > 10, 10.0, 1.0) * (1.0 if self.w_reproj_lo else 0.0)       # BA.py:163-166
-        ret["reproj_error"], ret["w_reproj"] = reproj, w_reproj
-        ret["sdf_surf"] = sdfs.abs().mean()
-        self._new_points = xyzs_new.detach()
-        return w_reproj * reproj + self.w_surf * ret["sdf_surf"] + self.tracing(ret)
+        return torch.where(n > 0, 0.5 * robust.sum() / n.clamp_min(1) + 0.5 * err.sum() / n.clamp_min(1), torch.zeros((), device=uv.device))
 
     def step(self, rays_idx=None, view=None):
         V = self.rot.shape[0]
