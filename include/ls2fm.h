@@ -190,6 +190,13 @@ int64_t ls2fm_sdf_points_workspace_bytes(const ls2fm_field_desc* field, const ls
 int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
                          const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
                          const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream);
+/* The same, as a SECOND gradient producer of a backward pass: the parameter gradients are ADDED to what `grads` already holds
+ * (written earlier on the same stream, e.g. by ls2fm_render_bwd) -- the table through the scatter's add mode (nothing is zeroed,
+ * slabs without items are not touched), the MLP tensors through the weight-norm backward's.  d_p is overwritten as above.  What
+ * autograd otherwise does with two dense 50 MB table gradients and seven small tensors per extra node: a sum kernel each. */
+int ls2fm_sdf_points_bwd_add(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                             const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
+                             const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused volumetric rendering, forward.

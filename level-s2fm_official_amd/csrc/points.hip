@@ -30,7 +30,7 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
                                  hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0);
 int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
-                              const float* wg, hipStream_t stream);
+                              const float* wg, hipStream_t stream, int add = 0);
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
 
 namespace {
@@ -270,9 +270,12 @@ int ls2fm_points_bwd_scatter(const ls2fm_field_desc* field, const ls2fm_grid_des
     return st;
 }
 
-extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
-                                    const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
-                                    const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream) {
+// add: the parameter gradients are ADDED to what `grads` holds (a previous producer of the same backward pass wrote them):
+// the table through slab_accumulate's add mode (nothing zeroed, slabs without items untouched), the MLP tensors through the
+// weight-norm backward's
+static int points_bwd_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                           const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
+                           const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream, int add) {
     LS2FM_CHECK_ARG(field && grid_desc_ok(grid) && params && grads && n >= 0);
     LS2FM_CHECK_ARG(params->sdf_table && params->sdf_mlp[0].weight_v && params->sdf_mlp[1].weight_v);
     LS2FM_CHECK_ARG(d_sdf || d_feat || d_normal);
@@ -284,8 +287,8 @@ extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_g
     if (!workspace) return LS2FM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     WsLayout w;
-    int st = ls2fm_points_bwd_front(field, grid, params, p, n, d_sdf, d_feat, d_normal, grads->sdf_table, d_p != nullptr, workspace, s, &w,
-                                    nullptr);
+    int st = ls2fm_points_bwd_front(field, grid, params, p, n, d_sdf, d_feat, d_normal, add ? nullptr : grads->sdf_table, d_p != nullptr,
+                                    workspace, s, &w, nullptr);
     if (st != LS2FM_OK) return st;
     const ls2fm_field_desc f1 = one_sample_field(field);
     const FieldC fc = make_field_c(&f1);
@@ -300,12 +303,12 @@ extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_g
     hipStream_t gs = forked ? sc.side : s;
     ls2fm_launch_wgrad_mlp(fc, 0, 2 * L, 0, w, pk, nullptr, nullptr, n, ws, gs, /*sdf_only=*/true);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
-    st = ls2fm_launch_finalize_sdf(params, grads, 3 + 2 * L, pk, ws + w.wg, gs);
+    st = ls2fm_launch_finalize_sdf(params, grads, 3 + 2 * L, pk, ws + w.wg, gs, add);
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (st == LS2FM_OK && forked && hipEventRecord(sc.join, sc.side) != hipSuccess) st = LS2FM_ERR_LAUNCH;
     if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
 
-    st = ls2fm_points_bwd_scatter(field, grid, n, workspace, grads->sdf_table, 0, s, 3);
+    st = ls2fm_points_bwd_scatter(field, grid, n, workspace, grads->sdf_table, add, s, 3);
     if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
     if (d_p) {
         ls2fm_prof_begin(LS2FM_PROF_POSE, s);
@@ -314,4 +317,16 @@ extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_g
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_sdf_points_bwd(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                    const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
+                                    const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream) {
+    return points_bwd_impl(field, grid, params, p, n, d_sdf, d_feat, d_normal, grads, d_p, workspace, stream, 0);
+}
+
+extern "C" int ls2fm_sdf_points_bwd_add(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
+                                        const float* p, int64_t n, const float* d_sdf, const float* d_feat, const float* d_normal,
+                                        const ls2fm_param_grads* grads, float* d_p, void* workspace, void* stream) {
+    return points_bwd_impl(field, grid, params, p, n, d_sdf, d_feat, d_normal, grads, d_p, workspace, stream, 1);
 }

@@ -63,8 +63,8 @@ wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_
 
 // weight-norm backward of the SDF MLP alone (point queries, points.hip): tasks 0 and 1 of finalize_kernel
 int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
-                              const float* wg, hipStream_t stream) {
-    finalize_kernel<<<2, 256, 0, stream>>>(FinalizeArgs{*params, *grads, in_dim, 0, 0, 0, pk, wg, nullptr, 0});
+                              const float* wg, hipStream_t stream, int add) {
+    finalize_kernel<<<2, 256, 0, stream>>>(FinalizeArgs{*params, *grads, in_dim, 0, 0, 0, pk, wg, nullptr, 0, add});
     return ls2fm_launch_status();
 }
 
@@ -174,7 +174,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     {   // sum of the partials + finalize tasks, one launch (the ticket word: slack of the reduced-gradient block, zeroed above)
         static_assert(WgLayout::total % 64 != 0 && (WgLayout::total + 63) / 64 * 64 - WgLayout::total >= 1, "ticket word in the block's slack");
         const int n_red = kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec;
-        const FinalizeArgs fa{*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg, ws + w.dbeta, n_rays};
+        const FinalizeArgs fa{*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg, ws + w.dbeta, n_rays, 0};
         wgrad_tail_kernel<<<n_red + kFinalizeTasks, 256, 0, gs>>>(parts, ws + w.wg, fa, n_red,
                                                                  reinterpret_cast<int*>(ws + w.wg + WgLayout::total));
     }

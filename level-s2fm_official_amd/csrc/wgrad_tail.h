@@ -86,7 +86,7 @@ __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg
 // weight-norm backward of a whole layer:  W = (g/||v||) v  ->  dg = <dW,v>/||v|| ; dv = (g/||v||) dW - g <dW,v>/||v||^3 v.
 // Called by all 256 threads; 16 lanes cooperate on a row (coalesced accesses, 16-wide shuffle reduction).
 [[maybe_unused]] __device__ void weight_norm_bwd_rows(const float* v, const float* g, const float* dw, int dw_ld, int rows, int n_in,
-                                     float* dv, float* dg, int tid) {
+                                     float* dv, float* dg, int tid, bool add = false) {
     const int sub = tid & 15;
     for (int row0 = 0; row0 < rows; row0 += 16) {
         const int row = row0 + (tid >> 4);
@@ -104,8 +104,11 @@ __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg
             const float nrm = sqrtf(ss);
             const float s = g[row] / nrm;
             const float c = g[row] * dot / (nrm * nrm * nrm);
-            for (int k = sub; k < n_in; k += 16) dv[row * n_in + k] = s * dw[row * dw_ld + k] - c * v[row * n_in + k];
-            if (sub == 0) dg[row] = dot / nrm;
+            for (int k = sub; k < n_in; k += 16) {
+                const float val = s * dw[row * dw_ld + k] - c * v[row * n_in + k];
+                dv[row * n_in + k] = add ? dv[row * n_in + k] + val : val;
+            }
+            if (sub == 0) dg[row] = add ? dg[row] + dot / nrm : dot / nrm;
         }
     }
 }
@@ -113,6 +116,7 @@ __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg
 struct FinalizeArgs {
     ls2fm_params P; ls2fm_param_grads G; int in_dim, in_dim2, rad_in, dual;
     const Packed* pk; const float* wg; const float* dbeta; int64_t n_rays;
+    int add;        // tasks 0 / 1 (SDF MLP layers) ADD their results to G's tensors: a second producer of the same backward pass
 };
 
 // one workgroup (256 threads) per task
@@ -143,8 +147,9 @@ struct FinalizeArgs {
         if ((task & 1) == 0) {
             for (int idx = tid; idx < kHidden * 36; idx += 256) s_row[idx / 36][idx % 36] = wg_load(&dW0[idx]);
             __syncthreads();
-            weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, &s_row[0][0], 68, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid);
-            if (tid < kHidden) gl[0].bias[tid] = s_row[tid][35];
+            const bool add = fa.add != 0 && which == 0;
+            weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, &s_row[0][0], 68, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid, add);
+            if (tid < kHidden) gl[0].bias[tid] = add ? gl[0].bias[tid] + s_row[tid][35] : s_row[tid][35];
             return;
         }
         for (int idx = tid; idx < kOut * kHidden; idx += 256) {
@@ -152,9 +157,10 @@ struct FinalizeArgs {
             s_row[o][j] = wg_load(&dW1[o * 65 + j]) + ((which == 0 && o == 0) ? wg_load(&wg[WgLayout::dW1r0 + j]) : 0.f);
         }
         __syncthreads();
+        const bool add = fa.add != 0 && which == 0;
         weight_norm_bwd_rows(lin[1].weight_v, lin[1].weight_g, &s_row[0][0], 68, kOut, kHidden, gl[1].weight_v,
-                             gl[1].weight_g, tid);
-        if (tid < kOut) gl[1].bias[tid] = wg_load(&dW1[tid * 65 + 64]);
+                             gl[1].weight_g, tid, add);
+        if (tid < kOut) gl[1].bias[tid] = add ? gl[1].bias[tid] + wg_load(&dW1[tid * 65 + 64]) : wg_load(&dW1[tid * 65 + 64]);
         return;
     }
 

@@ -115,6 +115,8 @@ _SIGNATURES = {
     "ls2fm_sdf_points_workspace_bytes": (c_int64, [POINTER(FieldDesc), POINTER(GridDesc), c_int64]),
     "ls2fm_sdf_points_bwd": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P,
                                        POINTER(ParamGrads), _P, _P, _P]),
+    "ls2fm_sdf_points_bwd_add": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(Params), _P, c_int64, _P, _P, _P,
+                                           POINTER(ParamGrads), _P, _P, _P]),
     "ls2fm_render_workspace_bytes": (c_int64, [POINTER(FieldDesc), POINTER(GridDesc), c_int64]),
     "ls2fm_interleave_tables": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ls2fm_render_fwd": (c_int32, [POINTER(FieldDesc), POINTER(GridDesc), POINTER(GridDesc), POINTER(Params), _P, _P,

@@ -269,6 +269,43 @@ def flat_gradient_views(ps, attach=True):
     return flat, views
 
 
+# ---- one gradient buffer per backward pass.  A render's backward publishes its gradient views for the duration of the autograd
+# pass it runs in; a point-query node of the SAME pass that runs after it (its forward came first: the loops' early key-point
+# tracings and point-side terms) adds its contribution into those views in place (ls2fm_sdf_points_bwd_add) and hands autograd
+# no gradient of its own -- instead of a second dense table gradient, a second set of MLP gradients and a sum kernel for each.
+_PASS = {}
+_PASS_ARMED = [False]
+_PASS_SHARING = os.environ.get("LS2FM_SHARE_GRADS", "1") != "0"
+
+
+def _clear_pass():
+    _PASS.clear()
+    _PASS_ARMED[0] = False
+
+
+def _publish_pass_gradients(ps, flat):
+    """flat: the buffer `flat_gradient_views(ps)` returned.  (Only the buffer is remembered, not the views handed to autograd: a
+    second reference to a view keeps AccumulateGrad from taking it as .grad -- it would copy every gradient instead.)"""
+    if not _PASS_SHARING:
+        return
+    _PASS[ps[0].data_ptr()] = (list(ps), flat)
+    if not _PASS_ARMED[0]:
+        torch.autograd.Variable._execution_engine.queue_callback(_clear_pass)        # runs when this backward pass ends
+        _PASS_ARMED[0] = True
+
+
+def _pass_gradients(ps):
+    """the views an earlier node of this backward pass published for these very parameters, or None"""
+    entry = _PASS.get(ps[0].data_ptr())
+    if entry is None or len(entry[0]) < len(ps) or not all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(ps, entry[0])):
+        return None
+    flat, views, at = entry[1], [], 0
+    for p in ps:                                       # the segment layout of flat_gradient_views
+        views.append(flat[at:at + p.numel()] if p.dim() == 1 else flat[at:at + p.numel()].view(p.shape))
+        at += (p.numel() + 3) // 4 * 4
+    return views
+
+
 def _is_table(p) -> bool:
     return p.dim() == 1 and p.numel() > 4096
 
@@ -504,6 +541,8 @@ class _Render(torch.autograd.Function):
                                    ptr(ctx.ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_bwd")
         if keep is not None:
             d_dref = None                              # consumed inside the call: the tracing node gets no gradient through autograd
+        if not events:
+            _publish_pass_gradients(ps, flat)          # (level groups: reductions of `flat` are already in flight -- no late adds)
         if events:
             tables = [grads[0]] + ([grads[_RAD_TABLE_AT]] if dual else [])
             _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels)
@@ -624,7 +663,8 @@ class _SdfPoints(torch.autograd.Function):
         def prep(t, width):
             return None if t is None else t.reshape(-1, width).float().contiguous()
         d_sdf, d_feat, d_normal = prep(d_sdf, 1), prep(d_feat, _lib.FEAT + 1), prep(d_normal, 3)
-        flat, grads = flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
+        shared = _pass_gradients(ps)                   # an earlier node of this pass owns the gradient buffer: add into it
+        flat, grads = (None, shared) if shared is not None else flat_gradient_views(ps)          # table, (v, g, b) x 2, beta
         gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
         pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
         d_p = torch.empty_like(p) if ctx.needs_input_grad[0] else None
@@ -632,10 +672,13 @@ class _SdfPoints(torch.autograd.Function):
         if ws_bytes < 0:
             check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
         ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
-        check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
-                                       ptr(d_feat), ptr(d_normal), ctypes.byref(gstruct), ptr(d_p), ptr(ws), stream_ptr()),
-              "ls2fm_sdf_points_bwd")
-        grads[7] = None                                # beta does not enter a point query: no gradient (not a zero tensor)
+        fn = lib.ls2fm_sdf_points_bwd_add if shared is not None else lib.ls2fm_sdf_points_bwd
+        check(fn(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
+                 ptr(d_feat), ptr(d_normal), ctypes.byref(gstruct), ptr(d_p), ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
+        if shared is not None:
+            grads = [None] * len(ps)                   # already inside the pass's gradient buffer
+        else:
+            grads[7] = None                            # beta does not enter a point query: no gradient (not a zero tensor)
         return (None if d_p is None else d_p.view(xyz_shape), None, None, None, *grads)
 
 
@@ -719,7 +762,7 @@ class _TracedDepth(torch.autograd.Function):
         if d_dpred is None and d_last is None:
             return (None,) * (n_in + len(ps))
         _, grads = _traced_depth_backward(ctx.meta, p, trips, gate, ps, d_dpred, d_last, attach=True)
-        grads[7] = None                                # beta does not enter a point query
+        grads[7] = None                                # beta does not enter a point query (None already when the pass shares a buffer)
         return (None,) * n_in + tuple(grads)
 
 
@@ -733,7 +776,8 @@ def _traced_depth_backward(meta, p, trips, gate, ps, d_dpred, d_last, attach):
     d_sdf = torch.empty(n_rays * k_max, device=p.device)
     check(lib.ls2fm_trace_depth_bwd(ptr(d_dpred), ptr(d_last), ptr(trips), ptr(gate), n_rays, k_max, ptr(d_sdf), stream_ptr()),
           "ls2fm_trace_depth_bwd")
-    flat, grads = flat_gradient_views(ps, attach=attach)          # table, (v, g, b) x 2, beta
+    shared = _pass_gradients(ps) if attach else None
+    flat, grads = (None, shared) if shared is not None else flat_gradient_views(ps, attach=attach)          # table, (v, g, b) x 2, beta
     gstruct = _params_struct(grads, False, beta_speed, with_rad=False, cls=_lib.ParamGrads)
     pstruct = _params_struct(ps, False, beta_speed, with_rad=False)
     n = n_rays * k_max
@@ -741,9 +785,10 @@ def _traced_depth_backward(meta, p, trips, gate, ps, d_dpred, d_last, attach):
     if ws_bytes < 0:
         check(int(ws_bytes), "ls2fm_sdf_points_workspace_bytes")
     ws = torch.empty(ws_bytes // 4, device=p.device, dtype=torch.float32)
-    check(lib.ls2fm_sdf_points_bwd(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
-                                   None, None, ctypes.byref(gstruct), None, ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
-    return flat, list(grads)
+    fn = lib.ls2fm_sdf_points_bwd_add if shared is not None else lib.ls2fm_sdf_points_bwd
+    check(fn(ctypes.byref(fdesc), ctypes.byref(gdesc), ctypes.byref(pstruct), ptr(p), n, ptr(d_sdf),
+             None, None, ctypes.byref(gstruct), None, ptr(ws), stream_ptr()), "ls2fm_sdf_points_bwd")
+    return flat, ([None] * len(ps) if shared is not None else list(grads))
 
 
 class TracedDepthNode:

@@ -762,7 +762,7 @@ class BALoop:
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="bg",
                                  extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)],
-                                 extra_prepare=self.tracing.prepare, input_fn=self._inputs)
+                                 extra_prepare=self._prepare, input_fn=self._inputs)
         self._idx = torch.zeros(self.rand_rays // se3.shape[0], dtype=torch.long, device=se3.device)
         self._view = torch.zeros(1, dtype=torch.long, device=se3.device)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")
@@ -777,10 +777,22 @@ class BALoop:
         self.tracing.select(self._view, self._camera_poses)
         return _pick_rays(self.views, self._render_poses, self._idx)
 
+    def _prepare(self):
+        """ahead of the render, as in BA.run_ba (BA.py:117-131 come before its render call): the tracing consistency's key-point
+        tracing starts on a stream of its own, and the point side's two field queries are issued -- their autograd nodes then
+        PRECEDE the render's, so that in the backward they run after it and add into its gradient buffer (ls2fm.fused: one
+        gradient buffer per backward pass) instead of producing dense gradients of their own"""
+        self.tracing.prepare()
+        xyzs_new, _ = self.sdf.get_surface_pts(self.xyzs_all[self.obs_point])
+        self._point_side = (xyzs_new, self.sdf.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1))
+
     def _extra(self, ret):
         """the terms BA.run_ba forms outside the render (BA.py:119-147) + the tracing consistency, already weighted"""
-        xyzs_new, _ = self.sdf.get_surface_pts(self.xyzs_all[self.obs_point])
-        sdfs = self.sdf.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1)
+        if getattr(self, "_point_side", None) is not None:
+            (xyzs_new, sdfs), self._point_side = self._point_side, None
+        else:
+            xyzs_new, _ = self.sdf.get_surface_pts(self.xyzs_all[self.obs_point])
+            sdfs = self.sdf.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1)
         poses = _cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1))                    # [V,3,4]: the live poses
         if xyzs_new.is_cuda:
             # one fused node each way for the per-observation block (projection, pixel error, on-surface / finite mask, robust mean)
