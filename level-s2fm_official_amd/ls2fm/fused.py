@@ -273,9 +273,26 @@ def flat_gradient_views(ps, attach=True):
 # pass it runs in; a point-query node of the SAME pass that runs after it (its forward came first: the loops' early key-point
 # tracings and point-side terms) adds its contribution into those views in place (ls2fm_sdf_points_bwd_add) and hands autograd
 # no gradient of its own -- instead of a second dense table gradient, a second set of MLP gradients and a sum kernel for each.
+# OPT-IN per backward pass (`pass_gradient_sharing`): the in-place adds are only seen by autograd if the published buffer is
+# still what it holds for the parameter when the adding node runs -- true when every OTHER gradient producer of these parameters
+# in the pass runs after the render too or shares as well; a node that ran BEFORE the render has already made autograd sum into
+# a tensor of its own, and later in-place adds into the render's buffer would be lost.  ls2fm.stage's loops know their graphs
+# (all extra producers are issued ahead of the render) and switch it on around their backward; nothing else does.
 _PASS = {}
 _PASS_ARMED = [False]
-_PASS_SHARING = os.environ.get("LS2FM_SHARE_GRADS", "1") != "0"
+_PASS_SHARING = [False]
+
+
+class pass_gradient_sharing:
+    def __init__(self, on=True):
+        self.on = bool(on) and os.environ.get("LS2FM_SHARE_GRADS", "1") != "0"
+
+    def __enter__(self):
+        self.prev, _PASS_SHARING[0] = _PASS_SHARING[0], self.on
+
+    def __exit__(self, *exc):
+        _PASS_SHARING[0] = self.prev
+        _clear_pass()
 
 
 def _clear_pass():
@@ -286,7 +303,7 @@ def _clear_pass():
 def _publish_pass_gradients(ps, flat):
     """flat: the buffer `flat_gradient_views(ps)` returned.  (Only the buffer is remembered, not the views handed to autograd: a
     second reference to a view keeps AccumulateGrad from taking it as .grad -- it would copy every gradient instead.)"""
-    if not _PASS_SHARING:
+    if not _PASS_SHARING[0]:
         return
     _PASS[ps[0].data_ptr()] = (list(ps), flat)
     if not _PASS_ARMED[0]:

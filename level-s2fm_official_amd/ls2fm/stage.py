@@ -145,7 +145,7 @@ class RenderStage:
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
                  eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None,
-                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None):
+                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None, share_gradients=False):
         """lr / lr_color: the reference's two field groups (`[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(),
         lr_color}]`, BA.py:79-83; lr_color=None: one rate); extra_params: tensors (one more group at `lr`) or
         `{"params": [...], "lr": x}` dicts (the pose groups of BA.py:60-75).  ONE ExponentialLR factor for all groups,
@@ -189,6 +189,9 @@ class RenderStage:
         # from device tensors it updates in place -- `step()` then takes no arguments and a captured iteration has no eager
         # preamble (the loops' ~50 launch-bound kernels of camera arithmetic per iteration were half of their time)
         self.input_fn = input_fn
+        # one gradient buffer per backward pass (ls2fm.fused.pass_gradient_sharing): only for a caller whose extra terms issue
+        # ALL their field queries in `extra_prepare`, i.e. ahead of the render (the loops below)
+        self.share_gradients = bool(share_gradients)
         self.eikonal_over = eikonal_over
         self.reducer = reducer
         self._graph = None
@@ -210,7 +213,9 @@ class RenderStage:
         if self.extra_loss is not None:
             ret["loss_extra"] = self.extra_loss(ret)
             ret["loss_all"] = ret["loss_all"] + ret["loss_extra"]
-        ret["loss_all"].backward(gradient=self._one)
+        from . import fused as _fused
+        with _fused.pass_gradient_sharing(self.share_gradients and static_trips and self.extra_prepare is not None):
+            ret["loss_all"].backward(gradient=self._one)
         if self.reducer is not None:
             self.reducer.all_reduce()
         self.optim.step()
@@ -436,7 +441,7 @@ class RefineLoop:
         self.extra = TracingConsistency(sdf_field, views, get("tracing_loss"), get("sdf_surf"), static_trips=static)
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self.extra, eikonal_over="all", extra_prepare=self.extra.prepare,
-                                 input_fn=self._inputs)
+                                 input_fn=self._inputs, share_gradients=bool(static))
         self.poses = views.poses if views.poses.shape[-1] == 4 else _cam.lie.se3_to_SE3(views.poses)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss")
         # an iteration's picks as device tensors, updated in place: the ray pick and the key-point rays are formed INSIDE the step
@@ -494,7 +499,7 @@ class InitLoop:
             self._kp_rays = [keypoint_rays(self.poses[v], views.intrinsic, views.keypoints[v]) for v in range(2)]
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="all", extra_prepare=self._prepare,
-                                 input_fn=lambda: self._fixed.pick(self._idx))
+                                 input_fn=lambda: self._fixed.pick(self._idx), share_gradients=bool(self.static))
         self._idx = torch.zeros(self.rand_rays // 2, dtype=torch.long, device=self.poses.device)
         self._fixed = _FixedPoseRays(views, self.poses)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "reproj_error")
@@ -762,7 +767,7 @@ class BALoop:
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="bg",
                                  extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)],
-                                 extra_prepare=self._prepare, input_fn=self._inputs)
+                                 extra_prepare=self._prepare, input_fn=self._inputs, share_gradients=bool(static))
         self._idx = torch.zeros(self.rand_rays // se3.shape[0], dtype=torch.long, device=se3.device)
         self._view = torch.zeros(1, dtype=torch.long, device=se3.device)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")

@@ -326,3 +326,28 @@ def test_geo_init_shaped_step_is_capturable():
     assert np.isfinite(replayed).all() and replayed[-1] < replayed[0]
     # same seed, same number of draws per step: the replays see the eager run's sample points
     np.testing.assert_allclose(replayed, eager, rtol=2e-3)
+
+
+def test_pass_gradient_sharing_gives_the_same_gradients():
+    """one gradient buffer per backward pass (ls2fm.fused.pass_gradient_sharing): point-query nodes issued AHEAD of the render add
+    into the render's buffer in its wake -- every parameter gradient of a BA-shaped step equals the one autograd sums from separate
+    buffers (LS2FM_SHARE_GRADS=0 semantics), to summation-order round-off"""
+    from ls2fm import fused
+    g = load_golden("stage_ba_dtu_dual")
+    out = []
+    for share in (False, True):
+        meta, opt, sdf, rad, ren, views, picks = _scene(g)
+        o = meta["optim"]
+        views.poses = torch.from_numpy(g["se3"]).to(DEV)
+        loop = stage.BALoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                            lr_color=o["lr_color"], lr_pose_r=o["lr_pose_r"], lr_pose_t=o["lr_pose_t"], max_iter=o["max_iter"],
+                            rand_rays=meta["rand_rays"])
+        loop.stage.share_gradients = share
+        loop.stage.optim.step = lambda: None                     # keep the gradients: no update
+        loop.step(*picks[0])
+        out.append({n: p.grad.detach().clone() for n, p in list(sdf.named_parameters()) + [("rot", loop.rot), ("trans", loop.trans)]
+                    if p.grad is not None})
+    assert out[0].keys() == out[1].keys()
+    for n in out[0]:
+        scale = float(out[0][n].abs().max()) + 1e-20
+        assert float((out[0][n] - out[1][n]).abs().max()) <= 2e-5 * scale, n
