@@ -343,6 +343,25 @@ def main():
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         blocks = tb.tolist()
     dt = sorted(blocks)[len(blocks) // 2]
+    # N > 1: what the gradient exchange costs, measured outside the timed region -- the same K steps WITHOUT exchange and update
+    # (compute only), so that a scaling run records exposed exchange time next to the bytes it moves.  Not
+    # for the level-group overlap, whose reductions are issued from inside the backward.
+    exchange = None
+    if multi and not args.inference:
+        flat_bytes = 4 * sum((p.numel() + 3) // 4 * 4 for p in params)
+        exchange = {"form": "reduce-scatter + sharded Adam + all-gather" if shard else
+                            ("all-reduce" if args.no_overlap else f"all-reduce, {args.overlap_groups} level groups overlapped with the backward"),
+                    "gradient_bytes": flat_bytes, "bytes_on_wire_per_gpu": 2 * (world - 1) / world * flat_bytes}
+        if shard or args.no_overlap:
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                captured.replay() if use_graph else render_step()
+            barrier()
+            t_compute = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_compute, op=dist.ReduceOp.MAX)
+            exchange["compute_only_ms_per_step"] = float(t_compute.item()) * 1e3
+            exchange["exchange_and_update_ms_per_step"] = dt / args.steps * 1e3 - exchange["compute_only_ms_per_step"]
     # per-kernel device times (roofline): the same K steps launched eagerly with the library's HIP-event profiler on
     # (events cannot be read back from inside a graph replay); also gives the eager step time
     lib.ls2fm_profile_reset()
@@ -406,6 +425,8 @@ def main():
                    "parallelism": f"dp{world} (rays sharded by view)"},
         "roofline": roofline,
     }
+    if exchange is not None:
+        out["exchange"] = exchange
     if rank == 0:
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
