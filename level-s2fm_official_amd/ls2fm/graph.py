@@ -29,14 +29,27 @@ class CapturedStep:
         # default stream breaks the capture and slows the eager steps (0.73 -> 1.0 ms here).
         side = stream if stream is not None else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                 # warm-up off the default stream: allocator pools, lazy library state
-            for _ in range(warmup):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self.outputs = fn()
+        # No cyclic garbage collection between here and the end of the capture: a collection that fires INSIDE the capture (they
+        # are triggered by allocation counts, from whichever thread is running -- autograd's worker included) can destroy device
+        # objects of earlier, already unreachable steps (graphs, events, pool memory), which the runtime does not allow while a
+        # stream is capturing: the process aborts.  Seen once in ~10 full test runs, in the backward of a loop's capture.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            with torch.cuda.stream(side):                 # warm-up off the default stream: allocator pools, lazy library state
+                for _ in range(warmup):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gc.collect()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.outputs = fn()
+        finally:
+            if gc_was_on:
+                gc.enable()
         # the gradients the capture produced live in the graph's memory pool; `params` lets replay() re-bind them after
         # eager code replaced p.grad in between
         self._grads = [(p, p.grad) for p in params] if params is not None else []
