@@ -470,6 +470,12 @@ int ls2fm_adam_step_multi(int32_t n_tensors, float* const* params, const float* 
                           void* const* sched_states, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                           void* stream);
 
+/* ExponentialLR.step() for parameter groups that took NO Adam step this iteration (every tensor's grad is None): the device
+ * schedules' learning rates decay, `lr *= gamma`, their Adam step counts do not move -- torch's scheduler decays every group at
+ * every step whether or not its tensors had gradients.  sched_states: HOST array of n DEVICE pointers (32-byte states as above).
+ */
+int ls2fm_adam_sched_decay(int32_t n, void* const* sched_states, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the

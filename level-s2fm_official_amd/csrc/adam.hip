@@ -60,6 +60,11 @@ __global__ void adam_advance_kernel(AdamSchedList list, double beta1, double bet
     st->lr *= st->gamma;
 }
 
+// groups without a gradient this step: the rate decays, the Adam step count stays
+__global__ void adam_decay_kernel(AdamSchedList list) {
+    if ((int)threadIdx.x < list.count) list.st[threadIdx.x]->lr *= list.st[threadIdx.x]->gamma;
+}
+
 __global__ void __launch_bounds__(kAdamThreads)
 adam_kernel(AdamJobs jobs, AdamHyper h) {
     int j = 0;
@@ -233,6 +238,23 @@ extern "C" int ls2fm_adam_step_multi(int32_t n_tensors, float* const* params, co
         jobs.first_block[jobs.count] = blocks;
         if (blocks) adam_kernel<<<blocks, kAdamThreads, 0, stream>>>(jobs, h);
     }
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_adam_sched_decay(int32_t n, void* const* sched_states, void* stream_) {
+    LS2FM_CHECK_ARG(n >= 0 && (n == 0 || sched_states));
+    hipStream_t stream = (hipStream_t)stream_;
+    AdamSchedList list;
+    list.count = 0;
+    for (int32_t t = 0; t < n; ++t) {
+        LS2FM_CHECK_ARG(sched_states[t]);
+        bool seen = false;
+        for (int q = 0; q < list.count; ++q) seen = seen || (list.st[q] == (AdamSched*)sched_states[t]);
+        if (seen) continue;
+        if (list.count == 16) { adam_decay_kernel<<<1, 16, 0, stream>>>(list); list.count = 0; }
+        list.st[list.count++] = (AdamSched*)sched_states[t];
+    }
+    if (list.count) adam_decay_kernel<<<1, 16, 0, stream>>>(list);
     return ls2fm_launch_status();
 }
 

@@ -96,7 +96,26 @@ def global_max_int(value: int, device) -> int:
 # n groups (ls2fm_render_opts.n_level_groups), records an event per group, and issues that group's all-reduce of both tables'
 # slices on a communication stream right away: the exchange of the first groups runs beside the scatter of the later ones.
 _COMM_STREAMS = {}
-_PENDING = {}          # id(flat) -> (flat, [async work handles]): group reductions launched from inside a fused backward
+# id(flat) -> (flat, [async work handles], owners): group reductions launched from inside a fused backward; owners = the
+# Parameters whose gradients live in `flat`.  A reducer (or sharded optimizer) only takes the entries of ITS parameters: two
+# field pairs with a reducer each in one process do not drain each other's reductions.
+_PENDING = {}
+
+
+def _pending_of(params):
+    """keys of the in-flight group reductions whose gradient buffer belongs to any of `params`"""
+    mine = {id(p) for p in params}
+    return [k for k, (_, _, owners) in _PENDING.items() if any(id(o) in mine for o in owners)]
+
+
+def _retire_superseded(owners):
+    """a backward that is never followed by all_reduce() leaves its entry (and a strong reference to a full gradient buffer)
+    behind: when the same parameters launch a NEW set of reductions, the old ones are waited for and dropped"""
+    for k in _pending_of(owners):
+        flat, handles, _ = _PENDING.pop(k)
+        for h in handles:
+            h.wait()
+        flat._ls2fm_pending = None
 
 
 def comm_stream(device) -> torch.cuda.Stream:
@@ -139,12 +158,14 @@ def _all_reduce_together(slices):
     return [dist.all_reduce(t, async_op=True) for t in slices]
 
 
-def launch_group_reductions(flat, tables, level_offsets, events, n_levels):
+def launch_group_reductions(flat, tables, level_offsets, events, n_levels, owners=()):
     """called by the fused backward after its kernels are enqueued: tables = gradient views (1-D, inside `flat`) of the hash
     tables, level_offsets[l] = first ENTRY of level l, events[g] recorded when group g's levels are final.  One collective
     launch per group; the LAST one waits for the whole backward instead of its event and carries everything else that lives
     in `flat` (the MLP / beta gradients between and after the tables), so a step issues len(events) launches in total."""
     n = len(events)
+    owners = list(owners)
+    _retire_superseded(owners)
     cur = torch.cuda.current_stream(flat.device)
     comm = comm_stream(flat.device)
     base = flat.data_ptr()
@@ -165,7 +186,8 @@ def launch_group_reductions(flat, tables, level_offsets, events, n_levels):
         with torch.cuda.stream(comm):
             pending.extend(_all_reduce_together([t[lo:hi] for t in tables] + (rest if last else [])))
     flat._ls2fm_pending = pending
-    _PENDING[id(flat)] = (flat, pending)       # GradAllReducer.all_reduce waits for EVERY launched reduction, whatever it finds in .grad
+    # GradAllReducer.all_reduce waits for every launched reduction of its parameters, whatever it finds in .grad
+    _PENDING[id(flat)] = (flat, pending, owners)
 
 
 class GradAllReducer:
@@ -214,8 +236,9 @@ class GradAllReducer:
         # Reductions a fused backward launched itself (enable_table_overlap) are ALWAYS waited for here -- also when this
         # reducer does not recognise their buffer as its gradients -- so nothing is left reducing `flat` in place on the
         # communication stream while later code reads or rewrites it.
-        launched = list(_PENDING.values())
-        _PENDING.clear()
+        # (entries without recorded owners -- a caller of launch_group_reductions that did not name them -- are taken too)
+        keys = _pending_of(self.params) + [k for k, v in _PENDING.items() if not v[2]]
+        launched = [_PENDING.pop(k)[:2] for k in dict.fromkeys(keys)]
         for flat, handles in launched:
             for h in handles:
                 h.wait()
@@ -384,7 +407,7 @@ class ShardedAdam:
     def step(self):
         self.wait_params()
         # reductions a fused backward launched itself must not be in flight on the buffer that is scattered next
-        if _PENDING:
+        if _pending_of(self.params):
             raise RuntimeError("ls2fm.dist.ShardedAdam: enable_table_overlap() launches all-reduces of the gradient buffer; use one "
                                "exchange or the other")
         flat_g = self._flat_gradient()

@@ -562,7 +562,7 @@ class _Render(torch.autograd.Function):
             _publish_pass_gradients(ps, flat)          # (level groups: reductions of `flat` are already in flight -- no late adds)
         if events:
             tables = [grads[0]] + ([grads[_RAD_TABLE_AT]] if dual else [])
-            _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels)
+            _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels, owners=ps)
         if want_pose:
             d_center, d_ray = d_center.view(ctx.pose_shape), d_ray.view(ctx.pose_shape)
         if d_dref is not None:

@@ -178,7 +178,11 @@ class SDF(nn.Module):
         sampled = None
         self.last_sample_mask = None
         if want_samples:
-            with torch.no_grad():
+            # t_end / trips / track / near / far are written by kernels on `launch_stream` when one is given: the sample block is
+            # enqueued there too (the caller joins that stream before it reads any output of this call)
+            import contextlib
+            on_stream = torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()
+            with torch.no_grad(), on_stream:
                 n_rays, it = o.shape[0], int(self.iters_max)
                 k = trips.long().reshape(1)
                 # sample_u [R]: the draw of SDF.py:217 given by the caller (parity tests replay the reference's)

@@ -36,6 +36,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         calls = {}                  # (betas, eps, weight_decay, step or None) -> [(param, grad, state, lr, schedule tensor or None)]
+        idle = []                   # device schedules of groups without a gradient this step: their rate decays all the same
         for gi, group in enumerate(self.param_groups):
             steps = set()
             items = []
@@ -67,7 +68,11 @@ class FusedAdam(torch.optim.Optimizer):
                 key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]),
                        None if sched is not None else int(st["step"]))
                 calls.setdefault(key, []).append((p, g, st, float(group["lr"]), sched))
-            if sched is not None and items:
+            if sched is not None:
+                # ExponentialLR decays EVERY group at every scheduler step, with or without gradients (a group whose tensors all
+                # have grad None this step keeps its Adam step count -- torch skips such tensors -- but not its rate)
+                if not items:
+                    idle.append(sched)
                 group["lr"] = float(group["lr"]) * self.scheduled_gamma        # host mirror of the device schedule
         # ONE launch per distinct (betas, eps, weight decay[, step]) -- normally one for the whole optimizer, whatever the number
         # of parameter groups: per-tensor learning rates / schedules ride in the call (ls2fm_adam_step_multi)
@@ -88,6 +93,9 @@ class FusedAdam(torch.optim.Optimizer):
                 torch.autograd.graph.increment_version(p)
                 if rec is not None:             # ... and the interleaved table copy, which already holds the new values
                     rec[0].written_by_optimizer(rec[1], p)
+        if idle:
+            _lib.check(lib.ls2fm_adam_sched_decay(len(idle), (ctypes.c_void_p * len(idle))(*[t.data_ptr() for t in idle]),
+                                                  _lib.stream_ptr()), "ls2fm_adam_sched_decay")
         return loss
 
     @staticmethod
@@ -115,7 +123,29 @@ class FusedAdam(torch.optim.Optimizer):
                 group["lr"] = float(group["lr"]) * self.scheduled_gamma ** n
 
     def load_state_dict(self, state_dict):
-        """the device-resident step count / learning rate (scheduled form) are derived state: dropped here and rebuilt from the
-        loaded `step` and `lr` by the next step() -- an optimizer that had already stepped would otherwise keep its old schedule"""
+        """IN PLACE: a captured step (ls2fm.graph.CapturedStep, RenderStage(capture=True)) has the device addresses of the moments
+        and of the device-resident schedules baked into its hipGraph.  The loaded values are therefore copied INTO the tensors this
+        optimizer already owns (moments, `_sched`), which a later replay then reads -- torch's loader alone would install new
+        tensors and leave the graph reading (and writing 32 bytes of schedule into) memory that was handed back to the allocator.
+        The device schedule is derived state: reseeded here from the loaded `step` and `lr` of its group."""
+        held = {p: dict(st) for p, st in self.state.items() if st}
         super().load_state_dict(state_dict)
-        self._sched = {}
+        with torch.no_grad():
+            for p, old in held.items():
+                st = self.state.get(p)
+                if not st:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if torch.is_tensor(old.get(k)) and torch.is_tensor(st.get(k)) and old[k].shape == st[k].shape:
+                        old[k].copy_(st[k])
+                        st[k] = old[k]
+                st["step"] = int(st["step"])
+            for gi, t in self._sched.items():
+                if gi >= len(self.param_groups):
+                    continue
+                group = self.param_groups[gi]
+                steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and self.state[p]}
+                if len(steps) > 1:
+                    raise RuntimeError("ls2fm.optim.FusedAdam(scheduled_gamma=...): the parameters of a group must step together")
+                t.copy_(torch.tensor([float(steps.pop()) if steps else 0.0, float(group["lr"]), self.scheduled_gamma, 0.0],
+                                     dtype=torch.float64))

@@ -195,6 +195,7 @@ class RenderStage:
         self.eikonal_over = eikonal_over
         self.reducer = reducer
         self._graph = None
+        self._table_versions = None
         self._one = torch.ones((), device=dev)
 
     def _eager(self, centers, rays, rgbs_gt, static_trips):
@@ -230,9 +231,7 @@ class RenderStage:
             elif self._graph is None:
                 return self._capture(lambda: self._eager(*self.input_fn(), static_trips=True))
             else:
-                out = self._graph.replay()
-                self.optim.replayed(1)
-                return out
+                return self._replay()
         if not self.capture:
             # the static form (trip count stays on the device, traced depth + masks as one fused node) whenever the fused tracing
             # kernel serves this field: no host round trip per step, ~40 fewer launches; else the reference-shaped form
@@ -247,9 +246,34 @@ class RenderStage:
             if dst.shape != src.shape:
                 raise RuntimeError("ls2fm.stage.RenderStage(capture=True): the batch shape is fixed by the first step")
         torch._foreach_copy_(list(self._in), [s.detach() for s in srcs])         # one launch for the three inputs
+        return self._replay()
+
+    def _replay(self):
+        """one replay of the captured step.  The graph reads the entry-interleaved table copy WITHOUT checking it (inside a capture
+        nothing can be checked): a foreign writer of a table since the last replay -- a checkpoint load, `load_state_dict`, another
+        optimizer -- is detected here, on the host, through the tables' version counters, and costs one rebuild of the copy."""
+        from . import fused as _fused
+        tabs = _fused.table_params(self.sdf, self.rad)
+        if tabs is not None and [t._version for t in tabs] != self._table_versions:
+            _fused.sync_mirror(self.sdf, self.rad)
         out = self._graph.replay()
         self.optim.replayed(1)
+        self._table_versions = None if tabs is None else [t._version for t in tabs]
         return out
+
+    # ---- checkpoint / resume (utils/util.py:198-259 stores `optim_*` / `sched_*` state dicts next to the fields')
+    def state_dict(self):
+        """the optimizer's state in torch's layout (per-parameter `step, exp_avg, exp_avg_sq`, per-group `lr`): with the device-
+        resident schedule that IS the scheduler state -- ExponentialLR's only state is the current rate"""
+        if self.sharded:
+            raise NotImplementedError("ls2fm.stage.RenderStage.state_dict: use ShardedAdam.state_dict() (per-rank shards)")
+        return {"optim": self.optim.state_dict(), "gamma": self.gamma}
+
+    def load_state_dict(self, state):
+        """resume: moments, step counts and rates are copied INTO the tensors this stage (and a captured graph of it) already
+        owns; the next step -- eager or a replay -- continues the saved trajectory.  Load the fields' state dicts first."""
+        self.optim.load_state_dict(state["optim"])
+        self._table_versions = None            # the next replay re-checks the interleaved copy against the (reloaded) tables
 
     def _capture(self, fn):
         from . import dist as _dist
@@ -265,48 +289,54 @@ class RenderStage:
         _fused.trust_mirror_in_capture(self.sdf, self.rad)
         self._graph = CapturedStep(fn, params=self.params)
         self._restore(snap)
-        _fused.sync_mirror(self.sdf, self.rad)          # the restore rewrote the tables behind the graph's back
-        out = self._graph.replay()
-        self.optim.replayed(1)
-        return out
+        self._table_versions = None                     # the restore rewrote the tables behind the graph's back: _replay re-syncs
+        return self._replay()
 
     # ---- state snapshot around the capture's warm-up steps
     def _snapshot(self):
-        opt = self.optim
-        return dict(params=[p.detach().clone() for p in self.params],
-                    state=[({k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state[p].items()} if p in opt.state else None)
-                           for p in self.params],
-                    lrs=[float(g["lr"]) for g in opt.param_groups],
-                    sched={gi: t.clone() for gi, t in opt._sched.items()})
+        return _snapshot_training_state(self.params, self.optim)
 
     def _restore(self, snap):
-        opt = self.optim
-        with torch.no_grad():
-            for p, old in zip(self.params, snap["params"]):
-                p.copy_(old)
-                torch.autograd.graph.increment_version(p)
-            for p, old in zip(self.params, snap["state"]):
-                st = opt.state.get(p)
-                if not st:
-                    continue
-                if old:
-                    st["step"] = old["step"]
-                    st["exp_avg"].copy_(old["exp_avg"])
-                    st["exp_avg_sq"].copy_(old["exp_avg_sq"])
-                else:                       # state created by the warm-up: back to its initial value
-                    st["step"] = 0
-                    st["exp_avg"].zero_()
-                    st["exp_avg_sq"].zero_()
-            for g, lr in zip(opt.param_groups, snap["lrs"]):
-                g["lr"] = lr
-            for gi, t in opt._sched.items():
-                if gi in snap["sched"]:
-                    t.copy_(snap["sched"][gi])
-                else:                       # schedule created by the warm-up: seeded from the step the group had BEFORE it
-                    steps = [int(old["step"]) for p, old in zip(self.params, snap["state"])
-                             if old and any(p is q for q in opt.param_groups[gi]["params"])]
-                    t.copy_(torch.tensor([float(steps[0]) if steps else 0.0, snap["lrs"][gi], opt.scheduled_gamma, 0.0],
-                                         dtype=torch.float64))
+        _restore_training_state(self.params, self.optim, snap)
+
+
+def _snapshot_training_state(params, opt):
+    """parameters, Adam moments / step counts, learning rates and device schedules -- what a capture's warm-up steps change"""
+    return dict(params=[p.detach().clone() for p in params],
+                state=[({k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state[p].items()} if p in opt.state else None)
+                       for p in params],
+                lrs=[float(g["lr"]) for g in opt.param_groups],
+                sched={gi: t.clone() for gi, t in opt._sched.items()})
+
+
+def _restore_training_state(params, opt, snap):
+    """put a `_snapshot_training_state` back IN PLACE (a captured graph holds the addresses)"""
+    with torch.no_grad():
+        for p, old in zip(params, snap["params"]):
+            p.copy_(old)
+            torch.autograd.graph.increment_version(p)
+        for p, old in zip(params, snap["state"]):
+            st = opt.state.get(p)
+            if not st:
+                continue
+            if old:
+                st["step"] = old["step"]
+                st["exp_avg"].copy_(old["exp_avg"])
+                st["exp_avg_sq"].copy_(old["exp_avg_sq"])
+            else:                       # state created by the warm-up: back to its initial value
+                st["step"] = 0
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+        for g, lr in zip(opt.param_groups, snap["lrs"]):
+            g["lr"] = lr
+        for gi, t in opt._sched.items():
+            if gi in snap["sched"]:
+                t.copy_(snap["sched"][gi])
+            else:                       # schedule created by the warm-up: seeded from the step the group had BEFORE it
+                steps = [int(old["step"]) for p, old in zip(params, snap["state"])
+                         if old and any(p is q for q in opt.param_groups[gi]["params"])]
+                t.copy_(torch.tensor([float(steps[0]) if steps else 0.0, snap["lrs"][gi], opt.scheduled_gamma, 0.0],
+                                     dtype=torch.float64))
 
 
 # ================================================================================================ the stage LOOPS
@@ -574,7 +604,11 @@ class GeoInitLoop:
     pairs: per registered view a dict  view (index into poses), kp_new [n,2], kp_src [n,2] (row j <-> row j: the inlier
     matches), point_id [n] long (index into xyzs of the 3-D point the new view's key point already has, -1: none)."""
 
-    def __init__(self, opt, sdf_field, poses, intrinsic, new_view, pairs, xyzs, weights, lr_sdf, lr_sdf_end, max_iter, reproj_max=15.0):
+    def __init__(self, opt, sdf_field, poses, intrinsic, new_view, pairs, xyzs, weights, lr_sdf, lr_sdf_end, max_iter, reproj_max=15.0,
+                 capture=False):
+        """capture=True: the first `step` records the whole iteration -- tracing, the fixed-shape sample points and their mask,
+        three point-query nodes, every term, the backward, Adam with the schedule on the device -- into ONE hipGraph; later
+        steps write the iteration's uniform draws into a persistent buffer and replay it."""
         get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
         w = lambda k: 0.0 if get(k) is None else 10.0 ** float(get(k))
         self.w_reproj, self.w_tracing, self.w_surf, self.w_eik = w("reproj_error"), w("tracing_loss"), w("sdf_surf"), w("eikonal_loss")
@@ -604,12 +638,34 @@ class GeoInitLoop:
         self._one = torch.ones((), device=xyzs.device)
         self._last = None
         self._keys = ("loss_all", "reproj_error", "tracing_loss", "sdf_surf", "eikonal_loss")
+        self.capture = bool(capture)
+        self._graph = None
+        self._u = torch.zeros(self.center.shape[0] * self.center.shape[1], device=xyzs.device)      # the draws of SDF.py:217
+
+    def step(self, sample_u=None):
+        """one iteration; sample_u [2 * n]: the uniform draws that place the along-ray eikonal points (parity tests replay the
+        reference's); default: fresh device-side draws"""
+        if not self.capture:
+            ret, self._last = self._iteration(sample_u)
+            return ret
+        if sample_u is None:
+            self._u.uniform_()
+        else:
+            self._u.copy_(sample_u.reshape(-1))
+        if self._graph is None:
+            from .graph import CapturedStep
+            snap = _snapshot_training_state(self.params, self.optim)      # the capture warms up by stepping for real
+            self._graph = CapturedStep(lambda: self._iteration(self._u), params=self.params)
+            _restore_training_state(self.params, self.optim, snap)
+        ret, self._last = self._graph.replay()
+        self.optim.replayed(1)
+        return ret
 
     def _project(self, pts, view):
         uv = _cam.cam2img(_cam.world2cam(pts.unsqueeze(0), self.poses[view:view + 1]), self.intrinsic.unsqueeze(0))[0]
         return (uv / (uv[..., 2:] + 1e-6))[..., :2]
 
-    def step(self, sample_u=None):
+    def _iteration(self, sample_u=None):
         for p in self.params:
             p.grad = None
         sdf = self.sdf
@@ -650,8 +706,7 @@ class GeoInitLoop:
                            + self.w_eik * eik)
         ret["loss_all"].backward(gradient=self._one)
         self.optim.step()
-        self._last = last
-        return ret
+        return ret, last
 
     def run(self, n_iters=None, draws=None):
         logs = {k: [] for k in self._keys}

@@ -62,6 +62,28 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def per_element_check(got, ref, what, rtol=2e-3, floor=1e-3):
+    """PER-ELEMENT bar for table gradients (the max-norm bar `rel_err` says nothing about small entries, and Adam turns the sign /
+    zero-ness of a tiny gradient into a +-lr step): every entry whose reference magnitude is >= `floor` x the largest one is
+    held to `rtol` RELATIVE TO ITS OWN MAGNITUDE, and exact zero-ness must agree entry by entry (zero <=> zero; a handful of
+    entries whose contributions cancel to exactly 0.0 in one summation order and to a last-bit residue in the other are
+    tolerated: <= 1e-4 of the non-zero count, each below 1e-6 of the scale).  An entry of a table gradient is a sum of
+    contributions of both signs, so the per-element bar is the summation noise of the fp32 reference, not 1e-4.
+    -> (worst relative error above the floor, number of entries above the floor)"""
+    got = torch.as_tensor(got).detach().cpu().double().reshape(-1)
+    ref = torch.as_tensor(ref).detach().cpu().double().reshape(-1)
+    scale = float(ref.abs().max())
+    big = ref.abs() >= floor * scale
+    worst = float(((got - ref).abs()[big] / ref.abs()[big]).max()) if bool(big.any()) else 0.0
+    assert worst <= rtol, f"{what}: per-element relative error {worst:.2e} above the floor ({int(big.sum())} entries)"
+    odd = (got == 0) != (ref == 0)
+    n_odd, nnz = int(odd.sum()), int((ref != 0).sum())
+    residue = float(torch.maximum(got.abs(), ref.abs())[odd].max()) if n_odd else 0.0
+    assert n_odd <= max(1, int(1e-4 * nnz)) and residue <= 1e-6 * scale, \
+        f"{what}: zero-ness differs on {n_odd} of {nnz} non-zero entries (largest {residue:.2e}, scale {scale:.2e})"
+    return worst, int(big.sum())
+
+
 def load_fullsize_golden():
     """tests/golden/fullsize_dtu_dual.npz (reference outputs at the shipped L16/F2/T19 configuration) + the two seeded
     tables it was recorded with, regenerated and checked against the stored sha256 -> (golden, sdf_state, rad_state)"""
@@ -88,6 +110,10 @@ def check_table_digest(grad, g, prefix, tol=1e-4):
     ref = torch.from_numpy(g[prefix + "/sample_val"])
     scale = float(ref.abs().max())
     assert float((grad[pos] - ref).abs().max()) < tol * scale, prefix
+    # ... and per element on the recorded samples (512 largest + 1024 random positions, most of the latter exactly zero):
+    # relative to each sample's own magnitude above the floor, zero <=> zero
+    worst, n_big = per_element_check(grad[pos], ref, prefix)
+    print(f"[table digest] {prefix}: per-element worst {worst:.2e} over {n_big} samples above the floor")
     abs_sum = float(g[prefix + "/abs_sum"])
     assert abs(float(g64.abs().sum()) - abs_sum) < tol * abs_sum, prefix
     assert abs(float(g64.sum()) - float(g[prefix + "/sum"])) < tol * abs_sum * 1e-2 + 1e-6, prefix   # signed sum: cancels

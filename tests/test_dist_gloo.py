@@ -157,7 +157,7 @@ def _pending_worker(rank, world, port, out_dir):
         flat.fill_(float(rank + 1))
         h = dist.all_reduce(flat, async_op=True)              # what launch_group_reductions leaves behind
         flat._ls2fm_pending = [h]
-        ldist._PENDING[id(flat)] = (flat, [h])
+        ldist._PENDING[id(flat)] = (flat, [h], [a, b])
         a.grad, b.grad = ga, gb
         ldist.GradAllReducer([a, b]).all_reduce()             # sole producer: waits, nothing reduced twice
         assert torch.equal(flat, torch.full_like(flat, 3.0)) and not ldist._PENDING
@@ -165,7 +165,7 @@ def _pending_worker(rank, world, port, out_dir):
         flat2, (ga2, gb2) = fused.flat_gradient_views([a, b])
         flat2.fill_(1.0)
         h2 = dist.all_reduce(flat2, async_op=True)
-        ldist._PENDING[id(flat2)] = (flat2, [h2])
+        ldist._PENDING[id(flat2)] = (flat2, [h2], [a, b])
         a.grad, b.grad = ga2 + 1.0, gb2                       # autograd summed another node's gradient into a NEW tensor
         try:
             ldist.GradAllReducer([a, b]).all_reduce()
@@ -173,6 +173,26 @@ def _pending_worker(rank, world, port, out_dir):
         except RuntimeError as e:
             raised = "only gradient producer" in str(e)
         assert raised and not ldist._PENDING and h2.is_completed()
+        # two field pairs with a reducer each (round-3 advisor): a reducer takes only the reductions of ITS parameters
+        c, d = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(4))
+        flat_a, (ga3, gb3) = fused.flat_gradient_views([a, b])
+        flat_c, (gc3, gd3) = fused.flat_gradient_views([c, d])
+        flat_a.fill_(float(rank + 1)); flat_c.fill_(10.0 * (rank + 1))
+        a.grad, b.grad, c.grad, d.grad = ga3, gb3, gc3, gd3
+        ha, hc = dist.all_reduce(flat_a, async_op=True), dist.all_reduce(flat_c, async_op=True)
+        ldist._PENDING[id(flat_a)] = (flat_a, [ha], [a, b])
+        ldist._PENDING[id(flat_c)] = (flat_c, [hc], [c, d])
+        ldist.GradAllReducer([a, b]).all_reduce()             # must not drain (or trip over) the other pair's entry
+        assert list(ldist._PENDING) == [id(flat_c)] and torch.equal(flat_a, torch.full_like(flat_a, 3.0))
+        ldist.GradAllReducer([c, d]).all_reduce()
+        assert not ldist._PENDING and torch.equal(flat_c, torch.full_like(flat_c, 30.0))
+        # a backward never followed by all_reduce(): its entry is retired when the same parameters launch again
+        flat_o, _ = fused.flat_gradient_views([a, b])
+        flat_o.fill_(1.0)
+        ho = dist.all_reduce(flat_o, async_op=True)
+        ldist._PENDING[id(flat_o)] = (flat_o, [ho], [a, b])
+        ldist._retire_superseded([a, b])
+        assert not ldist._PENDING and ho.is_completed()
         with open(os.path.join(out_dir, f"pend_ok{rank}"), "w") as f:
             f.write("ok")
     finally:

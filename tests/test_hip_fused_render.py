@@ -182,6 +182,10 @@ def test_fused_render_vs_oracle_full_size_grid(ds, dual, n_samples, n_rays):
                 _beta_ok(v, ref, _exact_beta_grad(cfg, sdf.state_dict(), rad.state_dict(), center, ray, tgt, nm))
                 continue
             assert rel_err(v, ref) < GTOL, k
+            if k.endswith("embedder_obj.params"):       # the whole 12 M-entry table gradient, entry by entry
+                from conftest import per_element_check
+                worst, n_big = per_element_check(v, ref, k)
+                print(f"[{ds}] {k}: per-element worst {worst:.2e} over {n_big} entries above the floor")
     assert osd["embed_fn.embedder_obj.params"].grad.abs().max() > 0
 
 

@@ -103,16 +103,18 @@ def test_captured_refine_loop_reproduces_the_eager_one_bit_for_bit():
         assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[1][k], runs[2][k]), k
 
 
-def test_ba_loop_vs_reference_loop():
+@pytest.mark.parametrize("capture", [False, True])
+def test_ba_loop_vs_reference_loop(capture):
     g = load_golden("stage_ba_dtu_dual")
     meta, opt, sdf, rad, ren, views, picks = _scene(g)
     o = meta["optim"]
     views.poses = torch.from_numpy(g["se3"]).to(DEV)            # the loop optimises the se(3) parameters
     loop = stage.BALoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
                         lr_color=o["lr_color"], lr_pose_r=o["lr_pose_r"], lr_pose_t=o["lr_pose_t"], max_iter=o["max_iter"],
-                        rand_rays=meta["rand_rays"])
+                        rand_rays=meta["rand_rays"], capture=capture)
     logs = {k: v.cpu().numpy() for k, v in loop.run(picks=picks).items()}
-    print(f"[ba] loss {logs['all'][0]:.4f} -> {logs['all'][-1]:.4f} (reference {g['log/all'][0]:.4f} -> {g['log/all'][-1]:.4f}); "
+    assert (loop.stage._graph is not None) == capture
+    print(f"[ba capture={capture}] loss {logs['all'][0]:.4f} -> {logs['all'][-1]:.4f} (reference {g['log/all'][0]:.4f} -> {g['log/all'][-1]:.4f}); "
           f"reproj {logs['reproj_error'][0]:.4f} -> {logs['reproj_error'][-1]:.4f} (reference {g['log/reproj_error'][-1]:.4f})")
     assert np.array_equal(10.0 ** g["log/w_reproj"], logs["w_reproj"]), "adaptive re-projection weight (BA.py:163-166)"
     _close("loss.all", logs["all"], g["log/all"], 3e-3)
@@ -176,7 +178,7 @@ def test_init_loop_vs_reference_loop(capture):
     assert float(err.max()) <= 2e-3 * scale, (float(err.max()), scale)
 
 
-def _geoinit_run(g, perturb=0.0):
+def _geoinit_run(g, perturb=0.0, capture=False, n_iters=None):
     meta = json.loads(bytes(g["meta_json"]).decode())
     meta["bg_sdf"] = None
     opt = options_for(meta, DEV)
@@ -195,10 +197,10 @@ def _geoinit_run(g, perturb=0.0):
     o = meta["optim"]
     loop = stage.GeoInitLoop(opt, sdf, torch.from_numpy(g["poses"]).to(DEV), torch.from_numpy(g["intrinsic"]).to(DEV), new_view=2,
                              pairs=pairs, xyzs=torch.from_numpy(g["xyzs"]).to(DEV), weights=meta["weights"], lr_sdf=o["lr_sdf"],
-                             lr_sdf_end=o["lr_sdf_end"], max_iter=o["max_iter"])
+                             lr_sdf_end=o["lr_sdf_end"], max_iter=o["max_iter"], capture=capture)
     assert loop.n_iters == meta["iters"]
     draws = [torch.from_numpy(u).to(DEV) for u in g["sample_u"]]
-    logs = {k: v.cpu().numpy().astype(np.float64) for k, v in loop.run(draws=draws).items()}
+    logs = {k: v.cpu().numpy().astype(np.float64) for k, v in loop.run(n_iters=n_iters, draws=draws).items()}
     return loop, sdf, logs, torch.arange(n)[inl.cpu()]
 
 
@@ -249,6 +251,26 @@ def test_geoinit_loop_vs_reference_loop():
         err = (mine - ref).norm(dim=-1)
         scale = float(ref.abs().max())
         assert float(err.median()) <= 2e-2 * scale and float(err.max()) <= 1e-1 * scale, (pair, float(err.median()), float(err.max()))
+
+
+def test_captured_geoinit_loop_vs_reference_loop():
+    """`GeoInitLoop(capture=True)`: the whole `geo_init_nf` iteration as ONE hipGraph (tracing, fixed-shape sample points + mask,
+    the three point-query nodes, every term, backward, Adam + schedule on the device), the iteration's uniform draws written into
+    a persistent buffer before each replay.  Held to the reference's own loop at the bar of the eager form's first iterations
+    (3e-4 per term -- afterwards the loop is chaotic, see above) and, over the whole run, to the eager form's bars."""
+    g = load_golden("stage_geoinit_dtu")
+    loop, sdf, logs, _ = _geoinit_run(g, capture=True)
+    assert loop._graph is not None
+    _, _, eager, _ = _geoinit_run(g, n_iters=3)
+    bars = dict(all=8e-2, reproj_error=6e-2, tracing_loss=6e-2, sdf_surf=6e-2, eikonal_loss=2e-1)
+    for k, bar in bars.items():
+        ref = g[f"log/{k}"]
+        _close(f"{k} (first iterations, captured)", logs[k][:3], ref[:3], 3e-4)
+        _close(f"{k} (captured vs eager)", logs[k][:3], eager[k][:3], 3e-4)
+        assert np.isfinite(logs[k]).all()
+        assert np.abs(logs[k] / ref - 1).max() <= bar, k
+    assert int(loop.optim.state[loop.params[0]]["step"]) == loop.n_iters
+    assert len(loop.triangulate()) == 2
 
 
 def test_static_sphere_tracing_samples_have_the_reference_structure():
