@@ -133,6 +133,38 @@ CONFIGS = {
 }
 
 
+def mirror_upkeep_us(sdf, rad, dev, reps=20):
+    """extra device time of one FusedAdam step for keeping the interleaved table copy current (paired job vs two plain jobs)"""
+    from ls2fm.optim import FusedAdam
+    tabs = [sdf.embed_fn.embedder_obj.params, rad.embed_fn.embedder_obj.params]
+    if any(getattr(t, "_ls2fm_mirror", None) is None for t in tabs):
+        return None
+    for t in tabs:
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
+
+    def timed(opt):
+        for _ in range(3):
+            opt.step()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            opt.step()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+    with_copy = timed(FusedAdam(tabs, lr=0.0))
+    held = [t._ls2fm_mirror for t in tabs]
+    for t in tabs:
+        t._ls2fm_mirror = None
+    try:
+        plain = timed(FusedAdam(tabs, lr=0.0))
+    finally:
+        for t, h in zip(tabs, held):
+            t._ls2fm_mirror = h
+    return with_copy - plain
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +196,12 @@ def main():
                          "buffer -> Adam on this rank's 1/N of the parameters (ls2fm.dist.ShardedAdam) -> all-gather of the updated "
                          "shards; allreduce: sum all-reduce of the gradients, no update in the step (--no-shard)")
     ap.add_argument("--no-shard", dest="exchange", action="store_const", const="allreduce")
+    ap.add_argument("--shard-groups", type=int, default=2,
+                    help="N > 1, --exchange shard: level groups of the PIPELINED exchange (per group, issued from inside the backward: "
+                         "reduce-scatter -> Adam on this rank's slice -> all-gather); 1 = one reduce-scatter / one all-gather around the update")
+    ap.add_argument("--with-update", action="store_true",
+                    help="N = 1: put the optimizer update (FusedAdam, schedule on the device) INSIDE the timed step, launched eagerly -- "
+                         "the like-for-like single-GPU point of a scaling curve whose N > 1 points (sharded exchange) contain their update")
     ap.add_argument("--inference", action="store_true",
                     help="time the forward-only render under no_grad (the eval path: Camera.render_img_by_slices renders an image "
                          "in rand_rays chunks, pipelines/Camera.py:274-311) instead of the training step")
@@ -226,14 +264,20 @@ def main():
         # reduce-scatter -> Adam on this rank's shard -> all-gather: the same bytes on xGMI as the all-reduce, optimizer state
         # and update traffic / world; the step then includes the (sharded) update
         from ls2fm.dist import ShardedAdam
-        sharded_opt = ShardedAdam.for_fields(sdf, rad, lr=1e-4, lr_color=1e-4, scheduled_gamma=1.0)
+        sharded_opt = ShardedAdam.for_fields(sdf, rad, lr=1e-4, lr_color=1e-4, scheduled_gamma=1.0, n_groups=args.shard_groups,
+                                             async_gather=args.shard_groups > 1)
         params = list(sharded_opt.params)
+    local_opt = None
+    if args.with_update and not multi and not args.inference:
+        from ls2fm.optim import FusedAdam
+        local_opt = FusedAdam([dict(params=list(sdf.parameters()), lr=1e-4), dict(params=list(rad.parameters()), lr=1e-4)],
+                              scheduled_gamma=1.0)
     if reducer is not None and not args.no_overlap:
         # the ~105 MB gradient exchange is as long as the step on 7 xGMI links and all of it comes out of the backward's last
         # kernels: scatter the levels in 4 groups and all-reduce a group's table slices while the next ones are scattered
         enable_table_overlap(sdf, rad, n_groups=args.overlap_groups)
 
-    if sharded_opt is None:
+    if sharded_opt is None and local_opt is None:
         # the timed loop never changes the tables (no optimizer in the step): a captured step needs no rebuild of the
         # interleaved table copy inside the graph
         fused.trust_mirror_in_capture(sdf, rad)
@@ -249,6 +293,8 @@ def main():
 
     def render_step():
         """Renderer.forward -> loss head -> backward: every parameter's .grad is (re)written"""
+        if sharded_opt is not None:
+            sharded_opt.wait_params()       # the previous step's all-gathers (device-side wait) before the first parameter read
         if args.inference:
             with torch.no_grad():
                 return ren.forward(opt, center, ray, sdf, rad)["rgb"]
@@ -266,8 +312,8 @@ def main():
     mode = "graph" if args.graph else args.launch
     if multi and mode != "graph":
         mode = "eager"                  # collectives are issued from inside the backward: keep them out of graph captures
-    if shard:
-        mode = "eager"                  # the step rewrites the parameters through collectives: not captured
+    if shard or local_opt is not None:
+        mode = "eager"                  # the step rewrites the parameters (collectives / an update the N > 1 lines launch eagerly too)
     # every step -- eager or captured -- runs on ONE non-default stream: autograd's gradient accumulators stay tied to
     # the stream of their first backward, and mixing streams costs synchronisations (and breaks captures)
     s_main = torch.cuda.Stream(device=dev)
@@ -284,6 +330,8 @@ def main():
             reducer.all_reduce()
         if sharded_opt is not None:
             sharded_opt.step()
+        if local_opt is not None:
+            local_opt.step()
 
     launch_probe = None
     if mode == "graph":
@@ -349,10 +397,11 @@ def main():
     exchange = None
     if multi and not args.inference:
         flat_bytes = 4 * sum((p.numel() + 3) // 4 * 4 for p in params)
-        exchange = {"form": "reduce-scatter + sharded Adam + all-gather" if shard else
+        exchange = {"form": (f"reduce-scatter + sharded Adam + all-gather, pipelined over {sharded_opt.n_groups} level groups from inside "
+                             "the backward" if shard and sharded_opt.n_groups > 1 else "reduce-scatter + sharded Adam + all-gather") if shard else
                             ("all-reduce" if args.no_overlap else f"all-reduce, {args.overlap_groups} level groups overlapped with the backward"),
                     "gradient_bytes": flat_bytes, "bytes_on_wire_per_gpu": 2 * (world - 1) / world * flat_bytes}
-        if shard or args.no_overlap:
+        if (shard and sharded_opt.n_groups <= 1) or (not shard and args.no_overlap):
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -385,7 +434,7 @@ def main():
         # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter summary of
         # this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is QUOTED when the workload
         # is the default one -- with the commit it was measured at, so a stale figure is recognisable
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(q)), "")
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
             doc = json.load(open(pmc))
             if roofline["kernel"].startswith("scatter_pair") and "scatter_fill" in doc and "slab_accumulate" in doc:
@@ -394,7 +443,7 @@ def main():
                 rec = doc.get(roofline["kernel"])
             if rec:
                 roofline["traffic"] = rec["fetch"] + rec["write"]
-                roofline["traffic_source"] = (f"quoted from profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                roofline["traffic_source"] = (f"quoted from profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                               f"passes at commit {doc.get('_commit', '?')}; FETCH_SIZE doubled per the guide)")
         if roofline:
             # SURVEY 8d's whole-step figures: algorithmic table bytes (gather + scatter, both grids) and dense FLOPs of one step
@@ -427,6 +476,15 @@ def main():
     }
     if exchange is not None:
         out["exchange"] = exchange
+    # is an optimizer update part of the timed step?  (N > 1 with the sharded exchange: yes; N = 1: only with --with-update --
+    # compare a scaling curve's points like for like)
+    out["update_in_step"] = bool(shard or local_opt is not None)
+    if dual and not multi and not args.inference:
+        # The dual-field render reads the ENTRY-INTERLEAVED copy of the two tables, which FusedAdam keeps current inside its own
+        # pass.  The default line times fwd + bwd only, so that upkeep is outside the timed region (with --with-update it is
+        # inside); its cost is measured here, after the timed region: the paired Adam job that also writes the copy against the
+        # two plain jobs (learning rate 0: the weights do not move).
+        out["mirror_upkeep"] = {"in_timed_region": local_opt is not None, "adam_pair_extra_us": mirror_upkeep_us(sdf, rad, dev)}
     if rank == 0:
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:

@@ -477,6 +477,19 @@ int ls2fm_adam_step_multi(int32_t n_tensors, float* const* params, const float* 
 int ls2fm_adam_sched_decay(int32_t n, void* const* sched_states, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * How the table-gradient scatter (inside ls2fm_render_bwd / ls2fm_sdf_points_bwd) finishes the few coarse levels whose slabs
+ * are split over several workgroups.  Process-wide; takes effect for the calls enqueued afterwards.
+ *   1 (default; env LS2FM_SCATTER_MODE)  every part's 64-bit fixed-point partial sums are combined by one more small launch:
+ *      integer sums, so every table-gradient entry is the exactly rounded sum of its fp32 contributions whatever the order
+ *      the hardware produced them in, and a backward repeats itself bit for bit
+ *   0  the parts flush with float atomics into a zeroed range: one launch fewer, sums of rounded partials in arrival order
+ *      (what rounds 1-3 shipped; kept for measurements)
+ * tcnn's kernel_grid_backward is atomicAdd on fp32/half2 throughout (non-deterministic); the reference has no switch.
+ */
+int ls2fm_set_scatter_mode(int mode);
+int ls2fm_get_scatter_mode(void);
+
+/* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (benchmarking aid; the library's only process-global state, off by default).
  * While enabled, every internal kernel launch of the calls above is bracketed by HIP events recorded on the
  * call's own stream; ls2fm_profile_get() synchronises those events and returns, per internal kernel, the

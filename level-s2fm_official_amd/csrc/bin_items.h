@@ -17,16 +17,32 @@ constexpr int kCountThreads = LS2FM_FILL_TILE;
 constexpr int kFillThreads = LS2FM_FILL_TILE;    // one sample point per thread
 constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
 constexpr int kAccThreads = 1024;
+#ifndef LS2FM_ACC_BATCH
+#define LS2FM_ACC_BATCH 4
+#endif
+constexpr int kAccBatch = LS2FM_ACC_BATCH;      // items per lane in flight in slab_accumulate (a hashed slab of the benchmark: 4096 items = one batch)
 constexpr int kMaxParts = 16;
 
 typedef unsigned long long u64;
 
-struct __attribute__((aligned(16))) Item {      // 32 bytes
+struct __attribute__((aligned(16))) Item {      // 32 bytes: BOTH grids of a dual-field pair, factored over the two x-corners
     uint32_t ij;           // local entry index of x-corner 0 (low 16 bits) and 1 (high 16 bits); 0xFFFF = not in this slab
     float wx;              // x weight: px(0) = 1 - wx, px(1) = wx
     float a0, a1, b0, b1;  // SDF grid, per feature: A = pyz de + qyz rr ; B = qd_x pyz rr
     float c0, c1;          // second grid: C = pyz de2
 };
+
+// Single field (the reference's default, options/LevelS2fM.yaml:9 `dual_field: false`, and every point query): the two
+// x-corners' contributions are formed where the records are read and travel EXPLICITLY -- 20 bytes instead of the 24 a
+// factored {ij, wx, A, B} would take (and of the 32 of the dual item with its second-grid half dead), one add per feature in
+// the accumulate pass, and a whole run of merged samples (below) still fits one item.
+struct __attribute__((aligned(4))) ItemS {      // 20 bytes
+    uint32_t ij;           // as above
+    float v00, v01;        // x-corner 0, features 0 / 1:  px0 A - B
+    float v10, v11;        // x-corner 1:                  wx A + B
+};
+template <bool DUAL> struct ItemOf { typedef ItemS type; };
+template <> struct ItemOf<true> { typedef Item type; };
 
 struct BinMeta {           // device arrays inside the workspace
     int* count;            // [L][kBins]  items per (level, slab)
@@ -34,7 +50,9 @@ struct BinMeta {           // device arrays inside the workspace
     int* tile;             // [L][n_tiles][kBins]  per fill-workgroup counts, turned into absolute offsets by the scan: no
                            //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
                            //                      order is deterministic
-    Item* items;
+    Item* items;           // (single field: ItemS records in the same storage)
+    u64* part_acc;         // kAccSlots u64 per (split slab, part): fixed-point partials, summed by slab_combine_kernel
+    int part_blocks;       // capacity of part_acc in blocks of kAccSlots
     float* level_bound;    // [32] max over rays of the per-ray contribution bounds (rows 0..15 SDF grid, 16..31 second grid)
     int n_tiles;
 };
@@ -96,6 +114,79 @@ __device__ __forceinline__ void for_each_item(const LevelC& L, const uint32_t g[
 }
 
 
+// ---- run merging.  Consecutive sample points that fall into the SAME cell of a level touch the same eight entries (coarse
+// levels: 7 .. 1.4 consecutive samples of a ray per cell on ETH3D's levels 0 .. 4): their contributions are summed in registers
+// by a segmented wave reduction in scatter_fill and travel as the items of the run's FIRST lane only -- fewer 20 / 32-byte
+// round trips, fewer 64-bit LDS atomics, and far fewer same-address collisions in the coarse slabs.  Which lanes continue a
+// run is a function of the cells alone, so the counting pass (render_fwd.hip) and the fill pass classify identically; a wave
+// takes the merging path only when at least kMergeMin of its lanes continue a run (a wave-uniform decision both passes make
+// from the same ballot), so the fine levels pay three shuffles and a ballot.
+// Single field: a run is one explicit item per corner pair.  Dual field: the factored item cannot carry a sum over different
+// x weights, so a merged run is two half items per pair (wx = 0 / 1, A = the summed corner values, B = 0).
+#ifndef LS2FM_MERGE_MIN
+#define LS2FM_MERGE_MIN 8
+#endif
+#ifndef LS2FM_MERGE_MIN_DUAL
+#define LS2FM_MERGE_MIN_DUAL 65
+#endif
+// lanes of a wave that must continue a run for the wave to merge (65: never).  Measured at C2 (profiles/r04_ab_scatter*.txt):
+// single field -- explicit items, a run is ONE item per pair -- merging takes scatter_fill 65.6 -> 53.2 us, slab_accumulate
+// 62.5 -> 57.8 and the gather pass's counting 83 -> 80 (fewer colliding histogram increments), the step 0.372 -> 0.358 ms
+// (ScanNet 4096 x 256: 2.48 -> 2.17 ms); dual field -- two half items per pair -- it costs scatter_fill what it saves
+// slab_accumulate (91 -> 102, 123 -> 113 us; step 0.545 vs 0.551 ms): off.
+constexpr int kMergeMinSingle = LS2FM_MERGE_MIN, kMergeMinDual = LS2FM_MERGE_MIN_DUAL;
+struct RunFlags { unsigned long long cont; bool head, merged; };      // cont: lanes that continue their predecessor's run
+
+__device__ __forceinline__ RunFlags wave_runs(const uint32_t g[3], bool live, int lane, int merge_min) {
+    if (merge_min > 64) { RunFlags r; r.cont = 0ull; r.head = live; r.merged = false; return r; }
+    const uint32_t p0 = __shfl_up(g[0], 1, 64), p1 = __shfl_up(g[1], 1, 64), p2 = __shfl_up(g[2], 1, 64);
+    const int prev_live = __shfl_up((int)live, 1, 64);
+    const bool same = lane > 0 && live && prev_live != 0 && p0 == g[0] && p1 == g[1] && p2 == g[2];
+    unsigned long long m = __ballot(same);
+    if ((int)__popcll(m) < merge_min) m = 0ull;
+    RunFlags r;
+    r.cont = m;
+    r.head = live && ((m >> lane) & 1ull) == 0ull;
+    r.merged = r.head && lane < 63 && ((m >> (lane + 1)) & 1ull) != 0ull;
+    return r;
+}
+
+// v[lane] <- sum of v over the lanes of the run that STARTS at `lane` (meaningful on the run's first lane); fixed order
+template <int NV>
+__device__ __forceinline__ void run_sums(float (&v)[NV], unsigned long long cont, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long need = ((1ull << o) - 1ull) << 1;            // lanes lane+1 .. lane+o must all continue
+        const bool ok = lane + o < 64 && ((cont >> lane) & need) == need;
+        if (__ballot(ok) == 0ull) break;                                      // no run reaches that far: wave-uniform exit
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float t = __shfl_down(v[q], o, 64);
+            if (ok) v[q] += t;
+        }
+    }
+}
+
+// The items of one (point, level) with run merging: nothing for a lane that continues a run; for a run's first lane the
+// classification of for_each_item, except that a merged run of a DUAL pair is always two half items.
+template <bool DUAL, typename F>
+__device__ __forceinline__ void for_each_item_merged(const LevelC& L, const uint32_t g[3], const RunFlags& rf, F&& f) {
+    if (!rf.head) return;
+    const uint32_t lmask = (1u << L.sshift) - 1u;
+#pragma unroll
+    for (unsigned c = 0; c < 4; ++c) {
+        const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
+        const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
+        const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
+        if (s0 == s1 && !(DUAL && rf.merged)) {
+            f((int)s0, c, i0 & lmask, i1 & lmask);
+        } else {
+            f((int)s0, c, i0 & lmask, 0xFFFFu);
+            f((int)s1, c, 0xFFFFu, i1 & lmask);
+        }
+    }
+}
+
 constexpr int kFillTile = kFillThreads;          // sample points per count / fill workgroup (must agree)
 static_assert(kCountThreads == kFillThreads, "count and fill classify the same tiles");
 
@@ -103,6 +194,15 @@ inline int64_t meta_ints(int64_t n_points) {
     const int64_t n_tiles = (n_points + kFillTile - 1) / kFillTile;
     return (2 * LS2FM_MAX_LEVELS * kBins + 64 + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
 }
+
+// Scratch of the point-split slabs (dense / tiny levels whose few slabs receive every point's items: a slab's list is cut into
+// `parts` workgroups): one block of kAccSlots 64-bit accumulators per (slab, part).  A level is only split while a part keeps
+// > 16 k items, which bounds the blocks by ~n_points / 2048 per level; the plan (bin_scatter.hip) lowers `parts` to fit.
+inline int part_blocks_capacity(int64_t n_points) {
+    const int64_t want = n_points / 128 + 16;
+    return (int)(want < 2048 ? want : 2048);
+}
+inline int64_t part_acc_floats(int64_t n_points) { return (int64_t)part_blocks_capacity(n_points) * kAccSlots * 2; }
 
 inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     BinMeta bm;
@@ -112,7 +212,9 @@ inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     bm.start = meta + LS2FM_MAX_LEVELS * kBins;
     bm.level_bound = reinterpret_cast<float*>(meta + 2 * LS2FM_MAX_LEVELS * kBins);
     bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
-    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points));      // 256-byte aligned
+    bm.part_acc = reinterpret_cast<u64*>(meta + meta_ints(n_points));   // 256-byte aligned
+    bm.part_blocks = part_blocks_capacity(n_points);
+    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points) + part_acc_floats(n_points));
     return bm;
 }
 
@@ -234,7 +336,6 @@ constexpr int kScanArenaInts = kScanTiles * kScanGroup + (512 / kScanGroup) * kS
 // ---- zero fills the backward needs, run by EXTRA WORKGROUPS of the shade_bwd launch: the weight-gradient accumulators and
 // the point-split coarse levels of the gradient table(s)
 struct ZeroJob { float4* a; int64_t na; float4* b; int64_t nb; float4* c; int64_t nc; int blocks; };
-
 __device__ __forceinline__ void zero_job_run(const ZeroJob& z, const int job, const int tid, const int nt) {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t stride = (int64_t)z.blocks * nt;

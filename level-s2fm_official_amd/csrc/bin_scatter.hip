@@ -29,6 +29,7 @@
 //                  integer sums are exact: the table gradient is the exactly rounded sum of its fp32 contributions,
 //                  order-independent.  Every entry belongs to one slab: the table is written once with plain coalesced
 //                  stores (no zero fill); only point-split coarse levels are flushed with a few float atomics.
+#include <atomic>
 #include <cstdlib>
 
 #include "bin_items.h"
@@ -43,13 +44,15 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
                     int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
                     const float* __restrict__ rec2, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad,
                     BinMeta bm, int level_base) {
+    typedef typename ItemOf<DUAL>::type ItemT;
     __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
     __shared__ int lds_off[kBins];       // first LDS slot of the slab's run
     __shared__ int base[kBins];          // first global item index of the slab's run
     __shared__ int run_len[kBins];       // items of this workgroup in the slab's run
-    __shared__ Item s_items[kFillCap];
+    __shared__ ItemT s_items[kFillCap];
     __shared__ uint32_t s_gidx[kFillCap];
     __shared__ int s_total;
+    ItemT* __restrict__ g_items = reinterpret_cast<ItemT*>(bm.items);
     const int tid = threadIdx.x, lane = tid & 63, l = level_base + (int)blockIdx.y;
     for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
     __syncthreads();
@@ -71,8 +74,10 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
             const float2 e = reinterpret_cast<const float2*>(rec2)[(int64_t)l * p_pad + i];
             e0 = e.x; e1 = e.y;
         }
-        for_each_item(L, g, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
     }
+    // runs of consecutive points in one cell (bin_items.h): the same flags the counting pass derived
+    const RunFlags rf = wave_runs(g, live, lane, DUAL ? kMergeMinDual : kMergeMinSingle);
+    for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
     __syncthreads();
     // runs: LDS offsets (exclusive prefix over the slabs, wave 0) and one global reservation per slab
     if (tid < 64) {
@@ -96,37 +101,77 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     __syncthreads();
     for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
     __syncthreads();
-    if (live) {
-        for_each_item(L, g, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
-            const int by = (int)(c & 1u), bz = (int)(c >> 1);
+    // per corner pair c = by + 2 bz: the factored payload (A, B[, C]) and the two x-corners' explicit values
+    //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
+    constexpr int NV = DUAL ? 32 : 16;
+    float fa[4][2], fb[4][2], fcc[4][2], val[NV];
+    {
+        const float px0 = 1.0f - w[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int by = c & 1, bz = c >> 1;
             const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
             const float pyz = py * pz;
             const float qyz = (by ? qd[1] : -qd[1]) * pz + py * (bz ? qd[2] : -qd[2]);
-            Item it;
-            it.ij = i0 | (i1 << 16);
-            it.wx = w[0];
-            it.a0 = fmaf(qyz, r0, pyz * d0);
-            it.a1 = fmaf(qyz, r1, pyz * d1);
-            it.b0 = qd[0] * pyz * r0;
-            it.b1 = qd[0] * pyz * r1;
-            it.c0 = pyz * e0;
-            it.c1 = pyz * e1;
-            int rank = atomicAdd(&hist[slab], 1);
-            // long runs (coarse levels: consecutive samples of a ray fall into the same cell) are stored permuted, so that
-            // the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same entry (same-address
-            // LDS atomics serialise): position = rank * K mod n with K prime > n
-            const int n_run = run_len[slab];
-            if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
-            const int slot = lds_off[slab] + rank;
-            const uint32_t gi = (uint32_t)(base[slab] + rank);
-            if (slot < kFillCap) { s_items[slot] = it; s_gidx[slot] = gi; }
-            else bm.items[gi] = it;                         // more split pairs than the staging area holds: direct write
-        });
+            fa[c][0] = fmaf(qyz, r0, pyz * d0);
+            fa[c][1] = fmaf(qyz, r1, pyz * d1);
+            fb[c][0] = qd[0] * pyz * r0;
+            fb[c][1] = qd[0] * pyz * r1;
+            fcc[c][0] = pyz * e0;
+            fcc[c][1] = pyz * e1;
+            constexpr int S = DUAL ? 8 : 4;
+            val[S * c + 0] = fmaf(px0, fa[c][0], -fb[c][0]);
+            val[S * c + 1] = fmaf(px0, fa[c][1], -fb[c][1]);
+            val[S * c + 2] = fmaf(w[0], fa[c][0], fb[c][0]);
+            val[S * c + 3] = fmaf(w[0], fa[c][1], fb[c][1]);
+            if (DUAL) {
+                val[S * c + 4] = px0 * fcc[c][0];
+                val[S * c + 5] = px0 * fcc[c][1];
+                val[S * c + 6] = w[0] * fcc[c][0];
+                val[S * c + 7] = w[0] * fcc[c][1];
+            }
+        }
     }
+    if (rf.cont != 0ull) run_sums<NV>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
+    for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
+        constexpr int S = DUAL ? 8 : 4;
+        ItemT it;
+        it.ij = i0 | (i1 << 16);
+        if constexpr (DUAL) {
+            if (rf.merged) {               // half item of a merged run: the summed values of ONE x-corner, wx = 0 / 1, B = 0
+                const bool second = i0 == 0xFFFFu;
+                it.wx = second ? 1.0f : 0.0f;
+                it.a0 = val[S * c + (second ? 2 : 0)];
+                it.a1 = val[S * c + (second ? 3 : 1)];
+                it.b0 = 0.f;
+                it.b1 = 0.f;
+                it.c0 = val[S * c + (second ? 6 : 4)];
+                it.c1 = val[S * c + (second ? 7 : 5)];
+            } else {
+                it.wx = w[0];
+                it.a0 = fa[c][0]; it.a1 = fa[c][1];
+                it.b0 = fb[c][0]; it.b1 = fb[c][1];
+                it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
+            }
+        } else {
+            it.v00 = val[S * c + 0]; it.v01 = val[S * c + 1];
+            it.v10 = val[S * c + 2]; it.v11 = val[S * c + 3];
+        }
+        int rank = atomicAdd(&hist[slab], 1);
+        // long runs (coarse levels: consecutive samples of a ray fall into the same cell) are stored permuted, so that
+        // the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same entry (same-address
+        // LDS atomics serialise): position = rank * K mod n with K prime > n
+        const int n_run = run_len[slab];
+        if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
+        const int slot = lds_off[slab] + rank;
+        const uint32_t gi = (uint32_t)(base[slab] + rank);
+        if (slot < kFillCap) { s_items[slot] = it; s_gidx[slot] = gi; }
+        else g_items[gi] = it;                          // more split pairs than the staging area holds: direct write
+    });
     __syncthreads();
-    // runs of one slab are contiguous in LDS and in memory: consecutive threads write consecutive 32-byte items
+    // runs of one slab are contiguous in LDS and in memory: consecutive threads write consecutive items
     const int staged = s_total < kFillCap ? s_total : kFillCap;
-    for (int q = tid; q < staged; q += kFillThreads) bm.items[s_gidx[q]] = s_items[q];
+    for (int q = tid; q < staged; q += kFillThreads) g_items[s_gidx[q]] = s_items[q];
     // the level's first workgroup also reduces the per-ray bounds of a single contribution (written by shade_bwd) to the
     // level's bound: the accumulate workgroups read two floats instead of n_rays each
     if (blockIdx.x == 0) {
@@ -153,38 +198,13 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
 struct SlabPlan {
     int first[LS2FM_MAX_LEVELS + 1];     // first workgroup of every level
     int parts[LS2FM_MAX_LEVELS];         // item-range parts per slab of the level
+    int scratch[LS2FM_MAX_LEVELS];       // first block of the level's (slab, part) partials in BinMeta::part_acc (parts > 1)
     int headroom_bits;                   // log2 of the worst-case number of contributions to one entry
 };
 
 __device__ __forceinline__ void add_fixed(u64* slot, float v, float to_fixed) {
     // v * to_fixed is exact (power-of-two scale); |.| < 2^62 / worst-case hits by construction of the quantum
     atomicAdd(slot, (u64)__float2ll_rn(v * to_fixed));        // two's complement: integer sums are exact
-}
-
-// Two features in ONE 64-bit add: 32-bit two's complement halves, value = hi * 2^32 + lo.  The low half's borrows and carries
-// run into the high half; decoding undoes them (lo = sign-extended low word, hi = (total - lo) >> 32), which is exact as long
-// as each half's SUM fits 32 bits -- guaranteed by the quantum (packed_quantum_of).  Halves the LDS atomics of the sole-owner
-// levels (12 of 16 at the benchmark); the price is the resolution of a contribution: 2^-(30 - hits bits) of the level's bound
-// (>= 17 bits for the <= 8 k items of a slab) instead of exact -- still order-independent and deterministic.
-__device__ __forceinline__ void add_fixed2(u64* slot, float v0, float v1, float to_fixed) {
-    const int lo = __float2int_rn(v0 * to_fixed), hi = __float2int_rn(v1 * to_fixed);
-    atomicAdd(slot, ((u64)(uint32_t)hi << 32) + (u64)(long long)lo);
-}
-__device__ __forceinline__ void unpack_fixed2(u64 total, float to_float, float& v0, float& v1) {
-    const int lo = (int)(uint32_t)(total & 0xFFFFFFFFull);
-    const int hi = (int)(((long long)total - (long long)lo) >> 32);
-    v0 = (float)lo * to_float;
-    v1 = (float)hi * to_float;
-}
-// hits: an upper bound of the contributions to one entry (the items this workgroup streams)
-__device__ __forceinline__ void packed_quantum_of(float bound, int hits, float& to_fixed, float& to_float) {
-    int e_bound = 0;
-    if (bound > 0.f) (void)frexpf(bound, &e_bound);             // bound < 2^e_bound
-    const int hb = 32 - __clz(hits > 1 ? hits : 1);            // hits < 2^hb
-    int shift = 30 - hb - e_bound;                              // |sum| <= hits * bound < 2^(hb + e_bound) -> * 2^shift < 2^30
-    shift = shift > 126 ? 126 : (shift < -126 ? -126 : shift);
-    to_fixed = ldexpf(1.0f, shift);
-    to_float = ldexpf(1.0f, -shift);
 }
 
 __device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float& to_fixed, double& to_float) {
@@ -205,22 +225,26 @@ __device__ long long g_acc_stamps[8 * 4096];
 #define ACC_STAMP(k) do {} while (0)
 #endif
 
-// -DLS2FM_PACKED_ACC=true: sole-owner slabs with short lists keep each feature PAIR in one 64-bit accumulator (add_fixed2).
-// Measured (C2): slab_accumulate alone 117.5 -> 95.7 us, the step unchanged (0.547 = 0.547 ms, A/B on one box: the
-// weight-gradient chain ends the backward, not the scatter); contributions below 2^-17 of the level's bound are lost (54 of
-// 265 884 non-zero entries of the full-size golden become zero, which Adam does not forgive: it turns ANY non-zero gradient
-// into a step of the learning rate), and lists of 16 k items or more (8192-ray batches) cannot use it.  Off.
-#ifndef LS2FM_PACKED_ACC
-#define LS2FM_PACKED_ACC false
-#endif
+// (A variant that packed each feature pair into one 64-bit accumulator -- half the LDS atomics, slab_accumulate alone 117.5 ->
+// 95.7 us at C2 -- left the step unchanged and dropped contributions below 2^-17 of a level's bound, which Adam does not
+// forgive; measured and removed in round 3 / 4, `git log -S LS2FM_PACKED_ACC`.)
 
+// Point-split slabs (dense / tiny levels: every point's items fall into a handful of slabs, whose lists are cut into `parts`
+// workgroups) have two flush forms, chosen per launch (ls2fm_set_scatter_mode):
+//   combine = 1  every part leaves its 64-bit fixed-point partials in scratch; slab_combine_kernel, the next launch on the stream,
+//                sums them -- integer sums: exact and order-independent -- and writes every entry once with a plain store.  The
+//                table gradient is then the exactly rounded sum of its contributions on EVERY level, the backward repeats itself
+//                bit for bit, nothing is zeroed beforehand and no floating-point atomic is left in the path.
+//   combine = 0  float atomics into a table range zeroed by the backward's zero job (rounds 1-3): one launch fewer, sums of
+//                rounded partials in arrival order.
 template <bool DUAL, bool ADD_INTO>
 __global__ void __launch_bounds__(kAccThreads)
 slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
-                       float* __restrict__ dtable2, int block_base) {
+                       float* __restrict__ dtable2, int block_base, int combine) {
+    typedef typename ItemOf<DUAL>::type ItemT;
     constexpr bool add_into = ADD_INTO;
     constexpr int F = DUAL ? 4 : 2;
-    __shared__ u64 acc[kAccSlots];
+    __shared__ __attribute__((aligned(16))) u64 acc[kAccSlots];
     const int tid = threadIdx.x;
     ACC_STAMP(0);
     const int bid = block_base + (int)blockIdx.x;        // a launch may cover a range of levels only (ls2fm_render_opts level groups)
@@ -234,107 +258,182 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
     const uint32_t lo = slab << sshift;
     const uint32_t hi = lo + (1u << sshift) < size ? lo + (1u << sshift) : size;
 
-    // this workgroup's share of the slab's payload list; the first trip's loads are issued before the LDS is zeroed
+    // this workgroup's share of the slab's payload list.  Items are taken kAccBatch per lane at a time, the NEXT batch's loads
+    // in flight while the current one is added (a hashed slab of the benchmark is one batch: its loads are issued before the LDS
+    // is zeroed and the streaming phase is LDS atomics only -- per-workgroup stamps: 6.2 -> ... us)
     const int n_items = bm.count[l * kBins + slab];
-    const Item* __restrict__ list = bm.items + bm.start[l * kBins + slab];
+    const ItemT* __restrict__ list = reinterpret_cast<const ItemT*>(bm.items) + bm.start[l * kBins + slab];
     const int j_lo = (int)((int64_t)n_items * part / parts), j_hi = (int)((int64_t)n_items * (part + 1) / parts);
-    if (add_into && j_hi <= j_lo) return;                // nothing to add to the tables' current values
-    uint4 q0 = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u), q1 = make_uint4(0u, 0u, 0u, 0u);
-    if (j_lo + tid < j_hi) {
-        q0 = reinterpret_cast<const uint4*>(list + j_lo + tid)[0];
-        q1 = reinterpret_cast<const uint4*>(list + j_lo + tid)[1];
+    // nothing to add to the tables' current values (decided per SLAB: slab_combine_kernel skips such a slab's partials)
+    if (add_into && n_items == 0) return;
+    // (the loads are UNCONDITIONAL -- out-of-range lanes re-read the list's last item and are masked when it is used: a load
+    // under a branch makes the compiler wait for it right there, one ~2 us round trip per item instead of one per batch)
+    const int j_last = j_hi > j_lo ? j_hi - 1 : j_lo;
+    ItemT buf[kAccBatch];
+#pragma unroll
+    for (int u = 0; u < kAccBatch; ++u) {
+        const int j = j_lo + tid + u * kAccThreads;
+        buf[u] = list[j < j_hi ? j : j_last];
     }
-    // sole owner of its entries and a short list: the feature pairs share a 64-bit accumulator (add_fixed2)
-    constexpr bool packing = LS2FM_PACKED_ACC;
-    const bool packed = packing && parts == 1 && j_hi - j_lo < (1 << 14);
-    const int n_slots = (packed ? F / 2 : F) * (int)(hi - lo);
-    for (int e = tid; e < n_slots; e += kAccThreads) acc[e] = 0ull;
+    // LDS layout: FEATURE-MAJOR, acc[f * E + entry] with E = the slab size.  (Entry-major -- 32 bytes per entry -- put the 64
+    // lanes of one ds_add_u64 on only FOUR bank pairs, (8 entry + 2 f) mod 32: every atomic instruction of the streaming phase
+    // was a 16-way bank conflict; feature-major spreads them over all 16 pairs.  Per-workgroup stamps, hashed slab of 4096
+    // items: streaming 6.0 -> ... us.)
+    const int E = 1 << sshift;
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int e = tid; e < kAccSlots / 2; e += kAccThreads) reinterpret_cast<uint4*>(acc)[e] = z;
+    }
     // bound of a single contribution on this level (reduced over the rays by scatter_fill); second grid: rows 16..31
     float to_fixed1, to_fixed2;
     double to_float1, to_float2;
-    float pk_float1 = 0.f, pk_float2 = 0.f;
-    if (packed) {
-        packed_quantum_of(bm.level_bound[l], j_hi - j_lo, to_fixed1, pk_float1);
-        packed_quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, j_hi - j_lo, to_fixed2, pk_float2);
-        to_float1 = to_float2 = 0.0;
-    } else {
-        quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
-        quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
-    }
+    quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
+    quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
     __syncthreads();
     ACC_STAMP(1);
 
-    // streamed, 32 bytes per lane, fully coalesced
-    for (int j = j_lo + tid; j < j_hi; j += kAccThreads) {
-        if (j != j_lo + tid) {
-            q0 = reinterpret_cast<const uint4*>(list + j)[0];
-            q1 = reinterpret_cast<const uint4*>(list + j)[1];
-        }
-        const uint32_t i0 = q0.x & 0xFFFFu, i1 = q0.x >> 16;
-        const float wx = __uint_as_float(q0.y);
-        const float a0 = __uint_as_float(q0.z), a1 = __uint_as_float(q0.w);
-        const float b0 = __uint_as_float(q1.x), b1 = __uint_as_float(q1.y);
-        const float c0 = __uint_as_float(q1.z), c1 = __uint_as_float(q1.w);
-        const float px0 = 1.0f - wx;
-        if (packed) {
+    auto add_item = [&](const ItemT& it) {
+        const uint32_t i0 = it.ij & 0xFFFFu, i1 = it.ij >> 16;
+        if constexpr (DUAL) {
+            const float px0 = 1.0f - it.wx;
+            if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
+                u64* slot = acc + i0;
+                add_fixed(slot, fmaf(px0, it.a0, -it.b0), to_fixed1);
+                add_fixed(slot + E, fmaf(px0, it.a1, -it.b1), to_fixed1);
+                add_fixed(slot + 2 * E, px0 * it.c0, to_fixed2);
+                add_fixed(slot + 3 * E, px0 * it.c1, to_fixed2);
+            }
+            if (i1 != 0xFFFFu) {                             // x-corner 1: px = wx, derivative sign +
+                u64* slot = acc + i1;
+                add_fixed(slot, fmaf(it.wx, it.a0, it.b0), to_fixed1);
+                add_fixed(slot + E, fmaf(it.wx, it.a1, it.b1), to_fixed1);
+                add_fixed(slot + 2 * E, it.wx * it.c0, to_fixed2);
+                add_fixed(slot + 3 * E, it.wx * it.c1, to_fixed2);
+            }
+        } else {                                             // explicit corner values (formed by scatter_fill)
             if (i0 != 0xFFFFu) {
-                u64* slot = acc + (F / 2) * i0;
-                add_fixed2(slot, fmaf(px0, a0, -b0), fmaf(px0, a1, -b1), to_fixed1);
-                if (DUAL) add_fixed2(slot + 1, px0 * c0, px0 * c1, to_fixed2);
+                add_fixed(acc + i0, it.v00, to_fixed1);
+                add_fixed(acc + E + i0, it.v01, to_fixed1);
             }
             if (i1 != 0xFFFFu) {
-                u64* slot = acc + (F / 2) * i1;
-                add_fixed2(slot, fmaf(wx, a0, b0), fmaf(wx, a1, b1), to_fixed1);
-                if (DUAL) add_fixed2(slot + 1, wx * c0, wx * c1, to_fixed2);
+                add_fixed(acc + i1, it.v10, to_fixed1);
+                add_fixed(acc + E + i1, it.v11, to_fixed1);
             }
-            continue;
         }
-        if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
-            u64* slot = acc + F * i0;
-            add_fixed(slot + 0, fmaf(px0, a0, -b0), to_fixed1);
-            add_fixed(slot + 1, fmaf(px0, a1, -b1), to_fixed1);
-            if (DUAL) { add_fixed(slot + 2, px0 * c0, to_fixed2); add_fixed(slot + 3, px0 * c1, to_fixed2); }
+    };
+    for (int base = j_lo + tid; base < j_hi; base += kAccBatch * kAccThreads) {
+        ItemT cur[kAccBatch];
+#pragma unroll
+        for (int u = 0; u < kAccBatch; ++u) cur[u] = buf[u];
+#pragma unroll
+        for (int u = 0; u < kAccBatch; ++u) {                // the next batch: in flight during this batch's atomics (unconditional,
+            const int j = base + (kAccBatch + u) * kAccThreads;      // see above; past the end it re-reads the last item)
+            buf[u] = list[j < j_hi ? j : j_last];
         }
-        if (i1 != 0xFFFFu) {                             // x-corner 1: px = wx, derivative sign +
-            u64* slot = acc + F * i1;
-            add_fixed(slot + 0, fmaf(wx, a0, b0), to_fixed1);
-            add_fixed(slot + 1, fmaf(wx, a1, b1), to_fixed1);
-            if (DUAL) { add_fixed(slot + 2, wx * c0, to_fixed2); add_fixed(slot + 3, wx * c1, to_fixed2); }
-        }
+#pragma unroll
+        for (int u = 0; u < kAccBatch; ++u)
+            if (base + u * kAccThreads < j_hi) add_item(cur[u]);
     }
     __syncthreads();
     ACC_STAMP(2);
     // ---- flush: fixed point -> fp32 (one rounding of the exact sum); slot e = F * entry + feature
     float* dst1 = dtable1 + 2ull * (lv.offset[l] + lo);
     float* dst2 = DUAL ? dtable2 + 2ull * (lv.offset[l] + lo) : nullptr;
-    if (packed) {                                        // slot e = (F / 2) * entry + grid: one float2 per slot (parts == 1)
-        for (int e = tid; e < n_slots; e += kAccThreads) {
-            const int entry = DUAL ? e >> 1 : e;
-            const bool second = DUAL && (e & 1);
-            float2 v;
-            unpack_fixed2(acc[e], second ? pk_float2 : pk_float1, v.x, v.y);
-            float2* dst = reinterpret_cast<float2*>((second ? dst2 : dst1) + 2 * entry);
-            if (add_into) {
-                if (acc[e] != 0ull) { float2 o = *dst; o.x += v.x; o.y += v.y; *dst = o; }
-            } else *dst = v;
-        }
+    if (parts > 1 && combine) {          // partials for slab_combine_kernel: plain coalesced stores, one block per (slab, part)
+        uint4* mine = reinterpret_cast<uint4*>(bm.part_acc + (size_t)(plan.scratch[l] + (int)wg) * kAccSlots);
+        for (int e = tid; e < kAccSlots / 2; e += kAccThreads) mine[e] = reinterpret_cast<const uint4*>(acc)[e];
         return;
     }
-    for (int e = tid; e < n_slots; e += kAccThreads) {
-        const int entry = e / F, f = e % F;
-        const bool second = DUAL && f >= 2;
-        float* dst = (second ? dst2 : dst1) + 2 * entry + (f & 1);
-        const float v = (float)((double)(long long)acc[e] * (second ? to_float2 : to_float1));
-        if (add_into) {                                           // a second producer of the same table: += (ordered behind the first)
-            if (acc[e] != 0ull) { if (parts == 1) *dst += v; else atomicAdd(dst, v); }
-        } else if (parts == 1) *dst = v;                          // sole owner of the entry
-        else if (acc[e] != 0ull) atomicAdd(dst, v);               // point-split coarse level, zeroed by the host
+    // one thread per ENTRY: its F accumulators (one or two 16-byte LDS reads), one float2 per grid
+    for (int entry = tid; entry < (int)(hi - lo); entry += kAccThreads) {
+        u64 tot[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) tot[f] = acc[f * E + entry];
+        float2 v1 = make_float2((float)((double)(long long)tot[0] * to_float1), (float)((double)(long long)tot[1] * to_float1));
+        float* d1 = dst1 + 2 * entry;
+        if (parts > 1) {                                          // float-atomic form (range zeroed by the backward's zero job
+            if (tot[0] != 0ull) atomicAdd(d1, v1.x);              // -- or holding the first producer's sums: add_into)
+            if (tot[1] != 0ull) atomicAdd(d1 + 1, v1.y);
+        } else if (add_into) {                                    // a second producer of the same table: += (ordered behind the first)
+            if ((tot[0] | tot[1]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d1); v1.x += o.x; v1.y += o.y; *reinterpret_cast<float2*>(d1) = v1; }
+        } else *reinterpret_cast<float2*>(d1) = v1;               // sole writer of the entry
+        if constexpr (DUAL) {
+            float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
+            float* d2 = dst2 + 2 * entry;
+            if (parts > 1) {
+                if (tot[2] != 0ull) atomicAdd(d2, v2.x);
+                if (tot[3] != 0ull) atomicAdd(d2 + 1, v2.y);
+            } else if (add_into) {
+                if ((tot[2] | tot[3]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d2); v2.x += o.x; v2.y += o.y; *reinterpret_cast<float2*>(d2) = v2; }
+            } else *reinterpret_cast<float2*>(d2) = v2;
+        }
     }
 #ifdef LS2FM_STAMPS
     __syncthreads();
     ACC_STAMP(3);
     if (tid == 0 && blockIdx.x < 4096) { g_acc_stamps[8 * blockIdx.x + 4] = l; g_acc_stamps[8 * blockIdx.x + 5] = j_hi - j_lo; }
 #endif
+}
+
+// ---- the point-split slabs' partials -> table entries (combine form).  Block = 1024 entries of one split slab.
+struct CombinePlan { int first[LS2FM_MAX_LEVELS + 1]; };      // first block of every level (levels with parts == 1: none)
+
+template <bool DUAL, bool ADD_INTO>
+__global__ void __launch_bounds__(kAccThreads)
+slab_combine_kernel(LevelSet lv, SlabPlan plan, CombinePlan cp, BinMeta bm, int sshift, float* __restrict__ dtable1,
+                    float* __restrict__ dtable2, int block_base) {
+    constexpr int F = DUAL ? 4 : 2;
+    const int bid = block_base + (int)blockIdx.x;
+    int l = 0;
+    while (bid >= cp.first[l + 1]) ++l;
+    const int chunks = (1 << sshift) / kAccThreads;           // blocks per slab
+    const int rel = bid - cp.first[l];
+    const uint32_t slab = (uint32_t)(rel / chunks);
+    const int entry = (rel % chunks) * kAccThreads + (int)threadIdx.x;
+    const uint32_t lo = slab << sshift;
+    const uint32_t hi = lo + (1u << sshift) < lv.size[l] ? lo + (1u << sshift) : lv.size[l];
+    if (lo + (uint32_t)entry >= hi) return;
+    if (ADD_INTO && bm.count[l * kBins + (int)slab] == 0) return;         // its parts returned without writing partials
+    const int parts = plan.parts[l];
+    float to_fixed, to_fixed2;
+    double to_float1, to_float2;
+    quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed, to_float1);
+    quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
+    // partials are feature-major like the accumulators: [part][f * E + entry].  Loads of kCombineBatch parts are issued together
+    // (a part beyond the last re-reads the last one and is masked): one memory round trip per batch, not per part
+    const int E = 1 << sshift;
+    const u64* __restrict__ src = bm.part_acc + (size_t)(plan.scratch[l] + (int)slab * parts) * kAccSlots + entry;
+    u64 tot[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) tot[f] = 0ull;
+    constexpr int kCombineBatch = 8;
+    for (int q0 = 0; q0 < parts; q0 += kCombineBatch) {
+        u64 v[kCombineBatch][F];
+#pragma unroll
+        for (int u = 0; u < kCombineBatch; ++u) {
+            const int q = q0 + u < parts ? q0 + u : parts - 1;
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[u][f] = src[(size_t)q * kAccSlots + f * E];
+        }
+#pragma unroll
+        for (int u = 0; u < kCombineBatch; ++u)
+            if (q0 + u < parts) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) tot[f] += v[u][f];
+            }
+    }
+    float2 v1 = make_float2((float)((double)(long long)tot[0] * to_float1), (float)((double)(long long)tot[1] * to_float1));
+    float2* d1 = reinterpret_cast<float2*>(dtable1 + 2ull * (lv.offset[l] + lo + entry));
+    if (ADD_INTO) {
+        if ((tot[0] | tot[1]) != 0ull) { const float2 o = *d1; v1.x += o.x; v1.y += o.y; *d1 = v1; }
+    } else *d1 = v1;
+    if constexpr (DUAL) {
+        float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
+        float2* d2 = reinterpret_cast<float2*>(dtable2 + 2ull * (lv.offset[l] + lo + entry));
+        if (ADD_INTO) {
+            if ((tot[2] | tot[3]) != 0ull) { const float2 o = *d2; v2.x += o.x; v2.y += o.y; *d2 = v2; }
+        } else *d2 = v2;
+    }
 }
 
 bool levels_fit(const ls2fm_grid_desc* grid, int sshift) {
@@ -347,8 +446,8 @@ bool levels_fit(const ls2fm_grid_desc* grid, int sshift) {
 
 // floats of workspace the scatter needs: meta + worst case 8 items (4 pairs, each split) of 32 bytes per (point, level)
 int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points) {
-    static_assert(sizeof(Item) == 32, "item layout");
-    return meta_ints(n_points) + 8 * 8 * (int64_t)n_levels * n_points + 64;
+    static_assert(sizeof(Item) == 32 && sizeof(ItemS) == 20, "item layouts");
+    return meta_ints(n_points) + part_acc_floats(n_points) + 8 * 8 * (int64_t)n_levels * n_points + 64;
 }
 
 size_t ls2fm_bin_counts_bytes() { return 0; }      // nothing to zero: every count is written, not accumulated
@@ -372,44 +471,64 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
 }
 
 namespace {
-struct HostPlan { SlabPlan plan; int total, zero_lo, zero_hi; };
+struct HostPlan { SlabPlan plan; CombinePlan cp; int total, zero_lo, zero_hi; };
+
+// 1: the point-split levels are combined in fixed point by slab_combine_kernel (deterministic, exactly rounded; default)
+// 0: float atomics into a zeroed range (rounds 1-3)
+std::atomic<int> g_scatter_mode{[] { const char* e = getenv("LS2FM_SCATTER_MODE"); return e ? atoi(e) : 1; }()};
 
 HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift) {
-    HostPlan h{};
-    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) h.plan.parts[l] = 1;
-    h.plan.headroom_bits = 4;                // 8 corners per point (+1)
-    while ((1ll << (h.plan.headroom_bits - 4)) < n_points) ++h.plan.headroom_bits;
-    h.zero_lo = h.zero_hi = -1;
-    const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
-    for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
-        h.plan.first[l] = h.total;
-        if (l >= grid->n_levels) continue;
-        const int slabs = level_slabs(grid->size[l], sshift);
-        int parts = 1;
-        if (!grid->hashed[l] || slabs < 16) {
-            // dense / tiny level: 4 pair items per point spread over few slabs -> split the slabs' lists
-            const int64_t per_block = 4 * n_points / slabs;
-            parts = (int)((per_block + target - 1) / target);
-            if (parts > kMaxParts) parts = kMaxParts;
-            if (parts < 1) parts = 1;
+    const int capacity = part_blocks_capacity(n_points);
+    const int chunks = (1 << sshift) / kAccThreads;
+    for (int max_parts = kMaxParts;; --max_parts) {
+        HostPlan h{};
+        for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) h.plan.parts[l] = 1;
+        h.plan.headroom_bits = 4;                // 8 corners per point (+1)
+        while ((1ll << (h.plan.headroom_bits - 4)) < n_points) ++h.plan.headroom_bits;
+        h.zero_lo = h.zero_hi = -1;
+        const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
+        int scratch = 0, comb = 0;
+        for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
+            h.plan.first[l] = h.total;
+            h.cp.first[l] = comb;
+            if (l >= grid->n_levels) continue;
+            const int slabs = level_slabs(grid->size[l], sshift);
+            int parts = 1;
+            if (!grid->hashed[l] || slabs < 16) {
+                // dense / tiny level: 4 pair items per point spread over few slabs -> split the slabs' lists
+                const int64_t per_block = 4 * n_points / slabs;
+                parts = (int)((per_block + target - 1) / target);
+                if (parts > max_parts) parts = max_parts;
+                if (parts < 1) parts = 1;
+            }
+            h.plan.parts[l] = parts;
+            h.plan.scratch[l] = scratch;
+            if (parts > 1) {
+                scratch += slabs * parts;        // one block of partials per (slab, part)
+                comb += slabs * chunks;
+                if (h.zero_lo < 0) h.zero_lo = l;
+                h.zero_hi = l;
+            }
+            h.total += slabs * parts;
         }
-        h.plan.parts[l] = parts;
-        if (parts > 1) {      // atomically flushed level: zeroed first (one range covering all such levels)
-            if (h.zero_lo < 0) h.zero_lo = l;
-            h.zero_hi = l;
-        }
-        h.total += slabs * parts;
+        if (scratch <= capacity || max_parts == 1) return h;     // (never more blocks than n_points / 2048 per level: fits)
     }
-    return h;
 }
 }  // namespace
 
-// the point-split coarse levels are flushed with float atomics: their range of the gradient table(s) is zeroed first (by
-// leading workgroups of the shade_bwd launch)
+extern "C" int ls2fm_set_scatter_mode(int mode) {
+    if (mode != 0 && mode != 1) return LS2FM_ERR_INVALID_ARGUMENT;
+    g_scatter_mode.store(mode);
+    return LS2FM_OK;
+}
+extern "C" int ls2fm_get_scatter_mode(void) { return g_scatter_mode.load(); }
+
+// float-atomic flush of the point-split coarse levels (mode 0): their range of the gradient table(s) is zeroed first (by
+// leading workgroups of the shade_bwd launch); mode 1: every entry is written once with a plain store, nothing to zero
 void ls2fm_scatter_zero_range(const ls2fm_grid_desc* grid, int64_t n_points, bool dual, int64_t* first, int64_t* count) {
     const HostPlan h = make_plan(grid, n_points, ls2fm_slab_shift(dual ? 1 : 0));
     *first = 0; *count = 0;
-    if (h.zero_lo < 0) return;               // levels in between that have a sole owner are overwritten afterwards anyway
+    if (g_scatter_mode.load() != 0 || h.zero_lo < 0) return;   // levels in between that have a sole owner are overwritten afterwards anyway
     *first = grid->offset[h.zero_lo];
     *count = (int64_t)grid->offset[h.zero_hi] + grid->size[h.zero_hi] - *first;
 }
@@ -420,9 +539,9 @@ extern "C" int ls2fm_debug_acc_stamps(long long* host) {
 }
 #endif
 
-// dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid; ls2fm_launch_scatter_zero must
-// have run on them before.  add_into: the sums are ADDED to the tables' current values instead (entries without items untouched,
-// nothing zeroed beforehand): a second gradient producer, ordered behind the first one by the caller.
+// dtable1 (and dtable2: dual field, both grids in one pass) are OVERWRITTEN over the whole grid (mode 0: the zero job of
+// ls2fm_scatter_zero_range must have run on them before).  add_into: the sums are ADDED to the tables' current values instead
+// (entries without items untouched, nothing zeroed beforehand): a second gradient producer, ordered behind the first one by the caller.
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
                                  hipStream_t stream, int level_lo, int level_hi, int add_into) {
     const bool dual = dtable2 != nullptr;
@@ -430,14 +549,24 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
     const HostPlan h = make_plan(grid, n_points, sshift);
+    const int combine = g_scatter_mode.load() != 0 ? 1 : 0;
     if (level_hi < 0) level_hi = grid->n_levels;
     const int base = h.plan.first[level_lo], blocks = h.plan.first[level_hi] - base;
     if (blocks <= 0) return LS2FM_OK;
     if (dual)
         (add_into ? slab_accumulate_kernel<true, true> : slab_accumulate_kernel<true, false>)<<<blocks, kAccThreads, 0, stream>>>(
-            lv, h.plan, bm, sshift, dtable1, dtable2, base);
+            lv, h.plan, bm, sshift, dtable1, dtable2, base, combine);
     else
         (add_into ? slab_accumulate_kernel<false, true> : slab_accumulate_kernel<false, false>)<<<blocks, kAccThreads, 0, stream>>>(
-            lv, h.plan, bm, sshift, dtable1, nullptr, base);
+            lv, h.plan, bm, sshift, dtable1, nullptr, base, combine);
+    const int cbase = h.cp.first[level_lo], cblocks = h.cp.first[level_hi] - cbase;
+    if (combine && cblocks > 0) {
+        if (dual)
+            (add_into ? slab_combine_kernel<true, true> : slab_combine_kernel<true, false>)<<<cblocks, kAccThreads, 0, stream>>>(
+                lv, h.plan, h.cp, bm, sshift, dtable1, dtable2, cbase);
+        else
+            (add_into ? slab_combine_kernel<false, true> : slab_combine_kernel<false, false>)<<<cblocks, kAccThreads, 0, stream>>>(
+                lv, h.plan, h.cp, bm, sshift, dtable1, nullptr, cbase);
+    }
     return ls2fm_launch_status();
 }

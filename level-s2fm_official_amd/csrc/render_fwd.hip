@@ -369,14 +369,20 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                 }
             }
         }
-        if (counting) {        // the classification of scatter_fill (for_each_item, bin_items.h) from the corner entries
-                               // already at hand: pair c = (by, bz) -> x-corners k = 2 by + 4 bz and k + 1
+        if (counting) {        // the classification of scatter_fill (for_each_item_merged, bin_items.h) from the corner entries
+                               // already at hand: pair c = (by, bz) -> x-corners k = 2 by + 4 bz and k + 1.  Every lane in
+                               // here is live and so is its predecessor (live lanes are a prefix of the wave): the run flags
+                               // are those the fill pass derives from the same cells
+            const RunFlags rf = wave_runs(g, true, tid & 63, ex.dual != 0 ? kMergeMinDual : kMergeMinSingle);
+            if (rf.head) {
+                const bool halves = ex.dual != 0 && rf.merged;                // a merged run of a dual pair: two half items
 #pragma unroll
-            for (int cp = 0; cp < 4; ++cp) {
-                const uint32_t i0 = c.idx[2 * cp] - lv.offset, i1 = c.idx[2 * cp + 1] - lv.offset;
-                const uint32_t s0 = i0 >> ex.sshift, s1 = i1 >> ex.sshift;
-                atomicAdd(&hist[tid / kFillTile][s0], 1);
-                if (s1 != s0) atomicAdd(&hist[tid / kFillTile][s1], 1);       // split pair: two half items
+                for (int cp = 0; cp < 4; ++cp) {
+                    const uint32_t i0 = c.idx[2 * cp] - lv.offset, i1 = c.idx[2 * cp + 1] - lv.offset;
+                    const uint32_t s0 = i0 >> ex.sshift, s1 = i1 >> ex.sshift;
+                    atomicAdd(&hist[tid / kFillTile][s0], 1);
+                    if (s1 != s0 || halves) atomicAdd(&hist[tid / kFillTile][s1], 1);       // split pair: two half items
+                }
             }
         }
     }

@@ -609,7 +609,7 @@ int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, i
     zero.na = (w.dbeta - w.wg) / 4;
     int64_t first = 0, count = 0;
     ls2fm_scatter_zero_range(zero_grid, w.p, dtable2 != nullptr, &first, &count);      // entries (level offsets: multiples of 8)
-    if (count > 0) {
+    if (count > 0) {                          // (float-atomic flush of the point-split levels only, ls2fm_set_scatter_mode(0))
         zero.b = reinterpret_cast<float4*>(dtable1 + 2 * first);
         zero.nb = count / 2;
         if (dtable2) { zero.c = reinterpret_cast<float4*>(dtable2 + 2 * first); zero.nc = count / 2; }

@@ -525,6 +525,10 @@ class _Render(torch.autograd.Function):
         # multi-GPU: scatter the levels in groups and all-reduce a group's table slices while the next group is scattered
         from . import dist as _dist
         n_groups = int(getattr(ps[0], "_ls2fm_overlap_groups", 0)) if _dist.is_distributed() else 0
+        if n_groups > 1 and getattr(ps[0], "_ls2fm_group_exchange", None) is not None and fl is not None and fl.depth_node is not None:
+            # a traced-depth node rides in this backward (ls2fm_depth_backward adds into the tables BEHIND the scatter: a group's
+            # slices would not be final at its event): a pipelined sharded optimizer then exchanges at its step() instead
+            n_groups = 0
         events = []
         if n_groups > 1:
             n_groups = min(n_groups, 4, g1.n_levels)
@@ -562,7 +566,10 @@ class _Render(torch.autograd.Function):
             _publish_pass_gradients(ps, flat)          # (level groups: reductions of `flat` are already in flight -- no late adds)
         if events:
             tables = [grads[0]] + ([grads[_RAD_TABLE_AT]] if dual else [])
-            _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels, owners=ps)
+            # a pipelined sharded optimizer takes the groups itself (reduce-scatter -> Adam -> all-gather per group); else all-reduces
+            hook = getattr(ps[0], "_ls2fm_group_exchange", None)
+            if hook is None or not hook(flat, tables, list(g1.offset), events, g1.n_levels):
+                _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels, owners=ps)
         if want_pose:
             d_center, d_ray = d_center.view(ctx.pose_shape), d_ray.view(ctx.pose_shape)
         if d_dref is not None:

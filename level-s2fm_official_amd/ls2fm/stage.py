@@ -145,7 +145,7 @@ class RenderStage:
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
                  eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None,
-                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None, share_gradients=False):
+                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None, share_gradients=False, shard_groups=1):
         """lr / lr_color: the reference's two field groups (`[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(),
         lr_color}]`, BA.py:79-83; lr_color=None: one rate); extra_params: tensors (one more group at `lr`) or
         `{"params": [...], "lr": x}` dicts (the pose groups of BA.py:60-75).  ONE ExponentialLR factor for all groups,
@@ -155,7 +155,8 @@ class RenderStage:
         apply 1/world of its local gradient and the replicas would drift apart) -- or sharded=True: the update is
         `ls2fm.dist.ShardedAdam` (reduce-scatter of the flat gradient buffer, Adam on this rank's 1/world of the parameters,
         all-gather of the updated shards; async_gather: the all-gather runs on the communication stream until the next step's
-        first parameter read).  Fields only: pose groups (extra_params) take the all-reduce form."""
+        first parameter read; shard_groups >= 2: the exchange is pipelined by level groups of the two tables, `ShardedAdam`).
+        Fields only: pose groups (extra_params) take the all-reduce form."""
         self.opt, self.renderer, self.sdf, self.rad = opt, renderer, sdf_field, rad_field
         dev = next(sdf_field.parameters()).device
         w = weights or {}
@@ -176,7 +177,7 @@ class RenderStage:
                 raise NotImplementedError("ls2fm.stage.RenderStage(sharded=True): the two field groups only, eager steps only")
             from .dist import ShardedAdam
             self.optim = ShardedAdam.for_fields(sdf_field, rad_field, lr=lr, lr_color=lr_color, betas=betas, eps=eps,
-                                                scheduled_gamma=self.gamma, async_gather=async_gather)
+                                                scheduled_gamma=self.gamma, async_gather=async_gather, n_groups=shard_groups)
             self.params = list(self.optim.params)
         else:
             self.optim = FusedAdam(groups, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)

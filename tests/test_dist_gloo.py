@@ -139,6 +139,78 @@ def _sharded_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _pipelined_worker(rank, world, port, out_dir):
+    """ShardedAdam(n_groups >= 2): per level group reduce-scatter -> Adam on this rank's slice -> all-gather, small tensors and
+    slice remainders replicated == one process running Adam on the summed gradients; state_dict round trip; close()"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ls2fm import fused
+        g = torch.Generator().manual_seed(0)
+        # two "hash tables" of 5 levels (entries: 8, 24, 40, 64, 64 -> 2 floats each) between small tensors of odd sizes
+        level_offsets = [0, 8, 32, 72, 136, 200]
+        shapes = [(400,), (64, 35), (64, 1), (17,), (1,), (400,), (3, 64), (5,)]
+        tables_at = (0, 5)
+        init = [torch.randn(sh, generator=g) for sh in shapes]
+        lrs = [1e-2 if k < 5 else 3e-3 for k in range(len(shapes))]
+        for n_groups in (2, 3):
+            params = [torch.nn.Parameter(t.clone()) for t in init]
+            ref = [torch.nn.Parameter(t.clone()) for t in init]
+            ref_opt = torch.optim.Adam([dict(params=ref[:5], lr=1e-2), dict(params=ref[5:], lr=3e-3)])
+            opt = ldist.ShardedAdam(params, group_lrs=lrs, update=lambda groups: torch.optim.Adam(groups), n_groups=n_groups,
+                                    tables=[params[k] for k in tables_at], level_offsets=level_offsets)
+            assert opt.n_groups == n_groups and opt._pipe is not None
+            sharded = sum(pc["n"] for grp in opt._pipe["pieces"] for pc in grp)
+            assert sharded >= 2 * 400 - 2 * n_groups * 4 * world            # all of both tables but the slices' remainders
+            assert getattr(params[0], "_ls2fm_overlap_groups") == n_groups
+            for it in range(4):
+                per_rank = [[torch.randn(sh, generator=g) for sh in shapes] for _ in range(world)]
+                if it % 2 == 0:
+                    flat, views = fused.flat_gradient_views(params)
+                    for v, t in zip(views, per_rank[rank]):
+                        v.copy_(t)
+                    for p_, v in zip(params, views):
+                        p_.grad = v
+                else:
+                    for p_, t in zip(params, per_rank[rank]):
+                        p_.grad = t.clone()
+                        p_._ls2fm_grad_flat = None
+                opt.step()
+                for p_, *gs in zip(ref, *per_rank):
+                    p_.grad = sum(gs)
+                ref_opt.step()
+                for k, (p_, q) in enumerate(zip(params, ref)):
+                    assert torch.allclose(p_.detach(), q.detach(), rtol=0, atol=1e-6), (n_groups, it, k, float((p_ - q).abs().max()))
+            # per-rank state: a fresh optimizer over the same values continues identically after load_state_dict
+            import copy
+            state = copy.deepcopy(opt.state_dict())                  # (as torch.save / torch.load would hand it over)
+            params2 = [torch.nn.Parameter(p_.detach().clone()) for p_ in params]
+            opt2 = ldist.ShardedAdam(params2, group_lrs=lrs, update=lambda groups: torch.optim.Adam(groups), n_groups=n_groups,
+                                     tables=[params2[k] for k in tables_at], level_offsets=level_offsets)
+            opt2.load_state_dict(state)
+            per_rank = [[torch.randn(sh, generator=g) for sh in shapes] for _ in range(world)]
+            for ps_, o in ((params, opt), (params2, opt2)):
+                for p_, t in zip(ps_, per_rank[rank]):
+                    p_.grad = t.clone()
+                    p_._ls2fm_grad_flat = None
+                o.step()
+            for k, (p_, q) in enumerate(zip(params, params2)):
+                assert torch.equal(p_.detach(), q.detach()), (n_groups, k)
+            opt.close(); opt2.close()
+            assert not hasattr(params[0], "_ls2fm_group_exchange") and not hasattr(params[0], "_ls2fm_flat_total")
+        with open(os.path.join(out_dir, f"pipe_ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_sharded_adam_two_rank_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_pipelined_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "pipe_ok0").exists() and (tmp_path / "pipe_ok1").exists()
+
+
 def test_sharded_adam_two_rank_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -99,7 +99,7 @@ def test_one_rank_rccl_overlapped_reduction(tmp_path):
     assert (tmp_path / "ok0").exists()
 
 
-def _stage_worker(rank, world, port, out_dir, backend, async_gather):
+def _stage_worker(rank, world, port, out_dir, backend, async_gather, shard_groups=1):
     """8 steps of the sharded stage (reduce-scatter -> Adam on this rank's shard -> all-gather) against 8 steps of the
     single-process RenderStage over all rays: same parameter trajectory"""
     import sys
@@ -131,8 +131,9 @@ def _stage_worker(rank, world, port, out_dir, backend, async_gather):
     try:
         sdf_b, rad_b, _ = _randomized(opt, 211)
         st_b = stage.RenderStage(opt, ren, sdf_b, rad_b, weights=w, lr=2e-3, lr_end=2e-4, max_iter=steps, lr_color=1e-3, eps=1e-15,
-                                 sharded=True, async_gather=async_gather)
+                                 sharded=True, async_gather=async_gather, shard_groups=shard_groups)
         assert st_b.optim.world == world and st_b.optim.shard * world == st_b.optim.total
+        assert st_b.optim.n_groups == shard_groups
         losses = []
         for c, r, gt in batches:
             cs, rs = ldist.shard_rays(c, r)                     # by view: one view per rank
@@ -140,8 +141,13 @@ def _stage_worker(rank, world, port, out_dir, backend, async_gather):
             losses.append(float(st_b.step(cs.contiguous(), rs.contiguous(), gs.contiguous())["loss_all"]))
         st_b.optim.wait_params()
         torch.cuda.synchronize()
-        n_state = sum(s_["exp_avg"].numel() for s_ in st_b.optim.inner.state.values())
-        assert n_state <= st_b.optim.shard                      # optimizer state / world
+        if shard_groups == 1:
+            n_state = sum(s_["exp_avg"].numel() for s_ in st_b.optim.inner.state.values())
+            assert n_state <= st_b.optim.shard                      # optimizer state / world
+        else:                                                   # pipelined: table slices / world + the replicated small tensors
+            pp = st_b.optim._pipe
+            n_state = sum(s_["exp_avg"].numel() for o in pp["inner"] if o is not None for s_ in o.state.values())
+            assert n_state == sum(pc["shard"] for grp in pp["pieces"] for pc in grp) <= st_b.optim.shard
         from conftest import rel_err
         for (k, pa), (_, pb) in zip(list(sdf_a.named_parameters()) + list(rad_a.named_parameters()),
                                     list(sdf_b.named_parameters()) + list(rad_b.named_parameters())):
@@ -159,6 +165,111 @@ def _stage_worker(rank, world, port, out_dir, backend, async_gather):
 def test_two_ranks_sharded_stage_matches_single_process_trajectory(async_gather, tmp_path):
     mp.spawn(_stage_worker, args=(2, _free_port(), str(tmp_path), "gloo", async_gather), nprocs=2, join=True)
     assert (tmp_path / "stage_ok0").exists() and (tmp_path / "stage_ok1").exists()
+
+
+@pytest.mark.parametrize("async_gather", [False, True])
+def test_two_ranks_pipelined_sharded_stage_matches_single_process_trajectory(async_gather, tmp_path):
+    """ShardedAdam(n_groups = 2) under RenderStage: a traced-depth node rides in the render's backward, so the per-group chain
+    (reduce-scatter -> Adam on the slice -> all-gather, small tensors replicated) is issued at step(); same 8-step trajectory"""
+    mp.spawn(_stage_worker, args=(2, _free_port(), str(tmp_path), "gloo", async_gather, 2), nprocs=2, join=True)
+    assert (tmp_path / "stage_ok0").exists() and (tmp_path / "stage_ok1").exists()
+
+
+def _pipelined_worker(rank, world, port, out_dir, backend, n_groups):
+    """the benchmark's step -- fused render with the loss head inside, backward, update -- with the exchange issued from INSIDE the
+    backward, level group by level group (ShardedAdam's hook on the table Parameter): 6 steps against the single-process run
+    over all rays with FusedAdam"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "level-s2fm_official_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      LS2FM_DIST_SINGLE="1" if world == 1 else "0")
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    from ls2fm import dist as ldist
+    from ls2fm.losses import RenderLossHead
+    from ls2fm.optim import FusedAdam
+    from ls2fm.options import make_options
+    from test_hip_fused_render import _randomized, _rays
+    n_rays, steps = 128, 6
+    opt = make_options("BlendedMVS", device=dev, dual_field=True, sample_intvs=32,
+                       hash_encoding=dict(n_levels=8, n_features_per_level=2, log2_hashmap_size=14, base_resolution=16))
+    data = []
+    for it in range(steps):
+        c, r = _rays(n_rays, 2.0, 500 + it)
+        gt = torch.rand(1, n_rays, 3, generator=torch.Generator().manual_seed(600 + it)).to(dev)
+        data.append((c, r, gt))
+    head = RenderLossHead(dev, 3.0, 2.0, None, global_counts="allreduce")
+
+    def one(sdf, rad, ren, params, c, r, gt):
+        for p in params:
+            p.grad = None
+        ret, loss = ren.forward_with_loss(opt, c, r, sdf, rad, head, gt)
+        loss["all"].backward()
+        return float(loss["all"])
+
+    sdf_a, rad_a, ren = _randomized(opt, 77)
+    pa = list(sdf_a.parameters()) + list(rad_a.parameters())
+    ref_opt = FusedAdam([dict(params=list(sdf_a.parameters()), lr=2e-3), dict(params=list(rad_a.parameters()), lr=1e-3)], eps=1e-15,
+                        scheduled_gamma=0.9)
+    ref_losses = []
+    for c, r, gt in data:
+        ref_losses.append(one(sdf_a, rad_a, ren, pa, c, r, gt))
+        ref_opt.step()
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        sdf_b, rad_b, _ = _randomized(opt, 77)
+        so = ldist.ShardedAdam.for_fields(sdf_b, rad_b, lr=2e-3, lr_color=1e-3, eps=1e-15, scheduled_gamma=0.9, n_groups=n_groups,
+                                          async_gather=True)
+        assert so.n_groups == n_groups and so._pipe is not None
+        pb = list(so.params)
+        losses = []
+        sl = slice(rank * n_rays // world, (rank + 1) * n_rays // world)
+        for c, r, gt in data:
+            so.wait_params()
+            losses.append(one(sdf_b, rad_b, ren, pb, c[:, sl].contiguous(), r[:, sl].contiguous(), gt[:, sl].contiguous()))
+            assert so._pipe["launched"], "the fused backward did not hand its level groups to the optimizer"
+            so.step()
+        so.wait_params()
+        torch.cuda.synchronize()
+        from conftest import rel_err
+        for (k, p_a), (_, p_b) in zip(list(sdf_a.named_parameters()) + list(rad_a.named_parameters()),
+                                      list(sdf_b.named_parameters()) + list(rad_b.named_parameters())):
+            tol = 5e-2 if not k.endswith("embedder_obj.params") else 2e-1
+            assert rel_err(p_b, p_a) < tol, (k, rel_err(p_b, p_a))
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) <= 3e-3 * abs(b), (losses, ref_losses)
+        # a second gradient producer in such a step is refused (the exchanged buffer is no longer what autograd holds)
+        so.wait_params()
+        c, r, gt = data[0]
+        one(sdf_b, rad_b, ren, pb, c[:, sl].contiguous(), r[:, sl].contiguous(), gt[:, sl].contiguous())
+        pb[0].grad = pb[0].grad + 1.0
+        try:
+            so.step()
+            refused = False
+        except RuntimeError as e:
+            refused = "only gradient producer" in str(e)
+        so.wait_params()
+        assert refused
+        with open(os.path.join(out_dir, f"pipe_ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_groups", [2, 3])
+def test_two_ranks_pipelined_exchange_from_inside_the_backward(n_groups, tmp_path):
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), str(tmp_path), "gloo", n_groups), nprocs=2, join=True)
+    assert (tmp_path / "pipe_ok0").exists() and (tmp_path / "pipe_ok1").exists()
+
+
+def test_one_rank_rccl_pipelined_exchange(tmp_path):
+    """the pipelined form against a real RCCL communicator (world size 1): reduce_scatter_tensor / all_gather_into_tensor per
+    level group on the communication stream, events recorded inside ls2fm_render_bwd, Adam on the communication stream"""
+    mp.spawn(_pipelined_worker, args=(1, _free_port(), str(tmp_path), "nccl", 2), nprocs=1, join=True)
+    assert (tmp_path / "pipe_ok0").exists()
 
 
 def test_one_rank_rccl_sharded_stage(tmp_path):

@@ -103,6 +103,62 @@ def test_captured_refine_loop_reproduces_the_eager_one_bit_for_bit():
         assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[1][k], runs[2][k]), k
 
 
+def _synthetic_views(extent, H, W, n_kp, seed):
+    """two cameras on the -z side of a [-extent, extent]^3 scene looking at its centre, smooth images inside (0.05, 0.95) (every
+    ray is in mask_bg), random key points that observe random scene points"""
+    import math
+    gen = torch.Generator().manual_seed(seed)
+    poses = []
+    for ang in (-0.12, 0.15):
+        c, s_ = math.cos(ang), math.sin(ang)
+        R = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]])
+        center = torch.tensor([2.5 * extent * math.sin(ang), 0.05 * extent, -2.5 * extent * math.cos(ang)])
+        poses.append(torch.cat([R, (-R @ center).view(3, 1)], dim=1))          # world-to-camera [R | t]
+    focal = 1.6 * W
+    intr = torch.tensor([[focal, 0.0, W / 2.0], [0.0, focal, H / 2.0], [0.0, 0.0, 1.0]])
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    imgs = torch.stack([torch.stack([0.5 + 0.4 * torch.sin(3 * xx + v), 0.5 + 0.4 * torch.cos(2 * yy - v), 0.3 + 0.4 * xx * yy], dim=-1)
+                        for v in range(2)]).reshape(2, H * W, 3).clamp(0.06, 0.94)
+    kp = [torch.stack([torch.rand(n_kp, generator=gen) * (W - 1), torch.rand(n_kp, generator=gen) * (H - 1)], dim=-1) for _ in range(2)]
+    ids = [torch.arange(n_kp) for _ in range(2)]
+    xyzs = (torch.rand(n_kp, 3, generator=gen) - 0.5) * extent
+    return stage.TrackedViews(torch.stack(poses).to(DEV), intr.to(DEV), imgs.to(DEV), [k.to(DEV) for k in kp], [t.to(DEV) for t in ids],
+                              xyzs.to(DEV), H, W)
+
+
+def test_full_size_refine_loop_captured_equals_eager():
+    """The shipped grid size (L16 / F2 / T19, options/LevelS2fM.yaml:66-90) at the pipeline's 8192 rays over 2 views (:134), 128
+    samples: five iterations of `RefineLoop` -- ray pick, key-point tracing consistency, render + tracing + losses, backward, Adam
+    + schedule -- captured as one hipGraph reproduce the eager loop BIT FOR BIT (the goldens above use reduced grids; since the
+    point-split coarse levels of the table scatter are combined in fixed point by a ticket instead of float atomics, the product
+    repeats itself at this size too), stay finite and lower the loss."""
+    from test_hip_fused_render import _randomized
+    from ls2fm.options import make_options
+    runs = []
+    for capture in (False, True):
+        opt = make_options("DTU", device=DEV, dual_field=True, sample_intvs=128)
+        opt.Res = 100
+        sdf, rad, ren = _randomized(opt, 5)
+        assert sdf.embed_fn.embedder_obj.desc.n_levels == 16 and max(sdf.embed_fn.embedder_obj.desc.size[:16]) == 1 << 19
+        views = _synthetic_views(1.0, 96, 128, 256, seed=9)
+        w = dict(rgb=3, eikonal_loss=1, DC_Loss=0, tracing_loss=1, sdf_surf=1)
+        loop = stage.RefineLoop(opt, ren, sdf, rad, views, weights=w, lr_sdf=1e-3, lr_sdf_end=5e-4, lr_color=1e-3, max_iter=5,
+                                rand_rays=8192, capture=capture)
+        gen = torch.Generator().manual_seed(17)
+        picks = [(torch.randperm(96 * 128, generator=gen)[:4096].to(DEV), it % 2) for it in range(5)]
+        logs = {k: v.cpu() for k, v in loop.run(picks=picks).items()}
+        assert (loop.stage._graph is not None) == capture
+        runs.append((logs, [p.detach().clone() for p in loop.stage.params]))
+    (eager, p_e), (captured, p_c) = runs
+    for k in eager:
+        assert bool(torch.isfinite(eager[k]).all()), k
+        assert torch.equal(eager[k], captured[k]), (k, eager[k], captured[k])
+    for a, b in zip(p_e, p_c):
+        assert torch.equal(a, b)
+    assert float(eager["all"][-1]) < float(eager["all"][0])
+    print(f"[full-size refine loop] loss {float(eager['all'][0]):.4f} -> {float(eager['all'][-1]):.4f}, PSNR {float(eager['PSNR'][-1]):.3f}")
+
+
 @pytest.mark.parametrize("capture", [False, True])
 def test_ba_loop_vs_reference_loop(capture):
     g = load_golden("stage_ba_dtu_dual")
@@ -269,7 +325,8 @@ def test_captured_geoinit_loop_vs_reference_loop():
         _close(f"{k} (captured vs eager)", logs[k][:3], eager[k][:3], 3e-4)
         assert np.isfinite(logs[k]).all()
         assert np.abs(logs[k] / ref - 1).max() <= bar, k
-    assert int(loop.optim.state[loop.params[0]]["step"]) == loop.n_iters
+    stepped = [int(st["step"]) for st in loop.optim.state.values() if st]
+    assert stepped and all(n == loop.n_iters for n in stepped)
     assert len(loop.triangulate()) == 2
 
 
