@@ -311,9 +311,12 @@ class ShardedAdam:
     nodes) are packed first.  One process group = one replica set; world 1 degenerates to a plain fused Adam."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, scheduled_gamma=None, group_lrs=None,
-                 async_gather=False, update=None, n_groups=1, tables=(), level_offsets=None):
+                 async_gather=False, update=None, n_groups=1, tables=(), level_offsets=None, in_backward=True):
         """n_groups >= 2 (with `tables`: the hash-table Parameters among `params`, and `level_offsets`: first ENTRY of every level
-        + the total, as the grid descriptor holds them): the PIPELINED exchange, see `_build_pipeline`."""
+        + the total, as the grid descriptor holds them): the PIPELINED exchange, see `_build_pipeline`.  in_backward: the fused
+        render's backward issues each group's chain itself, beside the scatter of the later groups -- only for steps whose ONLY
+        gradient producer is that render (the benchmark's step); False: the same per-group chain, issued at step() (steps with a
+        traced-depth or point-query node, whose gradients autograd sums afterwards: ls2fm.stage)."""
         from . import fused as _fused
         self.params = [p for p in params]
         if not self.params:
@@ -365,6 +368,7 @@ class ShardedAdam:
         self._gather = None
         self._fused = _fused
         self.n_groups = int(n_groups) if (tables and level_offsets is not None and int(n_groups) >= 2) else 1
+        self.in_backward = bool(in_backward)
         self._pipe = None
         if self.n_groups >= 2:
             hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, scheduled_gamma=scheduled_gamma)
@@ -454,8 +458,9 @@ class ShardedAdam:
                           inner_loose=make_inner([dict(params=v, lr=k) for k, v in by_lr.items()]) if by_lr else None,
                           level_offsets=level_offsets, n_levels=n_levels, done=None, inflight=None, launched=False)
         # the hook the fused backward calls instead of issuing all-reduces (ls2fm.fused): groups, then this optimizer
-        tables[0]._ls2fm_overlap_groups = G
-        tables[0]._ls2fm_group_exchange = self._exchange_from_backward
+        if self.in_backward:
+            tables[0]._ls2fm_overlap_groups = G
+            tables[0]._ls2fm_group_exchange = self._exchange_from_backward
         self._tables = tables
         # the monolithic form's shard-sized state is not used
         self.gshard = None
@@ -513,10 +518,13 @@ class ShardedAdam:
         pp = self._pipe
         if pp["launched"]:                                     # the backward already issued this step's exchange + update
             pp["launched"] = False
-            # (sole-producer rule, as for enable_table_overlap: the buffer that was exchanged must be what autograd holds)
+            # (sole-producer rule, as for enable_table_overlap: the buffer that was exchanged must be what autograd holds --
+            # every .grad still a view of it at this optimizer's offsets)
             flat_now = getattr(self.params[0], "_ls2fm_grad_flat", None)
-            if flat_now is not pp["inflight"] or any(p.grad is None or getattr(p, "_ls2fm_grad_flat", None) is not flat_now
-                                                     for p in self.params):
+            base = None if flat_now is None else flat_now.data_ptr()
+            if flat_now is not pp["inflight"] or any(
+                    p.grad is None or getattr(p, "_ls2fm_grad_flat", None) is not flat_now or p.grad.data_ptr() != base + 4 * o
+                    for p, o in zip(self.params, self.offsets)):
                 raise RuntimeError("ls2fm.dist.ShardedAdam(n_groups >= 2): the fused render must be the only gradient producer of a "
                                    "step whose exchange is issued from inside its backward; this step accumulated gradients from "
                                    "another node.  Use n_groups=1 for such steps")

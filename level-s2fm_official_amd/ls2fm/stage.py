@@ -177,7 +177,8 @@ class RenderStage:
                 raise NotImplementedError("ls2fm.stage.RenderStage(sharded=True): the two field groups only, eager steps only")
             from .dist import ShardedAdam
             self.optim = ShardedAdam.for_fields(sdf_field, rad_field, lr=lr, lr_color=lr_color, betas=betas, eps=eps,
-                                                scheduled_gamma=self.gamma, async_gather=async_gather, n_groups=shard_groups)
+                                                scheduled_gamma=self.gamma, async_gather=async_gather, n_groups=shard_groups,
+                                                in_backward=False)       # (a traced-depth node rides in every step)
             self.params = list(self.optim.params)
         else:
             self.optim = FusedAdam(groups, lr=lr, betas=betas, eps=eps, scheduled_gamma=self.gamma)

@@ -163,7 +163,7 @@ def _pipelined_worker(rank, world, port, out_dir):
             assert opt.n_groups == n_groups and opt._pipe is not None
             sharded = sum(pc["n"] for grp in opt._pipe["pieces"] for pc in grp)
             assert sharded >= 2 * 400 - 2 * n_groups * 4 * world            # all of both tables but the slices' remainders
-            assert getattr(params[0], "_ls2fm_overlap_groups") == n_groups
+            assert getattr(params[0], "_ls2fm_overlap_groups") == n_groups and opt.in_backward
             for it in range(4):
                 per_rank = [[torch.randn(sh, generator=g) for sh in shapes] for _ in range(world)]
                 if it % 2 == 0:

@@ -211,6 +211,40 @@ def test_fused_equals_composed_any_sample_count(n_samples):
         assert rel_err(g_f[k], g_c[k]) < GTOL, k
 
 
+@pytest.mark.parametrize("dual", [True, False])
+def test_backward_repeats_itself_bit_for_bit_at_baseline_size(dual):
+    """1024 rays x 128 samples on the full grids: the coarse levels' slabs are split over several workgroups there.  Default
+    scatter mode (ls2fm_set_scatter_mode(1)): their 64-bit fixed-point partials are combined by slab_combine_kernel -- integer
+    sums, so two backward passes over the same inputs give IDENTICAL gradients, every table entry being the exactly rounded sum
+    of its contributions; mode 0 (float atomics into a zeroed range, rounds 1-3) agrees to summation round-off."""
+    from ls2fm import _lib
+    lib = _lib.load()
+    opt = make_options("ETH3D", device=DEV, dual_field=dual, sample_intvs=128)
+    sdf, rad, ren = _randomized(opt, 31)
+    center, ray = _rays(1024, 5.0, 32)
+    tgt, nm = torch.rand(1, 1024, 3, device=DEV), torch.tensor([0.3, -0.2, 0.6], device=DEV)
+
+    def grads():
+        sdf.zero_grad(set_to_none=True); rad.zero_grad(set_to_none=True)
+        losses.render_loss(ren.forward(opt, center, ray, sdf, rad), tgt, nm).backward()
+        torch.cuda.synchronize()
+        return {**{"s." + k: v.clone() for k, v in named_grads(sdf).items()}, **{"r." + k: v.clone() for k, v in named_grads(rad).items()}}
+
+    assert lib.ls2fm_get_scatter_mode() == 1
+    a, b = grads(), grads()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    try:
+        _lib.check(lib.ls2fm_set_scatter_mode(0), "ls2fm_set_scatter_mode")
+        c = grads()
+    finally:
+        _lib.check(lib.ls2fm_set_scatter_mode(1), "ls2fm_set_scatter_mode")
+    for k in a:
+        assert rel_err(c[k], a[k]) < 1e-6, k
+    tab = a["s.embed_fn.embedder_obj.params"]
+    assert int((tab != 0).sum()) > 1000
+
+
 def test_fused_properties_at_baseline_size():
     """1024 rays x 128 samples, dual field, full-size tables (BASELINE.json config 2 shape): size-independent
     properties -- missed rays render the background exactly, opacity in [0,1], depth within [near, far],
