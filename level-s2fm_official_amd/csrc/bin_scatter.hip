@@ -284,6 +284,9 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         for (int e = tid; e < kAccSlots / 2; e += kAccThreads) reinterpret_cast<uint4*>(acc)[e] = z;
     }
+#ifdef LS2FM_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[8 * blockIdx.x + 7] = wall_clock64();
+#endif
     // bound of a single contribution on this level (reduced over the rays by scatter_fill); second grid: rows 16..31
     float to_fixed1, to_fixed2;
     double to_float1, to_float2;

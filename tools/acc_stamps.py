@@ -31,7 +31,8 @@ print("workgroups", len(a), "kernel span us", (a[:, 3].max() - t0) / 100.0)
 ph = ["start->zeroed+meta", "stream", "flush"]
 for lvl in sorted(set(a[:, 4])):
     m = a[a[:, 4] == lvl]
-    print(f"level {lvl:2d}: wgs {len(m):4d} items/wg {m[:,5].mean():8.0f}  " +
+    extra = f" [count/start known {((m[:,6]-m[:,0]).mean())/100.0:5.2f}, LDS zeroed {((m[:,7]-m[:,0]).mean())/100.0:5.2f}]" if (m[:, 6] > 0).all() else ""
+    print(f"level {lvl:2d}: wgs {len(m):4d} items/wg {m[:,5].mean():8.0f}  " + extra +
           "  ".join(f"{ph[q]} {((m[:, q + 1] - m[:, q]).mean()) / 100.0:6.2f}" for q in range(3)) +
           f"  total {((m[:, 3] - m[:, 0]).mean()) / 100.0:6.2f} us   starts {((m[:,0].min()-t0)/100.0):6.1f}..{((m[:,0].max()-t0)/100.0):6.1f}")
 tot = (a[:, 3] - a[:, 0]).sum() / 100.0
