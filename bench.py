@@ -311,9 +311,14 @@ def main():
 
     mode = "graph" if args.graph else args.launch
     if multi and mode != "graph":
-        mode = "eager"                  # collectives are issued from inside the backward: keep them out of graph captures
-    if shard or local_opt is not None:
-        mode = "eager"                  # the step rewrites the parameters (collectives / an update the N > 1 lines launch eagerly too)
+        mode = "eager"                  # N > 1 default: eager.  `--launch graph` captures the WHOLE sharded step -- render, the
+                                        # RCCL collectives on the communication stream, the sharded update -- into one hipGraph
+                                        # (measured with a one-rank RCCL group: 0.79 -> 0.74 ms/step; opt-in until it has run
+                                        # on a real multi-GPU node)
+    if local_opt is not None:
+        mode = "eager"                  # the like-for-like N = 1 point of the eager N > 1 lines
+    if reducer is not None and mode == "graph":
+        mode = "eager"                  # the all-reduce form issues async collectives with host-side waits: not captured
     # every step -- eager or captured -- runs on ONE non-default stream: autograd's gradient accumulators stay tied to
     # the stream of their first backward, and mixing streams costs synchronisations (and breaks captures)
     s_main = torch.cuda.Stream(device=dev)
@@ -321,21 +326,25 @@ def main():
     captured = None
     use_graph = False
 
+    def whole_step():
+        """what a graph captures: the render step and, under the sharded exchange, the exchange + update behind it"""
+        render_step()
+        if sharded_opt is not None:
+            sharded_opt.step()
+
     def step(eager=False):
         if use_graph and not eager:
             captured.replay()
         else:
-            render_step()
+            whole_step()
         if reducer is not None:
             reducer.all_reduce()
-        if sharded_opt is not None:
-            sharded_opt.step()
         if local_opt is not None:
             local_opt.step()
 
     launch_probe = None
     if mode == "graph":
-        captured = CapturedStep(render_step, params, stream=s_main)
+        captured = CapturedStep(whole_step, params, stream=s_main)
         use_graph = True
     if mode == "auto":                      # untimed probe (part of the warm-up): pick the faster launch mode on this host
         def probe(graph, n=40):
@@ -350,7 +359,7 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
         t_eager = probe(False)
-        captured = CapturedStep(render_step, params, stream=s_main)
+        captured = CapturedStep(whole_step, params, stream=s_main)
         t_graph = probe(True)
         use_graph = t_graph < 0.98 * t_eager
         launch_probe = {"eager_ms_per_step": t_eager * 1e3, "graph_ms_per_step": t_graph * 1e3}
@@ -405,7 +414,7 @@ def main():
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                captured.replay() if use_graph else render_step()
+                render_step()
             barrier()
             t_compute = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
             dist.all_reduce(t_compute, op=dist.ReduceOp.MAX)

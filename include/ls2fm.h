@@ -477,6 +477,27 @@ int ls2fm_adam_step_multi(int32_t n_tensors, float* const* params, const float* 
 int ls2fm_adam_sched_decay(int32_t n, void* const* sched_states, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Camera rays: the pixels' camera centers and (unnormalised) ray directions through n_views pinhole cameras, one launch --
+ * Camera.get_pts3D's ray construction and CameraSet.render's ray pick (pipelines/Camera.py:129-133, 457-463 on
+ * utils/camera.py:230-252: get_center_and_ray = img2cam + cam2world) with, optionally, the se(3) -> SE(3) exponential map of
+ * the live pose parameters in front (utils/camera.py:63-147: 11-term Taylor series, as BA.py:150-151 evaluates it every
+ * iteration).  No gradients (the reference detaches the render poses, BA.py:150-151); same operation order as the torch code.
+ *   poses [n_views,3,4] world-to-camera (device)  XOR  se3 [n_views,6] (w, u) (device);   kinv_host: the 3 x 3 K^-1 as 9 HOST floats
+ *   pixels: xy [n,2] (or [n_views,n,2] with xy_per_view) device float coordinates  XOR  pix [n] int64 pixel indices of a
+ *   width-`width` image (centres x + 0.5, y + 0.5: the same pixels in every view)
+ *   view_sel: NULL, or a DEVICE int64[1]: only that view is processed (outputs have ONE view) -- a captured step follows the value
+ *   centers, rays [n_views or 1, n, 3] (overwritten); poses_out [n_views or 1,3,4] or NULL: the poses used (se3 given: the exponentials)
+ */
+/* The exponential map alone, with its gradient: poses [n,3,4] = exp(se3 [n,6]) and d_se3 [n,6] from d_poses [n,3,4] (the chain
+ * rule through the truncated series, term by term, as autograd differentiates utils/camera.py:63-147) -- the live poses of a
+ * bundle-adjustment iteration that the re-projection term reads (BA.py:126-147), one launch each way instead of ~90. */
+int ls2fm_se3_exp_fwd(const float* se3, int32_t n, float* poses, void* stream);
+int ls2fm_se3_exp_bwd(const float* se3, const float* d_poses, int32_t n, float* d_se3, void* stream);
+int ls2fm_camera_rays(const float* poses, const float* se3, const float* kinv_host, const float* xy, const int64_t* pix,
+                      int32_t width, int32_t xy_per_view, const int64_t* view_sel, int32_t n_views, int64_t n, float* centers,
+                      float* rays, float* poses_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * How the table-gradient scatter (inside ls2fm_render_bwd / ls2fm_sdf_points_bwd) finishes the few coarse levels whose slabs
  * are split over several workgroups.  Process-wide; takes effect for the calls enqueued afterwards.
  *   1 (default; env LS2FM_SCATTER_MODE)  every part's 64-bit fixed-point partial sums are combined by one more small launch:

@@ -145,6 +145,9 @@ _SIGNATURES = {
     "ls2fm_adam_step_mirrored": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "ls2fm_adam_step_multi": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int64, _P]),
     "ls2fm_adam_sched_decay": (c_int32, [c_int32, _P, _P]),
+    "ls2fm_camera_rays": (c_int32, [_P, _P, POINTER(c_float), _P, _P, c_int32, c_int32, _P, c_int32, c_int64, _P, _P, _P, _P]),
+    "ls2fm_se3_exp_fwd": (c_int32, [_P, c_int32, _P, _P]),
+    "ls2fm_se3_exp_bwd": (c_int32, [_P, _P, c_int32, _P, _P]),
     "ls2fm_set_scatter_mode": (c_int32, [c_int32]),
     "ls2fm_get_scatter_mode": (c_int32, []),
     "ls2fm_profile_enable": (c_int32, [c_int32]),

@@ -465,30 +465,49 @@ class ShardedAdam:
         # the monolithic form's shard-sized state is not used
         self.gshard = None
 
+    @staticmethod
+    def _together(calls):
+        """issue several collectives as ONE backend launch where the backend groups them (RCCL: ncclGroupStart / End through
+        torch's coalescing manager -- a group's two table slices are two buffers, and a collective launch costs tens of
+        microseconds of host time each); one by one elsewhere (gloo)"""
+        if len(calls) > 1 and dist.get_backend() == "nccl" and _COALESCED.get("mgr") is not False:
+            try:
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(async_ops=False):
+                    for fn in calls:
+                        fn()
+                _COALESCED["mgr"] = True
+                return
+            except (RuntimeError, NotImplementedError, AttributeError, TypeError, ImportError):
+                if _COALESCED.get("mgr"):
+                    raise
+                _COALESCED["mgr"] = False
+        for fn in calls:
+            fn()
+
     def _exchange_group(self, g, flat_g, last):
         """enqueue (on the CURRENT stream: the communication stream) group g's reduce-scatter -> Adam -> all-gather"""
         pp = self._pipe
         coll = self._collective
-        for pc in pp["pieces"][g]:
-            inp = flat_g[pc["at"]:pc["at"] + pc["n"]]
-            if coll:
-                dist.reduce_scatter_tensor(pc["gshard"], inp)
-            else:
-                pc["gshard"].copy_(inp)
+        if coll:
+            self._together([(lambda pc=pc: dist.reduce_scatter_tensor(pc["gshard"], flat_g[pc["at"]:pc["at"] + pc["n"]]))
+                            for pc in pp["pieces"][g]])
+        else:
+            for pc in pp["pieces"][g]:
+                pc["gshard"].copy_(flat_g[pc["at"]:pc["at"] + pc["n"]])
         if last and pp["loose"]:
-            views = [flat_g[a:b] for a, b, _ in pp["loose"]]
-            if coll:
-                for h in _all_reduce_together(views):
+            if coll:                                            # the replicated spans as they lie in the buffer: 2 .. 4 messages
+                for h in _all_reduce_together([flat_g[a:b] for a, b in pp["loose_spans"]]):
                     h.wait()
-            for (a, b, q), v in zip(pp["loose"], views):
-                q.grad = v
+            for a, b, q in pp["loose"]:
+                q.grad = flat_g[a:b]
         if pp["inner"][g] is not None:
             pp["inner"][g].step()
         if last and pp["inner_loose"] is not None:
             pp["inner_loose"].step()
         if coll:
-            for pc in pp["pieces"][g]:
-                dist.all_gather_into_tensor(self.flat[pc["at"]:pc["at"] + pc["n"]], pc["param"].data)
+            self._together([(lambda pc=pc: dist.all_gather_into_tensor(self.flat[pc["at"]:pc["at"] + pc["n"]], pc["param"].data))
+                            for pc in pp["pieces"][g]])
 
     def _exchange_from_backward(self, flat_g, tables, level_offsets, events, n_levels):
         """the fused backward's hook: its kernels are enqueued, events[g] is recorded behind group g's scatter"""
@@ -544,7 +563,9 @@ class ShardedAdam:
             else:
                 for g in range(self.n_groups):
                     self._exchange_group(g, flat_g, g == self.n_groups - 1)
-        if not self.async_gather:
+        # (inside a hipGraph capture every branch must be joined before the capture ends: the communication stream's chain is
+        # then part of the step's graph, and a replay starts behind the previous one anyway)
+        if not self.async_gather or (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
             self.wait_params()
         for p in self.params:
             torch.autograd.graph.increment_version(p)

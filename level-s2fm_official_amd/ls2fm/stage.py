@@ -366,6 +366,8 @@ class TrackedViews:
         self.kp_pad = torch.stack([torch.cat([k, k[:1].expand(n_max - k.shape[0], 2)]) for k in self.keypoints]).to(dev)
         self.id_pad = torch.stack([torch.cat([t, t[:1].expand(n_max - t.shape[0])]) for t in self.track_ids]).to(dev)
         self.kp_live = torch.stack([torch.arange(n_max, device=dev) < k.shape[0] for k in self.keypoints]).float()
+        # K^-1 on the host for the fused ray construction (ls2fm_camera_rays): read back here, once, outside any captured step
+        self.kinv_host = _cam.host_inverse_intrinsic(intrinsic) if images.is_cuda else None
 
 
 def keypoint_rays(pose, intrinsic, kypts):
@@ -406,9 +408,13 @@ class TracingConsistency:
             pick = lambda t: t.index_select(0, view)[0]
             if fixed is not None:
                 c, r = fixed.kp_center.index_select(0, view), fixed.kp_ray.index_select(0, view)
+                self.center.copy_(c); self.ray.copy_(r)
+            elif self.views.kinv_host is not None and poses.shape[-1] == 4:
+                # one launch: the selected view's pose and key points -> its rays, written into the buffers the tracing reads
+                _cam.camera_rays(self.views.kinv_host, poses=poses, xy=self.views.kp_pad, view_sel=view, out=(self.center, self.ray))
             else:
                 c, r = keypoint_rays(pick(poses), self.views.intrinsic, pick(self.views.kp_pad))
-            self.center.copy_(c); self.ray.copy_(r)
+                self.center.copy_(c); self.ray.copy_(r)
             self.target.copy_(self.views.xyzs[pick(self.views.id_pad)])
             self.live.copy_(pick(self.views.kp_live))
             return
@@ -431,9 +437,18 @@ class TracingConsistency:
         return loss
 
 
-def _pick_rays(views, poses, rays_idx):
-    """CameraSet.render's ray pick for given poses (Camera.py:457-463): the same pixels in every view"""
-    centers, rays = _cam.get_center_and_ray(None, poses, intr=views.intrinsic.unsqueeze(0), rays_idx=rays_idx, xy_grid=views.grid)
+def _pick_rays(views, poses, rays_idx, se3=None, poses_out=None):
+    """CameraSet.render's ray pick for given poses (Camera.py:457-463): the same pixels in every view.  se3 [V,6]: the poses are
+    the exponentials of these parameters, formed in the same launch (and left in poses_out)"""
+    if views.kinv_host is not None and not (poses if se3 is None else se3).requires_grad:
+        centers, rays = _cam.camera_rays(views.kinv_host, poses=None if se3 is not None else poses, se3=se3, pix=rays_idx, width=views.W,
+                                         poses_out=poses_out)
+    else:
+        if se3 is not None:
+            poses = _cam.lie.se3_to_SE3(se3)
+            if poses_out is not None:
+                poses_out.copy_(poses)
+        centers, rays = _cam.get_center_and_ray(None, poses, intr=views.intrinsic.unsqueeze(0), rays_idx=rays_idx, xy_grid=views.grid)
     return centers, rays, views.images[:, rays_idx, :]
 
 
@@ -835,10 +850,9 @@ class BALoop:
         self._camera_poses = _cam.lie.se3_to_SE3(se3).detach()
 
     def _inputs(self):
-        with torch.no_grad():
-            self._render_poses.copy_(_cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1)))      # detached (BA.py:150-151)
         self.tracing.select(self._view, self._camera_poses)
-        return _pick_rays(self.views, self._render_poses, self._idx)
+        with torch.no_grad():            # the render poses are detached (BA.py:150-151): exponential + ray pick in one launch
+            return _pick_rays(self.views, None, self._idx, se3=torch.cat([self.rot, self.trans], dim=1), poses_out=self._render_poses)
 
     def _prepare(self):
         """ahead of the render, as in BA.run_ba (BA.py:117-131 come before its render call): the tracing consistency's key-point
@@ -856,7 +870,7 @@ class BALoop:
         else:
             xyzs_new, _ = self.sdf.get_surface_pts(self.xyzs_all[self.obs_point])
             sdfs = self.sdf.infer_sdf(xyzs_new, mode="ret_sdf").view(-1, 1)
-        poses = _cam.lie.se3_to_SE3(torch.cat([self.rot, self.trans], dim=1))                    # [V,3,4]: the live poses
+        poses = _cam.se3_to_SE3_fused(torch.cat([self.rot, self.trans], dim=1))                  # [V,3,4]: the live poses
         if xyzs_new.is_cuda:
             # one fused node each way for the per-observation block (projection, pixel error, on-surface / finite mask, robust mean)
             reproj, _ = reprojection_term(xyzs_new, poses, self.view_start, self._k_host, self.obs_uv, sdfs, 2 * self.sdf_threshold)

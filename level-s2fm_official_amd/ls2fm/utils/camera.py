@@ -99,6 +99,42 @@ def get_center_and_ray(opt, pose, intr=None, rays_idx=None, xy_grid=None):
     return center, cam2world(in_cam, pose) - center
 
 
+def host_inverse_intrinsic(cam_intr):
+    """K^-1 (as `img2cam` uses it: computed on the matrix's own device) as 9 host floats for `camera_rays` -- call it where a host
+    read-back is allowed (a loop's constructor), not inside a captured step"""
+    import ctypes
+    k = _inverse_intrinsic(cam_intr.reshape(3, 3))
+    return (ctypes.c_float * 9)(*[float(v) for v in k.detach().reshape(-1).cpu().tolist()])
+
+
+def camera_rays(kinv_host, poses=None, se3=None, xy=None, pix=None, width=0, view_sel=None, out=None, poses_out=None):
+    """`get_center_and_ray` / `keypoint_rays` (and, with `se3` [V,6], `Lie.se3_to_SE3` in front) as ONE launch, without a graph
+    (ls2fm_camera_rays): the pose algebra of a loop iteration's ray pick was ~95 launch-bound torch kernels.
+    poses [V,3,4] or se3 [V,6]; pixels: xy [n,2] / [V,n,2] float coordinates or pix [n] long indices of a width-`width` image;
+    view_sel: device long [1] -> only that view (outputs [1,n,3]).  out: (centers, rays) buffers to fill in place.
+    -> (centers, rays) [V or 1, n, 3]"""
+    from .. import _lib
+    lib = _lib.load()
+    src = poses if poses is not None else se3
+    _lib.require_device(src)
+    n_views = src.shape[0]
+    per_view = xy is not None and xy.dim() == 3
+    n = (pix.shape[0] if pix is not None else xy.shape[-2])
+    v_out = 1 if view_sel is not None else n_views
+    if out is None:
+        out = (torch.empty(v_out, n, 3, device=src.device), torch.empty(v_out, n, 3, device=src.device))
+    centers, rays = out
+    if centers.numel() != v_out * n * 3 or rays.numel() != v_out * n * 3 or not (centers.is_contiguous() and rays.is_contiguous()):
+        raise RuntimeError("ls2fm.utils.camera.camera_rays: out buffers must be contiguous [views, n, 3]")
+    f = lambda t: None if t is None else (t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous())
+    poses_c, se3_c, xy_c = f(None if poses is None else poses.detach()), f(None if se3 is None else se3.detach()), f(xy)
+    pix_c = None if pix is None else (pix if (pix.dtype == torch.int64 and pix.is_contiguous()) else pix.long().contiguous())
+    _lib.check(lib.ls2fm_camera_rays(_lib.ptr(poses_c), _lib.ptr(se3_c), kinv_host, _lib.ptr(xy_c), _lib.ptr(pix_c), int(width),
+                                     1 if per_view else 0, _lib.ptr(view_sel), n_views, n, _lib.ptr(centers), _lib.ptr(rays),
+                                     _lib.ptr(poses_out), _lib.stream_ptr()), "ls2fm_camera_rays")
+    return centers, rays
+
+
 # ------------------------------------------------------------------------------------------------ se(3)
 _N_TERMS = 11
 _SERIES = {}
@@ -185,6 +221,38 @@ class Lie:
         A, B, _ = _abc(theta)
         inv_v = torch.eye(3, device=w.device, dtype=w.dtype) - 0.5 * W + (1 - A / (2 * B)) / (theta ** 2 + eps) * (W @ W)
         return torch.cat([w, (inv_v @ t)[..., 0]], dim=-1)
+
+
+class _Se3Exp(torch.autograd.Function):
+    """ls2fm_se3_exp_fwd / _bwd: `Lie.se3_to_SE3` with its gradient as one launch each way (GPU tensors)"""
+
+    @staticmethod
+    def forward(ctx, wu):
+        from .. import _lib
+        lib = _lib.load()
+        x = wu.detach().float().contiguous()
+        _lib.require_device(x)
+        n = x.numel() // 6
+        out = torch.empty(*x.shape[:-1], 3, 4, device=x.device)
+        _lib.check(lib.ls2fm_se3_exp_fwd(_lib.ptr(x), n, _lib.ptr(out), _lib.stream_ptr()), "ls2fm_se3_exp_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import _lib
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        g = g.detach().float().contiguous()
+        d = torch.empty_like(x)
+        _lib.check(lib.ls2fm_se3_exp_bwd(_lib.ptr(x), _lib.ptr(g), x.numel() // 6, _lib.ptr(d), _lib.stream_ptr()), "ls2fm_se3_exp_bwd")
+        return d
+
+
+def se3_to_SE3_fused(wu):
+    """`Lie.se3_to_SE3` through the fused kernels when `wu` lives on the GPU (differentiable once), else the torch expression"""
+    return _Se3Exp.apply(wu) if wu.is_cuda else Lie.se3_to_SE3(wu)
 
 
 lie = Lie()

@@ -1,0 +1,88 @@
+"""ls2fm_camera_rays (one launch) against the torch restatement of the reference's ray construction it replaces in the loops'
+no-gradient preamble: `get_center_and_ray` (utils/camera.py:230-252), `Camera.get_pts3D`'s key-point rays
+(pipelines/Camera.py:129-133) and `Lie.se3_to_SE3` (utils/camera.py:63-147) -- the host mirrors in ls2fm.utils.camera, which
+tests/test_camera_helpers.py holds to the reference's formulas on the CPU."""
+import math
+
+import pytest
+import torch
+
+from ls2fm import stage
+from ls2fm.utils import camera as cam
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(V=3, H=48, W=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    se3 = torch.cat([0.4 * torch.randn(V, 3, generator=g), 2.0 * torch.randn(V, 3, generator=g)], dim=1).to(DEV)
+    se3[0, :3] = 0.0                                            # theta = 0: the series' first terms only
+    intr = torch.tensor([[1.3 * W, 0.0, W / 2.0], [0.0, 1.2 * W, H / 2.0], [0.0, 0.0, 1.0]], device=DEV)
+    return se3, intr, H, W, g
+
+
+def _close(a, b, what):
+    scale = float(b.abs().max())
+    err = float((a - b).abs().max())
+    same = float((a == b).float().mean())
+    print(f"[camera_rays] {what}: max |diff| {err:.2e} of scale {scale:.2e}, bit-identical {100 * same:.1f} %")
+    assert err <= 4e-7 * scale, what                           # a few ulp: the summation order of the 3- and 4-term products
+
+
+def test_camera_rays_match_the_torch_ray_construction():
+    se3, intr, H, W, g = _setup()
+    kinv = cam.host_inverse_intrinsic(intr)
+    poses = cam.lie.se3_to_SE3(se3)
+    idx = torch.randperm(H * W, generator=g)[:500].to(DEV)
+    grid = cam.mesh_grid(H=H, W=W, device=DEV)
+    c_ref, r_ref = cam.get_center_and_ray(None, poses, intr=intr.unsqueeze(0), rays_idx=idx, xy_grid=grid)
+    c, r = cam.camera_rays(kinv, poses=poses, pix=idx, width=W)
+    _close(c, c_ref, "centers (poses, pixel indices)")
+    _close(r, r_ref, "rays (poses, pixel indices)")
+    # the exponential in the same launch
+    out_poses = torch.zeros(se3.shape[0], 3, 4, device=DEV)
+    c2, r2 = cam.camera_rays(kinv, se3=se3, pix=idx, width=W, poses_out=out_poses)
+    _close(out_poses, poses, "se3 -> SE3")
+    _close(c2, c_ref, "centers (se3)")
+    _close(r2, r_ref, "rays (se3)")
+    assert torch.equal(out_poses[0, :, :3], torch.eye(3, device=DEV))        # theta = 0: R = I exactly
+    # key points of ONE view chosen by a device-side index, written into given buffers
+    kp = (torch.rand(se3.shape[0], 37, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])).to(DEV)
+    center, ray = torch.zeros(1, 37, 3, device=DEV), torch.zeros(1, 37, 3, device=DEV)
+    for v in range(se3.shape[0]):
+        sel = torch.tensor([v], device=DEV)
+        cam.camera_rays(kinv, poses=poses, xy=kp, view_sel=sel, out=(center, ray))
+        kc, kr = stage.keypoint_rays(poses[v], intr, kp[v])
+        _close(center, kc, f"key-point centers, view {v}")
+        _close(ray, kr, f"key-point rays, view {v}")
+
+
+def test_fused_se3_exponential_and_its_gradient_match_autograd():
+    se3, _, _, _, g = _setup(V=5, seed=3)
+    se3 = se3.clone()
+    se3[0, :3] = torch.tensor([1e-3, -2e-3, 5e-4])              # small angle: the series' low-order terms carry everything
+    upstream = torch.randn(5, 3, 4, generator=g).to(DEV)
+    a = se3.clone().requires_grad_(True)
+    b = se3.clone().requires_grad_(True)
+    pa, pb = cam.lie.se3_to_SE3(a), cam.se3_to_SE3_fused(b)
+    _close(pb.detach(), pa.detach(), "se3 -> SE3 (autograd node)")
+    (pa * upstream).sum().backward()
+    (pb * upstream).sum().backward()
+    scale = float(a.grad.abs().max())
+    err = float((a.grad - b.grad).abs().max())
+    print(f"[se3 exp] gradient: max |diff| {err:.2e} of scale {scale:.2e}")
+    assert err <= 2e-6 * scale
+    # against the closed forms in float64 (sin / cos): the 11-term series is exact to fp32 for these angles
+    w = se3[:, :3].double().cpu()
+    th = w.norm(dim=-1)[:, None, None]
+    Wm = cam.skew(w)
+    R64 = torch.eye(3, dtype=torch.float64) + torch.sin(th) / th * Wm + (1 - torch.cos(th)) / th ** 2 * (Wm @ Wm)
+    assert float((pb.detach().cpu().double()[:, :, :3] - R64).abs().max()) < 5e-7
+
+
+def test_camera_rays_refuses_cpu_tensors():
+    se3, intr, H, W, g = _setup()
+    kinv = cam.host_inverse_intrinsic(intr)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cam.camera_rays(kinv, poses=cam.lie.se3_to_SE3(se3).cpu(), pix=torch.arange(4), width=W)

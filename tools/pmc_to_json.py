@@ -5,7 +5,7 @@ import json, re, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 commit = sys.argv[2] if len(sys.argv) > 2 else "unknown"
-SHORT = [("ray_encode", "ray_encode_pair"), ("slab_accumulate", "slab_accumulate"), ("scatter_fill", "scatter_fill"),
+SHORT = [("ray_encode", "ray_encode_pair"), ("slab_accumulate", "slab_accumulate"), ("slab_combine", "slab_combine"), ("scatter_fill", "scatter_fill"),
          ("shade_bwd", "shade_bwd"), ("shade_fwd", "shade_fwd"), ("wgrad_mlp_kernelILb0", "wgrad_mlp_sdf"),
          ("wgrad_mlp_kernelILb1", "wgrad_mlp_geo"), ("wgrad_mlp_kernel<false", "wgrad_mlp_sdf"), ("wgrad_mlp_kernel<true", "wgrad_mlp_geo"),
          ("wgrad_dec", "wgrad_dec"), ("wgrad_tail", "reduce_finalize"), ("wgrad_reduce_all", "wgrad_reduce_all"), ("post_shade", "post_shade"), ("finalize", "finalize")]
