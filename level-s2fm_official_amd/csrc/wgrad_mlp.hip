@@ -246,15 +246,15 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
 // (per-ray sums of dz) renc^T.  Every operand already lies in HBM as [row][sample]: the MFMA operands (row jl, 4
 // consecutive samples) are plain 16-byte loads, no LDS.
 
-__device__ __forceinline__ float4 load4_masked(const float* __restrict__ row, int64_t s, int64_t n, bool on) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (on && s < n) {
-        v = *reinterpret_cast<const float4*>(row + s);
-        if (s + 1 >= n) v.y = 0.f;
-        if (s + 2 >= n) v.z = 0.f;
-        if (s + 3 >= n) v.w = 0.f;
-    }
-    return v;
+// four consecutive samples s .. s + 3 of one row: the load is UNCONDITIONAL (the address clamped into the row's padded extent) and
+// the masking is a separate step applied where the values are USED, one iteration later -- a load under a branch, or one whose
+// lanes are patched right behind it, makes the compiler wait for it on the spot (this kernel was four exposed memory round
+// trips per tile: 21 us for 21 MB)
+__device__ __forceinline__ float4 load4_raw(const float* __restrict__ row, int64_t s, int64_t s_last) {
+    return *reinterpret_cast<const float4*>(row + (s < s_last ? s : s_last));
+}
+__device__ __forceinline__ float4 mask4(const float4 v, int64_t s, int64_t n, bool on) {
+    return make_float4((on && s < n) ? v.x : 0.f, (on && s + 1 < n) ? v.y : 0.f, (on && s + 2 < n) ? v.z : 0.f, (on && s + 3 < n) ? v.w : 0.f);
 }
 
 __global__ void __launch_bounds__(kWmThreads)
@@ -267,26 +267,54 @@ wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__
 #pragma unroll
     for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int n_tiles_p = (int)((w.p + 15) / 16), n_tiles_r = (int)((n_rays + 15) / 16);
+    // software-pipelined: the NEXT tile's four operand loads are in flight during this tile's twelve MFMAs (a wave has ~8
+    // tiles: with the loads issued and awaited tile by tile the kernel was eight exposed memory round trips, 21 us for 21 MB)
+    const int step = gridDim.x * kWmWaves;
+    const int64_t s_last = P - 4;                  // rows are p_pad long (a multiple of 64)
+    const float* __restrict__ row_a = ws + w.dz + (jl < 3 ? jl : 0) * P;
+    const float* __restrict__ row_b0 = ws + w.fe + jl * P;
+    const float* __restrict__ row_b1 = ws + (dual ? w.fe2 : w.fe) + jl * P;
+    const float* __restrict__ row_b2 = jl < 3 ? ws + w.p3 + jl * P : ws + w.nrm + (jl < 6 ? jl - 3 : 0) * P;
+    {
+        // kDecBatch tiles per trip, all their loads issued before the first MFMA (a wave has ~8 tiles at the benchmark: two memory
+        // round trips instead of thirty-two).  (A rotating "next tile" prefetch does not survive the compiler here: it merges the
+        // loop-carried loads back into the iteration that uses them, or waits for vmcnt(0) at the loop head.)
+        constexpr int kDecBatch = 4;
 #pragma unroll 1
-    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_p; tile += gridDim.x * kWmWaves) {
-        const int64_t s = (int64_t)tile * 16 + 4 * g;
-        const float4 a = load4_masked(ws + w.dz + jl * P, s, w.p, jl < 3);
-        const float4 b0 = load4_masked(ws + w.fe + jl * P, s, w.p, true);
-        const float4 b1 = load4_masked(ws + w.fe2 + jl * P, s, w.p, dual != 0);
-        float4 b2 = load4_masked(jl < 3 ? ws + w.p3 + jl * P : ws + w.nrm + (jl - 3) * P, s, w.p, jl < 6);
-        if (jl == 6) b2 = make_float4(1.f, 1.f, 1.f, 1.f);           // bias column (a is zero beyond the last sample)
-        acc[0] = mfma4(a.x, b0.x, acc[0]); acc[0] = mfma4(a.y, b0.y, acc[0]); acc[0] = mfma4(a.z, b0.z, acc[0]); acc[0] = mfma4(a.w, b0.w, acc[0]);
-        acc[1] = mfma4(a.x, b1.x, acc[1]); acc[1] = mfma4(a.y, b1.y, acc[1]); acc[1] = mfma4(a.z, b1.z, acc[1]); acc[1] = mfma4(a.w, b1.w, acc[1]);
-        acc[2] = mfma4(a.x, b2.x, acc[2]); acc[2] = mfma4(a.y, b2.y, acc[2]); acc[2] = mfma4(a.z, b2.z, acc[2]); acc[2] = mfma4(a.w, b2.w, acc[2]);
+        for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_p; tile += kDecBatch * step) {
+            float4 ra[kDecBatch], rb0[kDecBatch], rb1[kDecBatch], rb2[kDecBatch];
+#pragma unroll
+            for (int u = 0; u < kDecBatch; ++u) {
+                const int64_t s = (int64_t)(tile + u * step) * 16 + 4 * g;
+                ra[u] = load4_raw(row_a, s, s_last); rb0[u] = load4_raw(row_b0, s, s_last);
+                rb1[u] = load4_raw(row_b1, s, s_last); rb2[u] = load4_raw(row_b2, s, s_last);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (the machine scheduler otherwise sinks each tile's loads to its MFMAs)
+#pragma unroll
+            for (int u = 0; u < kDecBatch; ++u) {
+                const int64_t s = (int64_t)(tile + u * step) * 16 + 4 * g;
+                const bool on = tile + u * step < n_tiles_p;
+                const float4 a = mask4(ra[u], s, w.p, on && jl < 3), b0 = mask4(rb0[u], s, w.p, on), b1 = mask4(rb1[u], s, w.p, on && dual != 0);
+                float4 b2 = mask4(rb2[u], s, w.p, on && jl < 6);
+                if (on && jl == 6) b2 = make_float4(1.f, 1.f, 1.f, 1.f);       // bias column (a is zero beyond the last sample)
+                acc[0] = mfma4(a.x, b0.x, acc[0]); acc[1] = mfma4(a.x, b1.x, acc[1]); acc[2] = mfma4(a.x, b2.x, acc[2]);
+                acc[0] = mfma4(a.y, b0.y, acc[0]); acc[1] = mfma4(a.y, b1.y, acc[1]); acc[2] = mfma4(a.y, b2.y, acc[2]);
+                acc[0] = mfma4(a.z, b0.z, acc[0]); acc[1] = mfma4(a.z, b1.z, acc[1]); acc[2] = mfma4(a.z, b2.z, acc[2]);
+                acc[0] = mfma4(a.w, b0.w, acc[0]); acc[1] = mfma4(a.w, b1.w, acc[1]); acc[2] = mfma4(a.w, b2.w, acc[2]);
+            }
+        }
     }
+    {
+        const int64_t r_last = w.r_pad - 4;
 #pragma unroll 1
-    for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_r; tile += gridDim.x * kWmWaves) {
-        const int64_t s = (int64_t)tile * 16 + 4 * g;
-        const float4 a = load4_masked(ws + w.dzr + jl * w.r_pad, s, n_rays, jl < 3);
-        const float4 b0 = load4_masked(ws + w.renc + jl * w.r_pad, s, n_rays, true);
-        const float4 b1 = load4_masked(ws + w.renc + (16 + jl) * w.r_pad, s, n_rays, 16 + jl < kView);
-        acc[3] = mfma4(a.x, b0.x, acc[3]); acc[3] = mfma4(a.y, b0.y, acc[3]); acc[3] = mfma4(a.z, b0.z, acc[3]); acc[3] = mfma4(a.w, b0.w, acc[3]);
-        acc[4] = mfma4(a.x, b1.x, acc[4]); acc[4] = mfma4(a.y, b1.y, acc[4]); acc[4] = mfma4(a.z, b1.z, acc[4]); acc[4] = mfma4(a.w, b1.w, acc[4]);
+        for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_r; tile += gridDim.x * kWmWaves) {
+            const int64_t s = (int64_t)tile * 16 + 4 * g;
+            const float4 ra = load4_raw(ws + w.dzr + (jl < 3 ? jl : 0) * w.r_pad, s, r_last), rb0 = load4_raw(ws + w.renc + jl * w.r_pad, s, r_last),
+                         rb1 = load4_raw(ws + w.renc + (16 + jl < kView ? 16 + jl : 0) * w.r_pad, s, r_last);
+            const float4 a = mask4(ra, s, n_rays, jl < 3), b0 = mask4(rb0, s, n_rays, true), b1 = mask4(rb1, s, n_rays, 16 + jl < kView);
+            acc[3] = mfma4(a.x, b0.x, acc[3]); acc[4] = mfma4(a.x, b1.x, acc[4]); acc[3] = mfma4(a.y, b0.y, acc[3]); acc[4] = mfma4(a.y, b1.y, acc[4]);
+            acc[3] = mfma4(a.z, b0.z, acc[3]); acc[4] = mfma4(a.z, b1.z, acc[4]); acc[3] = mfma4(a.w, b0.w, acc[3]); acc[4] = mfma4(a.w, b1.w, acc[4]);
+        }
     }
     for (int wv = 0; wv < kWmWaves; ++wv) {
         if (wave == wv) {

@@ -20,6 +20,14 @@ constexpr int kFinalizeTasks = 7;
 // whole L2 per workgroup: measured 35.6 us for the launch and +12 us on the step (it runs beside slab_accumulate).
 __device__ __forceinline__ void wg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float wg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// several of them IN FLIGHT together: the compiler keeps atomic loads in program order and waits for each on the spot (a
+// finalize task's nine loads per thread were nine exposed round trips to memory, ~13 us of the tail kernel's 35): the same
+// L2-bypassing load instruction, issued back to back, one wait
+__device__ __forceinline__ void wg_load3(const float* p0, const float* p1, const float* p2, float& v0, float& v1, float& v2) {
+    asm volatile("global_load_dword %0, %3, off sc1\n\tglobal_load_dword %1, %4, off sc1\n\tglobal_load_dword %2, %5, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
 
 // sum of the per-workgroup partials (fixed order -> deterministic), scattered into the reduced-gradient buffer
 // (WgLayout).  One launch for all three producers: block ranges [0,85) SDF MLP, [85,153) second MLP, then 20 decoder.
@@ -145,16 +153,31 @@ struct FinalizeArgs {
         const ls2fm_linear_grad* gl = which ? G.geo_mlp : G.sdf_mlp;
         const int ind = which ? in_dim2 : in_dim;
         if ((task & 1) == 0) {
-            for (int idx = tid; idx < kHidden * 36; idx += 256) s_row[idx / 36][idx % 36] = wg_load(&dW0[idx]);
+            static_assert(kHidden * 36 == 9 * 256, "three batches of three loads per thread");
+#pragma unroll
+            for (int q = 0; q < 9; q += 3) {
+                const int i0 = tid + 256 * q, i1 = i0 + 256, i2 = i0 + 512;
+                float v0, v1, v2;
+                wg_load3(&dW0[i0], &dW0[i1], &dW0[i2], v0, v1, v2);
+                s_row[i0 / 36][i0 % 36] = v0; s_row[i1 / 36][i1 % 36] = v1; s_row[i2 / 36][i2 % 36] = v2;
+            }
             __syncthreads();
             const bool add = fa.add != 0 && which == 0;
             weight_norm_bwd_rows(lin[0].weight_v, lin[0].weight_g, &s_row[0][0], 68, kHidden, ind, gl[0].weight_v, gl[0].weight_g, tid, add);
             if (tid < kHidden) gl[0].bias[tid] = add ? gl[0].bias[tid] + s_row[tid][35] : s_row[tid][35];
             return;
         }
-        for (int idx = tid; idx < kOut * kHidden; idx += 256) {
-            const int o = idx / kHidden, j = idx % kHidden;
-            s_row[o][j] = wg_load(&dW1[o * 65 + j]) + ((which == 0 && o == 0) ? wg_load(&wg[WgLayout::dW1r0 + j]) : 0.f);
+        {   // 17 x 64 values: four per thread (+ the last row's 64), the row-0 extra term with them -- two batches
+            static_assert(kOut == 17 && kHidden == 64, "layout of the batches below");
+            const int i0 = tid, i1 = tid + 256, i2 = tid + 512, i3 = tid + 768;
+            const float* last = tid < 64 ? &dW1[16 * 65 + tid] : &dW1[0];
+            const float* extra = tid < 64 ? &wg[WgLayout::dW1r0 + tid] : &dW1[0];
+            float v0, v1, v2, v3, v4, v5;
+            wg_load3(&dW1[(i0 / 64) * 65 + i0 % 64], &dW1[(i1 / 64) * 65 + i1 % 64], &dW1[(i2 / 64) * 65 + i2 % 64], v0, v1, v2);
+            wg_load3(&dW1[(i3 / 64) * 65 + i3 % 64], last, extra, v3, v4, v5);
+            s_row[i0 / 64][i0 % 64] = v0 + ((which == 0 && tid < 64) ? v5 : 0.f);        // (i0 / 64 == 0 <=> tid < 64)
+            s_row[i1 / 64][i1 % 64] = v1; s_row[i2 / 64][i2 % 64] = v2; s_row[i3 / 64][i3 % 64] = v3;
+            if (tid < 64) s_row[16][tid] = v4;
         }
         __syncthreads();
         const bool add = fa.add != 0 && which == 0;

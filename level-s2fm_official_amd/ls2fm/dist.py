@@ -515,7 +515,10 @@ class ShardedAdam:
         if len(events) != self.n_groups or flat_g.numel() != self.total:
             return False                                       # not this optimizer's layout: step() exchanges everything itself
         dev = self.flat.device
-        if not self.flat.is_cuda:
+        if not self.flat.is_cuda or torch.cuda.is_current_stream_capturing():
+            # (inside a hipGraph capture the chain is issued at step(), on the capturing stream itself: a communication-stream
+            # branch that forks again into the backend's own stream is a fork tree of depth three, which takes the capture down on
+            # ROCm 7.2 -- the same limit csrc/streams.hip works around)
             return False
         cur, comm = torch.cuda.current_stream(dev), comm_stream(dev)
         for g, ev in enumerate(events):
@@ -550,7 +553,7 @@ class ShardedAdam:
         else:                                                  # gradients from elsewhere (composed form, several nodes): same
             flat_g = self._flat_gradient()                     # per-group chain, issued now
             dev = self.flat.device
-            if self.flat.is_cuda:
+            if self.flat.is_cuda and not torch.cuda.is_current_stream_capturing():
                 cur, comm = torch.cuda.current_stream(dev), comm_stream(dev)
                 comm.wait_stream(cur)
                 with torch.cuda.stream(comm):

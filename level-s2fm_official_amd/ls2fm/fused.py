@@ -525,6 +525,8 @@ class _Render(torch.autograd.Function):
         # multi-GPU: scatter the levels in groups and all-reduce a group's table slices while the next group is scattered
         from . import dist as _dist
         n_groups = int(getattr(ps[0], "_ls2fm_overlap_groups", 0)) if _dist.is_distributed() else 0
+        if n_groups > 1 and getattr(ps[0], "_ls2fm_group_exchange", None) is not None and torch.cuda.is_current_stream_capturing():
+            n_groups = 0                           # (captured steps: the optimizer issues its chain at step(), ls2fm.dist)
         if n_groups > 1 and getattr(ps[0], "_ls2fm_group_exchange", None) is not None and fl is not None and fl.depth_node is not None:
             # a traced-depth node rides in this backward (ls2fm_depth_backward adds into the tables BEHIND the scatter: a group's
             # slices would not be final at its event): a pipelined sharded optimizer then exchanges at its step() instead
