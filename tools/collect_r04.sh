@@ -15,7 +15,8 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MO
   python tools/pmc_summary.py gpurun_out/${TAG}_pmc_$tag > gpurun_out/${TAG}_pmc_$tag.txt 2>&1
   rm -rf gpurun_out/${TAG}_pmc_$tag
 done
-cp gpurun_out/${TAG}_pmc_FETCH_SIZE.txt gpurun_out/${TAG}_pmc_fetch.txt; cp gpurun_out/${TAG}_pmc_WRITE_SIZE.txt gpurun_out/${TAG}_pmc_write.txt
+mv gpurun_out/${TAG}_pmc_FETCH_SIZE.txt gpurun_out/${TAG}_pmc_fetch.txt; mv gpurun_out/${TAG}_pmc_WRITE_SIZE.txt gpurun_out/${TAG}_pmc_write.txt
+mv gpurun_out/${TAG}_pmc_TCC_HIT_sum_.txt gpurun_out/${TAG}_pmc_l2.txt; mv gpurun_out/${TAG}_pmc_SQ_INSTS_VAL.txt gpurun_out/${TAG}_pmc_mfma.txt
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 for c in C1 C3 C4 C5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/${TAG}_bench_$c.json 2>/dev/null; done
 python bench.py --inference --rays 8192 --no-cpu-baseline > gpurun_out/${TAG}_bench_inference_8192rays.json 2>/dev/null
@@ -26,7 +27,10 @@ python bench.py --with-update --no-cpu-baseline > gpurun_out/${TAG}_bench_with_u
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard-groups 1 > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic.json 2>/dev/null
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard-groups 2 > gpurun_out/${TAG}_bench_1rank_rccl_shard_pipelined2.json 2>/dev/null
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard-groups 4 > gpurun_out/${TAG}_bench_1rank_rccl_shard_pipelined4.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph --shard-groups 1 > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic_graph.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph --shard-groups 2 > gpurun_out/${TAG}_bench_1rank_rccl_shard_pipelined2_graph.json 2>/dev/null
 python tools/time_points.py > gpurun_out/${TAG}_point_queries.txt 2>&1
+[ -f tools/ab/lib_stamps.so ] && LS2FM_LIB=$PWD/tools/ab/lib_stamps.so LS2FM_SERIAL=1 timeout 300 python tools/acc_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_acc_stamps.txt
 python tools/time_stage.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_stage_step.txt
 python tools/time_loops.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_loops_step.txt
 rocprofv3 --kernel-trace -d gpurun_out/tl -- python bench.py --no-cpu-baseline --launch graph --steps 50 --warmup 10 >/dev/null 2>&1
