@@ -37,9 +37,6 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
                  WsLayout wb, const float* __restrict__ wsb, int n_tiles_b) {
     constexpr int NT = GEO ? 4 : 5;
     constexpr int R = GEO ? kRegsGeo : kRegsSdf;
-#ifdef LS2FM_WGRAD_PRIO
-    __builtin_amdgcn_s_setprio(LS2FM_WGRAD_PRIO);      // instruction-issue priority over the scatter's waves on the same SIMD
-#endif
     __shared__ float s_w[4 * 9 * 64 + 4 * 5 * 64 + 4 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float s_x[kWmWaves][kXRows * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
