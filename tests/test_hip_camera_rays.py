@@ -86,3 +86,28 @@ def test_camera_rays_refuses_cpu_tensors():
     kinv = cam.host_inverse_intrinsic(intr)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cam.camera_rays(kinv, poses=cam.lie.se3_to_SE3(se3).cpu(), pix=torch.arange(4), width=W)
+
+
+def test_c_abi_argument_checks_of_the_round_4_entry_points():
+    """LS2FM_ERR_INVALID_ARGUMENT (-1), nothing enqueued: both or neither of poses / se3, both or neither of xy / pix, a pixel
+    index list without the image width, an unknown scatter mode"""
+    import ctypes
+    from ls2fm import _lib
+    lib = _lib.load()
+    se3, intr, H, W, g = _setup()
+    kinv = cam.host_inverse_intrinsic(intr)
+    poses = cam.lie.se3_to_SE3(se3).contiguous()
+    idx = torch.arange(16, device=DEV)
+    c, r = torch.empty(3, 16, 3, device=DEV), torch.empty(3, 16, 3, device=DEV)
+    P = _lib.ptr
+    call = lambda po, se, xy, pix, width: lib.ls2fm_camera_rays(P(po), P(se), kinv, P(xy), P(pix), width, 0, None, 3, 16, P(c), P(r), None,
+                                                                _lib.stream_ptr())
+    assert call(poses, se3, None, idx, W) == -1
+    assert call(None, None, None, idx, W) == -1
+    assert call(poses, None, None, None, W) == -1
+    assert call(poses, None, None, idx, 0) == -1
+    assert call(poses, None, None, idx, W) == 0
+    assert lib.ls2fm_set_scatter_mode(7) == -1 and lib.ls2fm_get_scatter_mode() == 1
+    assert lib.ls2fm_adam_sched_decay(1, None, _lib.stream_ptr()) == -1
+    assert lib.ls2fm_se3_exp_fwd(None, 2, None, _lib.stream_ptr()) == -1
+    torch.cuda.synchronize()
