@@ -130,7 +130,11 @@ __device__ __forceinline__ float corner_d2weight(const float w[3], int k, int a,
 // ~14 VALU ops instead of ~70 for expf + log1pf + two IEEE divisions; absolute error of h <= 1e-9, relative error of the
 // derivatives <= 3e-7 (the parity bar of the path is 1e-4 relative).
 __device__ __forceinline__ float log1p_unit(float e) {          // log(1 + e) for e in [0, 1]
-    return e < 0.02f ? e * fmaf(e, fmaf(e, 0.333333333f, -0.5f), 1.0f) : __builtin_amdgcn_logf(1.0f + e) * 0.693147181f;
+    // both forms computed, then selected: as a branch (what `c ? f() : g()` compiles to here) every softplus is a chain of
+    // small basic blocks, and nothing -- no MFMA of the next block, no load -- is scheduled across them
+    const float small = e * fmaf(e, fmaf(e, 0.333333333f, -0.5f), 1.0f);
+    const float large = __builtin_amdgcn_logf(1.0f + e) * 0.693147181f;
+    return e < 0.02f ? small : large;
 }
 
 __device__ __forceinline__ void softplus100(float a, float& h, float& d1, float& d2) {
@@ -138,7 +142,8 @@ __device__ __forceinline__ void softplus100(float a, float& h, float& d1, float&
     const float e = __builtin_amdgcn_exp2f(fabsf(z) * -1.44269504f);
     const float rd = __builtin_amdgcn_rcpf(1.0f + e);
     const bool lin = z > 20.0f;                                  // torch's threshold: identity above it
-    h = lin ? a : (fmaxf(z, 0.0f) + log1p_unit(e)) * 0.01f;
+    const float soft = (fmaxf(z, 0.0f) + log1p_unit(e)) * 0.01f;  // a value, then a select: no branch (see log1p_unit)
+    h = lin ? a : soft;
     const float er = e * rd;
     d1 = lin ? 1.0f : (z >= 0.0f ? rd : er);
     d2 = lin ? 0.0f : 100.0f * er * rd;
@@ -147,7 +152,8 @@ __device__ __forceinline__ void softplus100(float a, float& h, float& d1, float&
 __device__ __forceinline__ float softplus100_value(float a) {
     const float z = a * 100.0f;
     const float e = __builtin_amdgcn_exp2f(fabsf(z) * -1.44269504f);
-    return z > 20.0f ? a : (fmaxf(z, 0.0f) + log1p_unit(e)) * 0.01f;
+    const float soft = (fmaxf(z, 0.0f) + log1p_unit(e)) * 0.01f;
+    return z > 20.0f ? a : soft;
 }
 
 // slab test of one ray against one box (ngp_pl semantics).  fminf/fmaxf ignore NaNs.

@@ -363,6 +363,131 @@ sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const
     if (lane == 0 && kmax > 0) atomicMax(trips, kmax);
 }
 
+// ---- sphere tracing, one WAVE per ray end (a 128-thread workgroup = one ray).  At the stage loops' ray counts (1024 rays) the
+// 16-lane kernel above leaves the chip almost idle (one wave on half the SIMDs) and spends its step on 144 LDS weight reads and
+// 140 FMAs per lane.  Here lane j owns hidden unit j with its W0 row in registers for the whole trace, lanes 0-15 gather the 16
+// levels, the 32 encoding values are broadcast as scalars (v_readlane) and the sdf row is the same j = 0 .. 63 fmaf chain fed by
+// v_readlane -- every sum in the order of geometry_forward, so the result is BIT-IDENTICAL to the other two tracing kernels.
+// The two ends of a ray exchange their parameter through LDS once per trip (step 7).
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+template <int J>
+__device__ __forceinline__ float wave_chain(float w1_me, float h, float f) {
+    if constexpr (J < kHidden) {
+        const float hv = lane_bcast(h, J);
+        const float wv = lane_bcast(w1_me, J);
+        return wave_chain<J + 1>(w1_me, h, fmaf(wv, hv, f));
+    } else {
+        return f;
+    }
+}
+
+__device__ __forceinline__ float wave_sdf(const LevelSet& lv, const FieldC& fc, int bg_sdf, float bg_rad,
+                                          const float* __restrict__ table, const float (&w)[kInMax + 1], float w1_me, float b1_0,
+                                          const float p[3], int lane) {
+    float x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+    float y0 = 0.f, y1 = 0.f;
+    if (lane < lv.n_levels) {
+        Cell c;
+        locate(x, lv.scale[lane], lv.res[lane], lv.size[lane], lv.offset[lane], lv.hashed[lane], c);
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float wt = corner_weight(c.w, k);
+            y0 = fmaf(wt, v[k].x, y0);
+            y1 = fmaf(wt, v[k].y, y1);
+        }
+    }
+    float u[kInMax];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = p[a] / fc.rescale;
+#pragma unroll
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+        u[3 + 2 * l] = lane_bcast(y0, l);
+        u[4 + 2 * l] = lane_bcast(y1, l);
+    }
+    float a0 = w[kRecB0], a1 = 0.0f;               // same two-chain order as geometry_forward
+#pragma unroll
+    for (int k = 0; k + 1 < kInMax; k += 2) {
+        a0 = fmaf(w[k], u[k], a0);
+        a1 = fmaf(w[k + 1], u[k + 1], a1);
+    }
+    a0 = fmaf(w[kInMax - 1], u[kInMax - 1], a0);
+    const float h = softplus100_value(a0 + a1);
+    const float f0 = wave_chain<0>(w1_me, h, b1_0);
+    bool bg;
+    return signed_sdf(fc, bg_sdf, bg_rad, f0, p, &bg);
+}
+
+__global__ void __launch_bounds__(128)
+sphere_trace_wave_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
+                         const float* __restrict__ table, const float* __restrict__ ray0, const float* __restrict__ ray_dir,
+                         int64_t n_rays, float thr, int iters_max, float* __restrict__ near_out, float* __restrict__ far_out,
+                         float* __restrict__ track, float* __restrict__ t_end, float* __restrict__ track_sdf, int* __restrict__ trips) {
+    __shared__ float s_t[2][2];
+    const int lane = threadIdx.x & 63, side = threadIdx.x >> 6;
+    const int64_t r = blockIdx.x;                  // the grid is n_rays workgroups
+    float w[kInMax + 1];
+#pragma unroll
+    for (int k = 0; k <= kInMax; ++k) w[k] = pk->sdf[lane * kRecStride + k];
+    const float w1_me = pk->sdf[lane * kRecStride + kRecW1];
+    const float b1_0 = pk->sdf[kHidden * kRecStride];
+    const RayGeom g = load_ray(fc, ray0, ray_dir, r);
+    const float far = g.t_far;
+    float t_me = side ? g.t_far : g.t_near;
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
+    float sdf_me = wave_sdf(lv, fc, bg_sdf, bg_rad, table, w, w1_me, b1_0, p, lane);
+    float raw_me = sdf_me;               // the field's value at the current point (see sphere_trace_kernel)
+    const bool want_raw = track_sdf != nullptr && side == 0;
+    const bool writer = lane == 0;
+    if (writer && side == 0) { near_out[r] = g.t_near; far_out[r] = g.t_far; }
+    if (writer && side == 1) t_end[r * (iters_max + 1)] = t_me;
+    bool unf = false;
+    int kfin = -1;
+    for (int k = 0;; ++k) {
+        if (fabsf(sdf_me) <= thr) sdf_me = 0.f;                          // (1) converged values are zeroed
+        const bool m = fabsf(sdf_me) > thr;
+        unf = k == 0 ? m : (unf && m);                                    // (2)
+        if (side == 0 && !unf && kfin < 0) kfin = k;                      // (3) this ray's start end is done at trip k
+        if (k == iters_max) break;
+        if (writer && side == 0) {                                        // (5) pre-update start point -> track
+#pragma unroll
+            for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + k) * 3 + a] = p[a];
+            if (track_sdf) track_sdf[r * (iters_max + 1) + k] = raw_me;
+        }
+        const float t_before = t_me;
+        t_me = t_me + sdf_me;                                             // (4) both ends step with '+', clamp to far
+        if (t_me > far) t_me = far;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a] = g.o[a] + t_me * g.d[a];
+        if (unf || (want_raw && t_me != t_before)) {                      // (6) wave-uniform
+            raw_me = wave_sdf(lv, fc, bg_sdf, bg_rad, table, w, w1_me, b1_0, p, lane);
+            if (unf) sdf_me = raw_me;
+        }
+        if (writer) s_t[k & 1][side] = t_me;                              // the other end's parameter: one barrier per trip
+        __syncthreads();                                                  // (slot k & 1 is rewritten two barriers later)
+        const float t_other = s_t[k & 1][side ^ 1];
+        const float t_s = side ? t_other : t_me, t_e = side ? t_me : t_other;
+        unf = unf && (t_s < t_e);                                         // (7) crossed ends drop out
+        if (writer && side == 1) t_end[r * (iters_max + 1) + k + 1] = t_me;
+    }
+    if (writer && side == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) track[(r * (iters_max + 1) + iters_max) * 3 + a] = p[a];
+        if (track_sdf) track_sdf[r * (iters_max + 1) + iters_max] = raw_me;
+        const int kmax = kfin < 0 ? iters_max : kfin;
+        if (kmax > 0) atomicMax(trips, kmax);
+    }
+}
+
 }  // namespace
 
 static bool field_ok(const ls2fm_field_desc* f, const ls2fm_grid_desc* g, const ls2fm_params* p) {
@@ -496,10 +621,15 @@ static int sphere_trace_impl(const ls2fm_field_desc* field, const ls2fm_grid_des
     // latency-bound at stage-loop sizes (wide: 16 lanes per ray end; 8192 rays 0.26 ms per call against 0.52, 1024 rays 0.13
     // against 0.53), throughput-bound at tens of thousands of rays (one lane per ray end: no redundant lanes).  Both kernels
     // give bit-identical results.
-    static const int force = [] { const char* e = getenv("LS2FM_TRACE_KERNEL"); return e ? atoi(e) : 0; }();      // 1 narrow, 2 wide
-    const bool narrow = force == 1 || (force != 2 && n_rays > 20000);
+    static const int force = [] { const char* e = getenv("LS2FM_TRACE_KERNEL"); return e ? atoi(e) : 0; }();      // 1 narrow, 2 wide, 3 wave
+    const bool narrow = force == 1 || (force == 0 && n_rays > 20000);
+    const bool wave = force == 3 || (force == 0 && n_rays <= 2048);
     ls2fm_prof_begin(LS2FM_PROF_SPHERE_TRACE, s);
-    if (narrow)
+    if (wave)           // one ray per 128-thread workgroup
+        sphere_trace_wave_kernel<<<(unsigned)n_rays, 128, 0, s>>>(
+            make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk, params->sdf_table, ray0, ray_dir, n_rays,
+            sdf_threshold, iters_max, near, far, track, t_end, track_sdf, trips);
+    else if (narrow)
         sphere_trace_kernel<<<(unsigned)((2 * n_rays + 255) / 256), 256, 0, s>>>(
             make_level_set(grid), make_field_c(field), field->bg_sdf, field->bg_rad, pk, params->sdf_table, ray0, ray_dir, n_rays,
             sdf_threshold, iters_max, near, far, track, t_end, track_sdf, trips);

@@ -41,6 +41,9 @@ def _rays(g, extra, s, seed):
     return c.contiguous(), d.contiguous()
 
 
+_EXTRA_RAYS = dict(wave=1000, wide=3000, narrow=20100)          # + the 48 recorded rays: which kernel ls2fm_sphere_trace picks
+
+
 def _device_field(sdf):
     def field(q):
         with torch.no_grad():
@@ -49,15 +52,16 @@ def _device_field(sdf):
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
-@pytest.mark.parametrize("kernel", ["wide", "narrow"])
+@pytest.mark.parametrize("kernel", ["wave", "wide", "narrow"])
 def test_trace_loop_resynchronised_is_bit_exact_at_iters_max(case, kernel, manifest, monkeypatch):
     g = load_golden(case)
     meta = manifest[case]
     opt, sdf, rad, ren = product_for(meta, g, DEV)
     cfg = golden_cfg(meta)
     s = (cfg.bound_max[0] - cfg.bound_min[0]) / 2
-    # the narrow (lane per ray end) kernel serves calls above 20 000 rays: same code path as production
-    c, d = _rays(g, 1000 if kernel == "wide" else 20100, s, seed=11)
+    # the wave-per-end kernel serves calls of up to 2048 rays, the 16-lanes-per-end one those up to 20 000, the narrow
+    # (lane per ray end) kernel the rest: same code path as production
+    c, d = _rays(g, _EXTRA_RAYS[kernel], s, seed=11)
     osd = golden_state(g, "sdf", requires_grad=True)
     det = {}
     od, os_, _, ofin, otrips = OF.sphere_tracing(cfg, c.view(1, -1, 3), d.view(1, -1, 3), osd, rng=False,
@@ -69,7 +73,7 @@ def test_trace_loop_resynchronised_is_bit_exact_at_iters_max(case, kernel, manif
     assert torch.equal(near.cpu(), det["near"]) and torch.equal(far.cpu(), det["far"])
     assert torch.equal(pts.cpu(), det["track"]), "track differs from the oracle loop fed the same field values"
     assert torch.equal(t_hist.cpu(), det["t_end"])
-    if kernel == "narrow":
+    if kernel != "wave":
         return
     # differentiable tail on that track: d_pred, sdf_last, finish mask, gradients
     losses.tracing_loss(od, os_).backward()
@@ -127,7 +131,7 @@ def test_trace_free_running_vs_oracle_and_reference_goldens(case, manifest, reco
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES[:2])
-@pytest.mark.parametrize("kernel", ["wide", "narrow"])
+@pytest.mark.parametrize("kernel", ["wave", "wide", "narrow"])
 def test_track_values_from_the_loop_are_the_field_at_the_track_points(case, kernel, manifest):
     """ls2fm_sphere_trace's track_sdf output -- what the static tracing path sums into the depth instead of evaluating the track
     a second time -- is, bit for bit, the field at the track points: also for start ends that stopped being refreshed but kept
@@ -136,7 +140,7 @@ def test_track_values_from_the_loop_are_the_field_at_the_track_points(case, kern
     opt, sdf, rad, ren = product_for(manifest[case], g, DEV)
     cfg = golden_cfg(manifest[case])
     s = (cfg.bound_max[0] - cfg.bound_min[0]) / 2
-    c, d = _rays(g, 1000 if kernel == "wide" else 20100, s, seed=23)
+    c, d = _rays(g, _EXTRA_RAYS[kernel], s, seed=23)
     with torch.no_grad():
         near, far, track, t_end, trips = fused.sphere_trace(sdf, c.to(DEV), d.to(DEV), sync=False)
         vals = track._ls2fm_track_sdf
