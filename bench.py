@@ -447,7 +447,8 @@ def main():
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
             doc = json.load(open(pmc))
             if roofline["kernel"].startswith("scatter_pair") and "scatter_fill" in doc and "slab_accumulate" in doc:
-                rec = {k: doc["scatter_fill"][k] + doc["slab_accumulate"][k] for k in ("fetch", "write")}
+                rec = {k: doc["scatter_fill"][k] + doc["slab_accumulate"][k] + doc.get("slab_combine", {}).get(k, 0.0)     # the
+                       for k in ("fetch", "write")}                   # accumulate span covers its combine launch (split slabs)
             else:
                 rec = doc.get(roofline["kernel"])
             if rec:
