@@ -8,7 +8,7 @@
 namespace {
 
 constexpr int kAccSlots = 2 << kSlabShift;       // 16384 u64 accumulators = 128 KiB of LDS per workgroup
-constexpr int kSlabBins = 128;                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
+constexpr int kSlabBins = 128 << (13 - kSlabShift);                   // slabs per level (2^19 entries / 4096); bigger levels get wider slabs
 constexpr int kBins = kSlabBins;
 #ifndef LS2FM_FILL_TILE
 #define LS2FM_FILL_TILE 256
@@ -16,7 +16,10 @@ constexpr int kBins = kSlabBins;
 constexpr int kCountThreads = LS2FM_FILL_TILE;
 constexpr int kFillThreads = LS2FM_FILL_TILE;    // one sample point per thread
 constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
-constexpr int kAccThreads = 1024;
+#ifndef LS2FM_ACC_THREADS
+#define LS2FM_ACC_THREADS 1024
+#endif
+constexpr int kAccThreads = LS2FM_ACC_THREADS;
 #ifndef LS2FM_ACC_BATCH
 #define LS2FM_ACC_BATCH 4
 #endif

@@ -217,7 +217,10 @@ struct WsLayout {
     int64_t total;
 };
 
-constexpr int kSlabShift = 13;          // table-gradient scatter: 8192-entry slabs of one grid, or 4096-entry slabs of both
+#ifndef LS2FM_SLAB_SHIFT
+#define LS2FM_SLAB_SHIFT 13
+#endif
+constexpr int kSlabShift = LS2FM_SLAB_SHIFT;          // table-gradient scatter: 8192-entry slabs of one grid, or 4096-entry slabs of both
 static inline int ls2fm_slab_shift(int dual) { return dual ? kSlabShift - 1 : kSlabShift; }
 constexpr int kWgradMlpBlocks = 256;   // persistent workgroups of wgrad_mlp: ONE per CU -- alone the kernels are slower than with two
                                       // (63 + 43 vs 52 + 34 us), but they run beside scatter_fill / slab_accumulate and leave them
