@@ -186,10 +186,12 @@ __device__ __forceinline__ void geometry_forward(const float* __restrict__ rec, 
 
 // Fourier view embedding component c (0..26) of direction d: [d, sin(1 d), cos(1 d), sin(2 d), ...]
 __device__ __forceinline__ float view_component(const float d[3], int c) {
-    if (c < 3) return d[c];
-    const int q = (c - 3) / 3, a = (c - 3) % 3;       // q: 0 sin f0, 1 cos f0, 2 sin f1, ...
+    // (selects, not d[a] with a run-time a: a dynamically indexed ray record is put into scratch memory as a whole)
+    const int q = c < 3 ? 0 : (c - 3) / 3, a = c < 3 ? c : (c - 3) % 3;       // q: 0 sin f0, 1 cos f0, 2 sin f1, ...
+    const float da = a == 0 ? d[0] : (a == 1 ? d[1] : d[2]);
+    if (c < 3) return da;
     const float f = (float)(1 << (q >> 1));
-    const float x = d[a] * f;
+    const float x = da * f;
     return (q & 1) ? cosf(x) : sinf(x);
 }
 
