@@ -361,7 +361,7 @@ def main():
         t_eager = probe(False)
         captured = CapturedStep(whole_step, params, stream=s_main)
         t_graph = probe(True)
-        use_graph = t_graph < 0.98 * t_eager
+        use_graph = not (t_eager < 0.98 * t_graph)      # a tie goes to the replay: its step time does not depend on the host
         launch_probe = {"eager_ms_per_step": t_eager * 1e3, "graph_ms_per_step": t_graph * 1e3}
         if rank == 0:
             print(f"[bench] launch probe: eager {t_eager * 1e3:.3f} ms/step, hipGraph {t_graph * 1e3:.3f} ms/step", file=sys.stderr)
