@@ -196,9 +196,10 @@ def main():
                          "buffer -> Adam on this rank's 1/N of the parameters (ls2fm.dist.ShardedAdam) -> all-gather of the updated "
                          "shards; allreduce: sum all-reduce of the gradients, no update in the step (--no-shard)")
     ap.add_argument("--no-shard", dest="exchange", action="store_const", const="allreduce")
-    ap.add_argument("--shard-groups", type=int, default=2,
+    ap.add_argument("--shard-groups", type=int, default=1,
                     help="N > 1, --exchange shard: level groups of the PIPELINED exchange (per group, issued from inside the backward: "
-                         "reduce-scatter -> Adam on this rank's slice -> all-gather); 1 = one reduce-scatter / one all-gather around the update")
+                         "reduce-scatter -> Adam on this rank's slice -> all-gather); 1 (default: the form that measured faster on a one-rank RCCL group, "
+                         "DESIGN 6) = one reduce-scatter / one all-gather around the update")
     ap.add_argument("--with-update", action="store_true",
                     help="N = 1: put the optimizer update (FusedAdam, schedule on the device) INSIDE the timed step, launched eagerly -- "
                          "the like-for-like single-GPU point of a scaling curve whose N > 1 points (sharded exchange) contain their update")

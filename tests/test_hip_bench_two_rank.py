@@ -2,7 +2,7 @@
 (torch.distributed.run, one process per rank) with LS2FM_BENCH_BACKEND=gloo -- RCCL refuses two ranks per device, gloo carries
 device tensors.  The figures of such a run mean nothing (both ranks share the GPU, the all-reduce goes through the host); what
 is tested is the control flow the 2/4/8-GPU runs take: process-group set-up, sharded rays, the gradient exchange -- the default
-reduce-scatter -> sharded Adam -> all-gather, and (--no-shard) the all-reduce, flat or overlapped from inside the backward --,
+reduce-scatter -> sharded Adam -> all-gather (monolithic, or --shard-groups 2: pipelined by level group), and (--no-shard) the all-reduce, flat or overlapped from inside the backward --,
 barriers, the block-count and max-over-ranks reductions, ONE JSON line on rank 0."""
 import json
 import os
@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("extra", [[], ["--no-shard"], ["--no-shard", "--no-overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--shard-groups", "2"], ["--no-shard"], ["--no-shard", "--no-overlap"]])
 def test_bench_two_ranks_one_gpu(extra):
     env = dict(os.environ, LS2FM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
