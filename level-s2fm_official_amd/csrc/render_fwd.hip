@@ -49,6 +49,48 @@ __device__ __forceinline__ int row_base(int li) {
 __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad,
                                   Packed* __restrict__ out, const int task, const int tid, const int nt) {
     // with_rad == 0: the no-graph SDF evaluation / sphere tracing -- scalar records of the SDF MLP only, no MFMA-ordered copies
+    if (!with_rad) {
+        // SDF-only users (sdf_eval, sphere tracing: `task` 0 alone, ahead of EVERY such call): one pass, no LDS hand-over -- the 16
+        // lanes of a row keep its weights in registers across the norm (same summation order as below: same scale, same bits),
+        // scale them and store the packed record entries themselves.  Rows 0..63 = layer 0, 64..80 = layer 1 (stored transposed).
+        float* __restrict__ dst = out->sdf;
+        for (int idx = tid; idx < kHidden * kRecStride; idx += nt) {          // everything that is not a scaled weight
+            const int j = idx / kRecStride, k = idx % kRecStride;
+            if (k == kRecB0) dst[idx] = P.sdf_mlp[0].bias[j];
+            else if ((k >= in_dim && k < kRecB0) || k >= kRecW1 + kOut) dst[idx] = 0.f;
+        }
+        for (int o = tid; o < 32; o += nt) dst[kHidden * kRecStride + o] = o < kOut ? P.sdf_mlp[1].bias[o] : 0.f;
+        for (int row0 = 0; row0 < kHidden + kOut; row0 += nt / 16) {
+            const int row = row0 + (tid >> 4), sub = tid & 15;
+            const bool on = row < kHidden + kOut, second = row >= kHidden;
+            const int o = second ? row - kHidden : row, in = second ? kHidden : in_dim;
+            const float* __restrict__ v = second ? P.sdf_mlp[1].weight_v : P.sdf_mlp[0].weight_v;
+            float x[4], ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = sub + 16 * q;
+                x[q] = (on && k < in) ? v[o * in + k] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ss = fmaf(x[q], x[q], ss);            // k >= in adds +0: the sum of the loop below
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 16);
+            if (on) {
+                const float sc = (second ? P.sdf_mlp[1].weight_g : P.sdf_mlp[0].weight_g)[o] / sqrtf(ss);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = sub + 16 * q;
+                    if (k < in) dst[second ? k * kRecStride + kRecW1 + o : o * kRecStride + k] = x[q] * sc;
+                }
+            }
+        }
+        if (tid == 3) {
+            const float beta = expf(P.beta[0] * P.beta_speed);
+            out->beta = beta;
+            out->alpha = 1.0f / beta;
+        }
+        return;
+    }
     __shared__ float row_scale[296];
     // one workgroup per independent task (a single workgroup doing everything was a 72 us latency chain that gated
     // shade_fwd in single-field runs): 0 = SDF MLP, 1 = second field's MLP, 2 = radiance chain (+ beta)
@@ -192,11 +234,13 @@ __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2
     if (tid == 3) out->bc[3] = 0.f;
 }
 
-__global__ void __launch_bounds__(256)
+constexpr int kPrepThreads = 1024;      // a chain of dependent round trips (norms -> scales -> packed rows): the wider the workgroup, the
+                                        // fewer trips per thread (256 threads: 13 us for the SDF MLP alone, ahead of every tracing call)
+__global__ void __launch_bounds__(kPrepThreads)
 prep_weights_kernel(ls2fm_params P, int in_dim, int in_dim2, int rad_in, int dual, int with_rad, Packed* __restrict__ out,
                     int32_t* __restrict__ zero_word) {
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;        // e.g. a tracing call's trip counter: no launch of its own
-    prep_weights_task(P, in_dim, in_dim2, rad_in, dual, with_rad, out, (int)blockIdx.x, (int)threadIdx.x, 256);
+    prep_weights_task(P, in_dim, in_dim2, rad_in, dual, with_rad, out, (int)blockIdx.x, (int)threadIdx.x, kPrepThreads);
 }
 
 // ------------------------------------------------------------------------------------------- ray_encode
@@ -504,7 +548,7 @@ static XcdPlan make_xcd_plan(const ls2fm_grid_desc* g1, int l1, const ls2fm_grid
 // weight-norm + packing of the SDF MLP only (shared with sdf_eval.hip)
 int ls2fm_launch_prep_sdf(const ls2fm_params* params, int n_levels, Packed* out, hipStream_t stream, int32_t* zero_word) {
     ls2fm_prof_begin(LS2FM_PROF_PREP, stream);
-    prep_weights_kernel<<<1, 256, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out, zero_word);      // task 0 only
+    prep_weights_kernel<<<1, kPrepThreads, 0, stream>>>(*params, 3 + 2 * n_levels, 0, 0, 0, 0, out, zero_word);      // task 0 only
     ls2fm_prof_end(LS2FM_PROF_PREP, stream);
     return ls2fm_launch_status();
 }
