@@ -25,24 +25,41 @@ __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, fl
     return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
 }
 
-// pose [3][4] of one view from its se(3) parameters (w, u)
+// The three 11-term series A, B, C (and their term-by-term derivatives) of one view, by ONE WAVE: lane 11 s + i forms term i of
+// series s -- 33 powf calls side by side instead of one after the other in a single lane (15 us per call of the exponential, in
+// front of every ray pick of a BA iteration) -- and every lane then sums the terms in the reference's order, left to right.
+// Denominators by the reference's running products (utils/camera.py:100-147): A (2i+1)!, B (2i+2)!, C (2i+3)!.  All 64 lanes of
+// the wave must be here.
+template <bool WANT_D>
+__device__ __forceinline__ void se3_series(float theta, float (&abc)[3], float (&dabc)[3]) {
+    const int lane = threadIdx.x & 63;
+    const int s = lane / kTerms, i = lane % kTerms;                 // lanes >= 33: s = 3.., never read
+    double denom = s == 0 ? 1.0 : (s == 1 ? 2.0 : 6.0);
+    for (int q = 1; q <= i; ++q)
+        denom *= s == 0 ? (double)((2 * q) * (2 * q + 1)) : (s == 1 ? (double)((2 * q + 1) * (2 * q + 2)) : (double)((2 * q + 2) * (2 * q + 3)));
+    const float sign = (i & 1) ? -1.0f : 1.0f;
+    const float term = (sign * powf(theta, (float)(2 * i))) / (float)denom;
+    float dterm = 0.f;
+    if (WANT_D && i > 0) dterm = (sign * ((float)(2 * i) * powf(theta, (float)(2 * i - 1)))) / (float)denom;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float total = __shfl(term, q * kTerms, 64), dtotal = 0.f;
+#pragma unroll
+        for (int k = 1; k < kTerms; ++k) {
+            total = total + __shfl(term, q * kTerms + k, 64);
+            if (WANT_D) dtotal += __shfl(dterm, q * kTerms + k, 64);
+        }
+        abc[q] = total;
+        dabc[q] = dtotal;
+    }
+}
+
+// pose [3][4] of one view from its se(3) parameters (w, u): a whole wave calls this, every lane ends with the same pose
 __device__ void se3_exp(const float* __restrict__ wu, float pose[12]) {
     const float w0 = wu[0], w1 = wu[1], w2 = wu[2];
     const float theta = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-    // denominators by the reference's running products (utils/camera.py:100-147): A (2i+1)!, B (2i+2)!, C (2i+3)!
-    float abc[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        double denom = s == 0 ? 1.0 : (s == 1 ? 2.0 : 6.0);
-        float total = 0.f;
-        for (int i = 0; i < kTerms; ++i) {
-            if (i > 0) denom *= s == 0 ? (double)((2 * i) * (2 * i + 1)) : (s == 1 ? (double)((2 * i + 1) * (2 * i + 2)) : (double)((2 * i + 2) * (2 * i + 3)));
-            const float sign = (i & 1) ? -1.0f : 1.0f;
-            const float term = (sign * powf(theta, (float)(2 * i))) / (float)denom;
-            total = i == 0 ? term : total + term;
-        }
-        abc[s] = total;
-    }
+    float abc[3], unused[3];
+    se3_series<false>(theta, abc, unused);
     const float A = abc[0], B = abc[1], C = abc[2];
     const float W[3][3] = {{0.f, -w2, w1}, {w2, 0.f, -w0}, {-w1, w0, 0.f}};
     float W2[3][3], R[3][3], V[3][3];
@@ -67,24 +84,13 @@ __device__ void se3_exp(const float* __restrict__ wu, float pose[12]) {
 
 // d L / d (w, u) from d L / d pose [3][4]: the chain rule through  t = V u,  R = I + A W + B W2,  V = I + B W + C W2,  W2 = W W,
 // W = skew(w),  theta = |w|  and the series' term-by-term derivatives  X'(theta) = sum_i (-1)^i 2i theta^(2i-1) / d_i  -- what
-// autograd forms from the truncated series (the i = 0 terms are constants; |w| at 0 has the zero subgradient, as in torch)
+// autograd forms from the truncated series (the i = 0 terms are constants; |w| at 0 has the zero subgradient, as in torch).
+// A whole wave calls this (se3_series); every lane computes the same d_wu, the caller lets one lane store it.
 __device__ void se3_exp_bwd(const float* __restrict__ wu, const float* __restrict__ g, float* __restrict__ d_wu) {
     const float w[3] = {wu[0], wu[1], wu[2]}, u[3] = {wu[3], wu[4], wu[5]};
     const float theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     float abc[3], dabc[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        double denom = s == 0 ? 1.0 : (s == 1 ? 2.0 : 6.0);
-        float total = 0.f, dtotal = 0.f;
-        for (int i = 0; i < kTerms; ++i) {
-            if (i > 0) denom *= s == 0 ? (double)((2 * i) * (2 * i + 1)) : (s == 1 ? (double)((2 * i + 1) * (2 * i + 2)) : (double)((2 * i + 2) * (2 * i + 3)));
-            const float sign = (i & 1) ? -1.0f : 1.0f;
-            const float term = (sign * powf(theta, (float)(2 * i))) / (float)denom;
-            total = i == 0 ? term : total + term;
-            if (i > 0) dtotal += (sign * ((float)(2 * i) * powf(theta, (float)(2 * i - 1)))) / (float)denom;
-        }
-        abc[s] = total; dabc[s] = dtotal;
-    }
+    se3_series<true>(theta, abc, dabc);
     const float A = abc[0], B = abc[1], C = abc[2];
     const float W[3][3] = {{0.f, -w[2], w[1]}, {w[2], 0.f, -w[0]}, {-w[1], w[0], 0.f}};
     float W2[3][3], V[3][3];
@@ -135,18 +141,22 @@ __device__ void se3_exp_bwd(const float* __restrict__ wu, const float* __restric
     for (int j = 0; j < 3; ++j) d_wu[3 + j] = dot3(V[0][j], gT[0], V[1][j], gT[1], V[2][j], gT[2]);
 }
 
-__global__ void se3_exp_fwd_kernel(const float* __restrict__ se3, int n, float* __restrict__ poses) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
+// one wave (= one 64-thread workgroup) per view
+__global__ void __launch_bounds__(64) se3_exp_fwd_kernel(const float* __restrict__ se3, int n, float* __restrict__ poses) {
+    const int v = blockIdx.x;
     float pose[12];
     se3_exp(se3 + 6 * v, pose);
-    for (int q = 0; q < 12; ++q) poses[12 * v + q] = pose[q];
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 12; ++q) poses[12 * v + q] = pose[q];
 }
 
-__global__ void se3_exp_bwd_kernel(const float* __restrict__ se3, const float* __restrict__ d_poses, int n, float* __restrict__ d_se3) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    se3_exp_bwd(se3 + 6 * v, d_poses + 12 * v, d_se3 + 6 * v);
+__global__ void __launch_bounds__(64)
+se3_exp_bwd_kernel(const float* __restrict__ se3, const float* __restrict__ d_poses, int n, float* __restrict__ d_se3) {
+    const int v = blockIdx.x;
+    float d[6];
+    se3_exp_bwd(se3 + 6 * v, d_poses + 12 * v, d);
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 6; ++q) d_se3[6 * v + q] = d[q];
 }
 
 // grid: (blocks over the pixels, views).  view_sel != null: ONE view, chosen on the device (blockIdx.y == 0 only), whose
@@ -158,12 +168,16 @@ camera_rays_kernel(const float* __restrict__ poses, const float* __restrict__ se
     __shared__ float s_pose[12];
     const int out_v = (int)blockIdx.y;
     const int v = view_sel ? (int)view_sel[0] : out_v;
-    if (threadIdx.x == 0) {
-        if (se3) se3_exp(se3 + 6 * v, s_pose);
+    if (threadIdx.x < 64) {                       // the first wave: the exponential is a wave-wide job (se3_series)
+        float pose[12];
+        if (se3) se3_exp(se3 + 6 * v, pose);
         else
-            for (int q = 0; q < 12; ++q) s_pose[q] = poses[12 * v + q];
-        if (poses_out && blockIdx.x == 0)
-            for (int q = 0; q < 12; ++q) poses_out[12 * out_v + q] = s_pose[q];
+            for (int q = 0; q < 12; ++q) pose[q] = poses[12 * v + q];
+        if (threadIdx.x == 0) {
+            for (int q = 0; q < 12; ++q) s_pose[q] = pose[q];
+            if (poses_out && blockIdx.x == 0)
+                for (int q = 0; q < 12; ++q) poses_out[12 * out_v + q] = pose[q];
+        }
     }
     __syncthreads();
     // camera-to-world [R^T | -(R^T t)]  (invert_pose: the product first, then the negation)
@@ -204,14 +218,14 @@ camera_rays_kernel(const float* __restrict__ poses, const float* __restrict__ se
 extern "C" int ls2fm_se3_exp_fwd(const float* se3, int32_t n, float* poses, void* stream) {
     LS2FM_CHECK_ARG(n >= 0 && (n == 0 || (se3 && poses)));
     if (n == 0) return LS2FM_OK;
-    se3_exp_fwd_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(se3, n, poses);
+    se3_exp_fwd_kernel<<<n, 64, 0, (hipStream_t)stream>>>(se3, n, poses);
     return ls2fm_launch_status();
 }
 
 extern "C" int ls2fm_se3_exp_bwd(const float* se3, const float* d_poses, int32_t n, float* d_se3, void* stream) {
     LS2FM_CHECK_ARG(n >= 0 && (n == 0 || (se3 && d_poses && d_se3)));
     if (n == 0) return LS2FM_OK;
-    se3_exp_bwd_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(se3, d_poses, n, d_se3);
+    se3_exp_bwd_kernel<<<n, 64, 0, (hipStream_t)stream>>>(se3, d_poses, n, d_se3);
     return ls2fm_launch_status();
 }
 
