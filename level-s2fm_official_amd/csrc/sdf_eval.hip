@@ -292,6 +292,139 @@ sdf_eval_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pac
     if (i < n && jl == 0) sdf_out[i] = v;
 }
 
+// ---- sdf + the 16 features + the analytic normal, 16 lanes per point: the point queries of the stage loops (SDF.gradient /
+// get_surface_pts on a few thousand key points: the thread-per-point kernel is one 80 us latency chain however few the points).
+// Lane jl of a group gathers level jl and keeps its eight corner values; hidden units jl, jl + 16, .. as in group_sdf; then ONE
+// pass over j = 0 .. 63 with unit j's h and s' w1_0 broadcast by DPP, in which the lane advances the sdf row (every lane),
+// feature row 1 + jl and r[jl], r[16 + jl], r[32 + jl] -- each the same fmaf chain over j as geometry_forward's; the normal's
+// sum over (level, corner) runs through the lanes in level order.  Every sum in the thread-per-point order: BIT-IDENTICAL outputs.
+constexpr int kW1Stride = kOut;         // 17: odd, the 16 lanes' feature weights of one unit are conflict-free
+
+template <bool WANT_R, int J>
+__device__ __forceinline__ void full_chain(const float* __restrict__ w0, const float* __restrict__ w1, float h, float g, int jl,
+                                           float& f0, float& fm, float (&r)[3]) {
+    if constexpr (J < 16) {
+        const float hv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(h), 0x150 + J, 0xF, 0xF, false));
+        const float* __restrict__ w1j = w1 + J * kW1Stride;
+        f0 = fmaf(w1j[0], hv, f0);
+        fm = fmaf(w1j[1 + jl], hv, fm);
+        if (WANT_R) {
+            const float gv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g), 0x150 + J, 0xF, 0xF, false));
+            const float* __restrict__ w0j = w0 + J * kW0Stride;
+            r[0] = fmaf(w0j[jl], gv, r[0]);
+            r[1] = fmaf(w0j[16 + jl], gv, r[1]);
+            r[2] = fmaf(w0j[32 + jl], gv, r[2]);            // k = 32 + jl: an input only for jl < 3 (the others are never read)
+        }
+        full_chain<WANT_R, J + 1>(w0, w1, h, g, jl, f0, fm, r);
+    }
+}
+
+template <bool WANT_NORMAL>
+__global__ void __launch_bounds__(256)
+sdf_eval_wide_full_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
+                          const float* __restrict__ table, const float* __restrict__ pts, int64_t n, float* __restrict__ sdf_out,
+                          float* __restrict__ feat_out, float* __restrict__ normal_out) {
+    __shared__ float s_w0[kHidden * kW0Stride + 16];          // + 16: the k = 32 + jl reads of the last row stay inside
+    __shared__ float s_w1[kHidden * kW1Stride];
+    __shared__ float s_r[16][48];                             // r[0 .. 34] of the group's point
+    for (int q = threadIdx.x; q < kHidden * kW0Stride; q += 256) s_w0[q] = pk->sdf[(q / kW0Stride) * kRecStride + q % kW0Stride];
+    for (int q = threadIdx.x; q < kHidden * kW1Stride; q += 256) s_w1[q] = pk->sdf[(q / kW1Stride) * kRecStride + kRecW1 + q % kW1Stride];
+    if (threadIdx.x < 16) s_w0[kHidden * kW0Stride + threadIdx.x] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, jl = lane & 15, gbase = lane & 48, grp = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + grp;
+    const int64_t ii = i < n ? i : n - 1;
+    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+    float x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+    // ---- this lane's level: corner values (kept for the normal) and the trilinear value
+    const bool has_level = jl < lv.n_levels;
+    float2 v[8];
+    Cell c;
+    float y0 = 0.f, y1 = 0.f, scale_l = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = make_float2(0.f, 0.f);
+    c.w[0] = c.w[1] = c.w[2] = 0.f;
+    if (has_level) {
+        scale_l = lv.scale[jl];
+        locate(x, scale_l, lv.res[jl], lv.size[jl], lv.offset[jl], lv.hashed[jl], c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float wt = corner_weight(c.w, k);
+            y0 = fmaf(wt, v[k].x, y0);
+            y1 = fmaf(wt, v[k].y, y1);
+        }
+    }
+    float u[kInMax];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = p[a] / fc.rescale;
+#pragma unroll
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+        u[3 + 2 * l] = __shfl(y0, gbase + l, 64);
+        u[4 + 2 * l] = __shfl(y1, gbase + l, 64);
+    }
+    // ---- hidden units jl + 16 q, each block followed by its 16 steps of the rows over j = 0 .. 63 (a run-time loop over q: fully
+    // unrolled, the scheduler hoists all 464 LDS weight reads to the top -- 426 registers, or a kilobyte of scratch under a cap)
+    float f0 = pk->sdf[kHidden * kRecStride], fm = pk->sdf[kHidden * kRecStride + 1 + jl], r[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const float* __restrict__ w = s_w0 + (jl + 16 * q) * kW0Stride;
+        float a0 = w[kRecB0], a1 = 0.0f;           // same two-chain order as geometry_forward
+#pragma unroll
+        for (int k = 0; k + 1 < kInMax; k += 2) {
+            a0 = fmaf(w[k], u[k], a0);
+            a1 = fmaf(w[k + 1], u[k + 1], a1);
+        }
+        a0 = fmaf(w[kInMax - 1], u[kInMax - 1], a0);
+        float h, s1, s2;
+        softplus100(a0 + a1, h, s1, s2);
+        const float g = s1 * s_w1[(jl + 16 * q) * kW1Stride];
+        full_chain<WANT_NORMAL, 0>(s_w0 + 16 * q * kW0Stride, s_w1 + 16 * q * kW1Stride, h, g, jl, f0, fm, r);
+    }
+    bool bg;
+    const float sdf = signed_sdf(fc, bg_sdf, bg_rad, f0, p, &bg);
+    const bool live = i < n;
+    if (live && jl == 0) sdf_out[i] = sdf;
+    if (live && feat_out) {
+        if (jl == 0) feat_out[i * kOut] = f0;
+        feat_out[i * kOut + 1 + jl] = fm;
+    }
+    if (WANT_NORMAL) {
+        s_r[grp][jl] = r[0];
+        s_r[grp][16 + jl] = r[1];
+        s_r[grp][32 + jl] = r[2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float rr0 = s_r[grp][3 + 2 * jl], rr1 = s_r[grp][4 + 2 * jl];
+        // this level's eight terms: m_k = (v.x rr0 + v.y rr1) scale, weights d w_k / d x_a
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaf(v[k].x, rr0, v[k].y * rr1) * scale_l;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int l = 0; l < lv.n_levels; ++l) {              // stage l: lane l's level continues the chain
+            float t[3] = {acc[0], acc[1], acc[2]};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) t[a] = fmaf(corner_dweight(c.w, k, a), m[k], t[a]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = __shfl(t[a], gbase + l, 64);
+        }
+        if (live && jl < 3) {
+            const float len = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+            const float pa = jl == 0 ? p[0] : (jl == 1 ? p[1] : p[2]);
+            const float acc_a = jl == 0 ? acc[0] : (jl == 1 ? acc[1] : acc[2]);
+            const float inv_a = jl == 0 ? fc.inv_ext[0] : (jl == 1 ? fc.inv_ext[1] : fc.inv_ext[2]);
+            const float nrm = fc.kappa * (s_r[grp][jl] / fc.rescale + acc_a * inv_a);
+            normal_out[i * 3 + jl] = bg ? -pa / len : nrm;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 sphere_trace_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Packed* __restrict__ pk,
                          const float* __restrict__ table, const float* __restrict__ ray0, const float* __restrict__ ray_dir,
@@ -514,6 +647,12 @@ extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_de
     if (!normal && !feat && n <= 65536)       // sdf only, few points: latency-bound -> 16 lanes per point (bit-identical)
         sdf_eval_wide_kernel<<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table,
                                                                       p, n, sdf);
+    else if (n <= 16384 && normal)            // sdf + features + normal of a few thousand points (the loops' point queries)
+        sdf_eval_wide_full_kernel<true><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk,
+                                                                                  params->sdf_table, p, n, sdf, feat, normal);
+    else if (n <= 16384 && feat)
+        sdf_eval_wide_full_kernel<false><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk,
+                                                                                   params->sdf_table, p, n, sdf, feat, nullptr);
     else if (normal)
         sdf_eval_kernel<true><<<blocks, 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table, p, Lattice{},
                                                      n, sdf, feat, normal);

@@ -108,3 +108,31 @@ def test_infer_sdf_small_and_large_calls_are_bit_identical():
         big = sdf.infer_sdf(p)                       # thread-per-point
         for a, b in ((0, 1), (7, 1000), (1000, 66536), (150000, 200000)):
             assert torch.equal(sdf.infer_sdf(p[a:b].contiguous()), big[a:b]), (a, b)
+
+
+@pytest.mark.parametrize("dataset,bg", [("ETH3D", False), ("DTU", True), ("scannet", False)])
+def test_point_query_forward_small_and_large_calls_are_bit_identical(dataset, bg):
+    """sdf + features + normal of up to 16 384 points take the 16-lanes-per-point kernel (the stage loops' point queries): every
+    output of a point has the same bits there and inside a larger, thread-per-point call -- also with the background sphere"""
+    from ls2fm.options import make_options
+    from ls2fm.models.SDF import SDF
+    opt = make_options(dataset, device=DEV)
+    if bg:
+        opt.data.bg_sdf = True
+    sdf = SDF(opt).to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    s = float(opt.data.bound_max[0])
+    with torch.no_grad():
+        sdf.embed_fn.embedder_obj.params.copy_(((torch.rand(sdf.embed_fn.embedder_obj.params.shape, generator=gen) * 2 - 1) * 0.1).to(DEV))
+        w = sdf.SDF_MLP.mlp[0].weight_v
+        w[:, 3:] = (torch.randn(w[:, 3:].shape, generator=gen) * 0.05).to(DEV)
+        p = ((torch.rand(40000, 3, generator=gen) * 2 - 1) * s).to(DEV)
+        p[:64] *= 1.3                                  # some points outside the box (and beyond the background sphere)
+        big = fused.sdf_eval(sdf, p, want_feat=True, want_normal=True)                 # 40 000 points: thread per point
+        big_f = fused.sdf_eval(sdf, p, want_feat=True)
+        for a, b in ((0, 1), (0, 17), (5, 5000), (23616, 40000)):
+            small = fused.sdf_eval(sdf, p[a:b].contiguous(), want_feat=True, want_normal=True)
+            for name, x, y in zip(("sdf", "feat", "normal"), small, big):
+                assert torch.equal(x, y[a:b]), (name, a, b, int((x != y[a:b]).sum()))
+            small_f = fused.sdf_eval(sdf, p[a:b].contiguous(), want_feat=True)
+            assert torch.equal(small_f[0], big_f[0][a:b]) and torch.equal(small_f[1], big_f[1][a:b]), (a, b)
