@@ -18,6 +18,8 @@
 //   scatter_fill + slab_accumulate                 table gradient, exact fixed-point sums, written in full
 //   points_dx        (only when d p is wanted) first derivatives of the encodings contracted with DE and the mixed second
 //                    partials contracted with RR and the normal's upstream (8 gathers per level again)
+#include <cstdlib>
+
 #include "bin_items.h"
 
 int ls2fm_launch_points_encode(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params,
@@ -140,6 +142,156 @@ points_bwd_kernel(FieldC fc, LevelScales lsc, int n_levels, WsLayout w, const Pa
     }
 }
 
+// ---- the same, 16 lanes per point (up to 16 384 points: the stage loops' point queries -- thread per point the 64-unit loop above
+// is a 90 us latency chain in 84 workgroups).  Lane jl of a group reads the two channels of level jl, evaluates hidden units
+// jl + 16 q, and in ONE pass over j = 0 .. 63 (unit j's DA and GJ broadcast by DPP) advances de[k], rr[k] for k = jl, 16 + jl,
+// 32 + jl: every sum in the order of the thread-per-point kernel -- BIT-IDENTICAL records and rows.
+constexpr int kPbW0 = 36;           // [j][k = 0 .. 34, b0]
+constexpr int kPbW1 = kOut;         // [j][o]
+
+template <int J>
+__device__ __forceinline__ void points_chain(const float* __restrict__ w0, float da, float gj, int jl, float (&de)[3], float (&rr)[3]) {
+    if constexpr (J < 16) {
+        const float dav = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(da), 0x150 + J, 0xF, 0xF, false));
+        const float gjv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gj), 0x150 + J, 0xF, 0xF, false));
+        const float* __restrict__ w0j = w0 + J * kPbW0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {                   // k = 32 + jl is an input only for jl < 3 (the others are never read)
+            const float wk = w0j[16 * t + jl];
+            de[t] = fmaf(wk, dav, de[t]);
+            rr[t] = fmaf(wk, gjv, rr[t]);
+        }
+        points_chain<J + 1>(w0, da, gj, jl, de, rr);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+points_bwd_wide_kernel(FieldC fc, LevelScales lsc, int n_levels, WsLayout w, const Packed* __restrict__ pk, const float* __restrict__ pts,
+                       const float* __restrict__ d_sdf, const float* __restrict__ d_feat, const float* __restrict__ d_normal,
+                       float* __restrict__ ws, int want_dx, ZeroJob zero) {
+    if ((int)blockIdx.x < zero.blocks) {
+        zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, 256);
+        return;
+    }
+    __shared__ float s_w0[kHidden * kPbW0 + 16];          // + 16: the k = 32 + jl reads of the last row stay inside
+    __shared__ float s_w1[kHidden * kPbW1];
+    __shared__ float s_o[16][96];                         // de[0 .. 47] | rr[0 .. 47] of the group's point
+    for (int q = threadIdx.x; q < kHidden * kPbW0; q += 256) s_w0[q] = pk->sdf[(q / kPbW0) * kRecStride + q % kPbW0];
+    for (int q = threadIdx.x; q < kHidden * kPbW1; q += 256) s_w1[q] = pk->sdf[(q / kPbW1) * kRecStride + kRecW1 + q % kPbW1];
+    if (threadIdx.x < 16) s_w0[kHidden * kPbW0 + threadIdx.x] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, jl = lane & 15, gbase = lane & 48, grp = threadIdx.x >> 4;
+    const int64_t i_raw = ((int64_t)blockIdx.x - zero.blocks) * 16 + grp;
+    const bool live = i_raw < w.p;
+    const int64_t i = live ? i_raw : w.p - 1;
+    const int64_t P = w.p_pad;
+    float p[3], x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        p[a] = pts[i * 3 + a];
+        x[a] = (p[a] - fc.bmin[a]) / (fc.bmax[a] - fc.bmin[a]);
+    }
+    float gf[kOut];
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) gf[o] = d_feat ? d_feat[i * kOut + o] : 0.f;
+    if (d_sdf) gf[0] = fmaf(fc.kappa, d_sdf[i], gf[0]);               // sdf = kappa f0
+    float gnk[3], gns[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        gnk[a] = d_normal ? fc.kappa * d_normal[i * 3 + a] : 0.f;
+        gns[a] = gnk[a] * fc.inv_ext[a];
+    }
+    // this lane's two channels (level jl): e and v = J . gns
+    float e_me[2] = {0.f, 0.f}, v_me[2] = {0.f, 0.f};
+    if (jl < n_levels) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int64_t c = 2 * jl + f;
+            e_me[f] = ws[w.e1 + c * P + i];
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc = fmaf(ws[w.j1 + (c * P + i) * 3 + a], gns[a], acc);         // [channel][point][3]
+            v_me[f] = acc;
+        }
+    }
+    float u[kInMax], v[kInMax];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { u[a] = p[a] / fc.rescale; v[a] = gnk[a] / fc.rescale; }
+#pragma unroll
+    for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) {
+        u[3 + 2 * l] = __shfl(e_me[0], gbase + l, 64);
+        u[4 + 2 * l] = __shfl(e_me[1], gbase + l, 64);
+        v[3 + 2 * l] = __shfl(v_me[0], gbase + l, 64);
+        v[4 + 2 * l] = __shfl(v_me[1], gbase + l, 64);
+    }
+    float de[3] = {0.f, 0.f, 0.f}, rr[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                   // (a run-time loop: see sdf_eval_wide_full_kernel)
+        const int j = jl + 16 * q;
+        const float* __restrict__ wr = s_w0 + j * kPbW0;
+        float a0 = wr[kRecB0], a1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int k = 0; k + 1 < kInMax; k += 2) {
+            a0 = fmaf(wr[k], u[k], a0);
+            a1 = fmaf(wr[k + 1], u[k + 1], a1);
+            q0 = fmaf(wr[k], v[k], q0);
+            q1 = fmaf(wr[k + 1], v[k + 1], q1);
+        }
+        a0 = fmaf(wr[kInMax - 1], u[kInMax - 1], a0);
+        q0 = fmaf(wr[kInMax - 1], v[kInMax - 1], q0);
+        float h, s1, s2;
+        softplus100(a0 + a1, h, s1, s2);
+        const float qq = q0 + q1;
+        const float* __restrict__ w1r = s_w1 + j * kPbW1;
+        float t = 0.f;
+#pragma unroll
+        for (int o = 0; o < kOut; ++o) t = fmaf(w1r[o], gf[o], t);
+        const float w10 = w1r[0];
+        const float da = fmaf(s1, t, s2 * w10 * qq);
+        const float gj = s1 * w10;
+        points_chain<0>(s_w0 + 16 * q * kPbW0, da, gj, jl, de, rr);
+    }
+    // ---- hand-over to the weight-gradient and scatter kernels of the render backward
+    if (live) {
+        if (jl < 3) {
+            const float va = jl == 0 ? v[0] : (jl == 1 ? v[1] : v[2]);
+            const float pa = jl == 0 ? p[0] : (jl == 1 ? p[1] : p[2]);
+            ws[w.v + (int64_t)jl * P + i] = va;
+            ws[w.p3 + (int64_t)jl * P + i] = pa;
+        }
+        ws[w.v + (int64_t)(3 + 2 * jl) * P + i] = v_me[0];
+        ws[w.v + (int64_t)(4 + 2 * jl) * P + i] = v_me[1];
+        {
+            float g_me = gf[0];                     // row jl of the 17 (a select chain: no run-time index into the register array)
+#pragma unroll
+            for (int o = 1; o < 16; ++o) g_me = jl == o ? gf[o] : g_me;
+            ws[w.gf + (int64_t)jl * P + i] = g_me;
+            if (jl == 0) ws[w.gf + (int64_t)16 * P + i] = gf[16];
+        }
+        if (jl == 0) {
+            float4* rpt = reinterpret_cast<float4*>(ws + w.rpt + i * 8);
+            rpt[0] = make_float4(x[0], x[1], x[2], gns[0]);
+            rpt[1] = make_float4(gns[1], gns[2], 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { s_o[grp][16 * t + jl] = de[t]; s_o[grp][48 + 16 * t + jl] = rr[t]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (live) {
+        const float g1 = fabsf(gns[0]) + fabsf(gns[1]) + fabsf(gns[2]);
+        float b = 0.f;                              // lane = level
+        if (jl < n_levels) {
+            const float d0 = s_o[grp][3 + 2 * jl], d1 = s_o[grp][4 + 2 * jl], r0 = s_o[grp][48 + 3 + 2 * jl], r1 = s_o[grp][48 + 4 + 2 * jl];
+            *reinterpret_cast<float4*>(ws + w.rec1 + ((int64_t)jl * P + i) * 4) = make_float4(d0, d1, r0, r1);
+            b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[jl] * g1 * fmaxf(fabsf(r0), fabsf(r1));
+        }
+        ws[w.smax + (int64_t)jl * w.r_pad + i] = b;            // a point is its own "ray" (n_samples = 1)
+        if (want_dx && jl < 3) ws[w.dexyz + (int64_t)jl * P + i] = s_o[grp][jl];
+    }
+}
+
 // d L / d p  =  (1 / rescale) (W0^T DA)_p  +  inv_ext . sum_l sum_f [ de_f  d e_f / d x  +  rr_f (d^2 e_f / d x d x) gns ]
 // (pose_grad.hip's per-sample expression, SDF grid only)
 __global__ void __launch_bounds__(256)
@@ -235,8 +387,14 @@ int ls2fm_points_bwd_front(const ls2fm_field_desc* field, const ls2fm_grid_desc*
     ls2fm_prof_end(LS2FM_PROF_ENCODE_SDF, s);
     if (st != LS2FM_OK) return st;
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-    points_bwd_kernel<<<(unsigned)((n + 255) / 256 + zero.blocks), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws,
-                                                                                want_dp, zero);
+    const char* force = getenv("LS2FM_POINTS_KERNEL");         // tests: 1 = thread per point, 2 = 16 lanes per point, whatever n
+    const int forced = force ? atoi(force) : 0;
+    if (forced == 2 || (forced != 1 && n <= 16384))          // latency-bound: 16 lanes per point (bit-identical)
+        points_bwd_wide_kernel<<<(unsigned)((n + 15) / 16 + zero.blocks), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws,
+                                                                                       want_dp, zero);
+    else
+        points_bwd_kernel<<<(unsigned)((n + 255) / 256 + zero.blocks), 256, 0, s>>>(fc, lsc, L, w, pk, p, d_sdf, d_feat, d_normal, ws,
+                                                                                    want_dp, zero);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
     // the per-point rows a weight-gradient kernel contracts are final here (the scans below only serve the table scatter)
     if (rows_ready && hipEventRecord(rows_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;

@@ -95,3 +95,26 @@ def test_point_queries_leave_no_grad_paths_and_shapes_alone():
     with torch.no_grad():
         n2 = sdf.gradient(pts.clone())                            # the reference enables grad inside (SDF.py:103)
     assert n2.requires_grad and rel_err(n2.detach().cpu(), n.detach().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("ds,m", [("ETH3D", 37), ("DTU", 3000), ("scannet", 16384)])
+def test_point_query_backward_kernels_are_bit_identical(ds, m, monkeypatch):
+    """up to 16 384 points the backward's per-point kernel runs 16 lanes per point (the stage loops' sizes), beyond it one
+    thread per point: forced onto the SAME points (LS2FM_POINTS_KERNEL) the two leave the same bits in every gradient -- table,
+    MLP and the points themselves"""
+    opt = make_options(ds, device=DEV)
+    sdf, rad, ren = _randomized(opt, 93)
+    s = float(opt.data.bound_max[0])
+    pts = ((torch.rand(m, 3, generator=torch.Generator().manual_seed(94)) * 2 - 1) * s * 1.02).to(DEV)
+    sdf.point_queries = "fused"
+    res = {}
+    for which in ("1", "2"):
+        monkeypatch.setenv("LS2FM_POINTS_KERNEL", which)
+        sdf.zero_grad()
+        val, p, outs = _scalar(sdf, pts)
+        val.backward()
+        res[which] = (p.grad.clone(), {k: torch.as_tensor(v).clone() for k, v in named_grads(sdf).items()})
+    assert torch.equal(res["1"][0], res["2"][0])
+    for k, v in res["1"][1].items():
+        assert torch.equal(v, res["2"][1][k]), k
+    assert res["1"][1]["embed_fn.embedder_obj.params"].abs().max() > 0
