@@ -340,6 +340,67 @@ points_dx_kernel(FieldC fc, LevelSet lv, WsLayout w, const float* __restrict__ t
     for (int a = 0; a < 3; ++a) d_p[i * 3 + a] = fmaf(acc[a], fc.inv_ext[a], ws[w.dexyz + (int64_t)a * P + i] / fc.rescale);
 }
 
+// the same with 16 lanes per point (lane = level: ONE round of gathers instead of sixteen dependent ones); the sum over the levels
+// runs through the lanes in level order -- bit-identical
+__global__ void __launch_bounds__(256)
+points_dx_wide_kernel(FieldC fc, LevelSet lv, WsLayout w, const float* __restrict__ table, const float* __restrict__ ws,
+                      float* __restrict__ d_p) {
+    const int lane = threadIdx.x & 63, jl = lane & 15, gbase = lane & 48;
+    const int64_t i_raw = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = i_raw < w.p;
+    const int64_t i = live ? i_raw : w.p - 1;
+    const int64_t P = w.p_pad;
+    const float4 pa = reinterpret_cast<const float4*>(ws + w.rpt)[2 * i];
+    const float4 pb = reinterpret_cast<const float4*>(ws + w.rpt)[2 * i + 1];
+    const float x[3] = {pa.x, pa.y, pa.z};
+    const float gns[3] = {pa.w, pb.x, pb.y};
+    float xl[3] = {0.f, 0.f, 0.f}, yl[3] = {0.f, 0.f, 0.f}, sc = 0.f;        // this level's two terms
+    if (jl < lv.n_levels) {
+        Cell c;
+        sc = lv.scale[jl];
+        locate(x, sc, lv.res[jl], lv.size[jl], lv.offset[jl], lv.hashed[jl], c);
+        float2 tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tv[k] = reinterpret_cast<const float2*>(table)[c.idx[k]];
+        const float4 rec = reinterpret_cast<const float4*>(ws + w.rec1)[(int64_t)jl * P + i];
+        const float de[2] = {rec.x, rec.y}, rr[2] = {rec.z, rec.w};
+        float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f}, h0[3] = {0.f, 0.f, 0.f}, h1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float dw = corner_dweight(c.w, k, a);
+                j0[a] = fmaf(tv[k].x, dw, j0[a]);
+                j1[a] = fmaf(tv[k].y, dw, j1[a]);
+            }
+            const float d01 = corner_d2weight(c.w, k, 0, 1), d02 = corner_d2weight(c.w, k, 0, 2), d12 = corner_d2weight(c.w, k, 1, 2);
+            h0[0] = fmaf(tv[k].x, d01, h0[0]); h0[1] = fmaf(tv[k].x, d02, h0[1]); h0[2] = fmaf(tv[k].x, d12, h0[2]);
+            h1[0] = fmaf(tv[k].y, d01, h1[0]); h1[1] = fmaf(tv[k].y, d02, h1[1]); h1[2] = fmaf(tv[k].y, d12, h1[2]);
+        }
+        const float hg0[3] = {h0[0] * gns[1] + h0[1] * gns[2], h0[0] * gns[0] + h0[2] * gns[2], h0[1] * gns[0] + h0[2] * gns[1]};
+        const float hg1[3] = {h1[0] * gns[1] + h1[1] * gns[2], h1[0] * gns[0] + h1[2] * gns[2], h1[1] * gns[0] + h1[2] * gns[1]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            xl[a] = de[0] * j0[a] + de[1] * j1[a];
+            yl[a] = rr[0] * hg0[a] + rr[1] * hg1[a];
+        }
+    }
+    const float s2 = sc * sc;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int l = 0; l < lv.n_levels; ++l) {              // stage l: lane l's level continues the chain
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t = fmaf(s2, yl[a], fmaf(sc, xl[a], acc[a]));
+            acc[a] = __shfl(t, gbase + l, 64);
+        }
+    }
+    if (live && jl < 3) {
+        const float acc_a = jl == 0 ? acc[0] : (jl == 1 ? acc[1] : acc[2]);
+        const float inv_a = jl == 0 ? fc.inv_ext[0] : (jl == 1 ? fc.inv_ext[1] : fc.inv_ext[2]);
+        d_p[i * 3 + jl] = fmaf(acc_a, inv_a, ws[w.dexyz + (int64_t)jl * P + i] / fc.rescale);
+    }
+}
+
 ls2fm_field_desc one_sample_field(const ls2fm_field_desc* field) {
     ls2fm_field_desc f = *field;
     f.n_samples = 1;
@@ -470,7 +531,12 @@ static int points_bwd_impl(const ls2fm_field_desc* field, const ls2fm_grid_desc*
     if (st != LS2FM_OK) return ls2fm_join_on_error(forked, sc, s, st);
     if (d_p) {
         ls2fm_prof_begin(LS2FM_PROF_POSE, s);
-        points_dx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(fc, make_level_set(grid), w, params->sdf_table, ws, d_p);
+        const char* force = getenv("LS2FM_POINTS_KERNEL");         // tests: 1 = thread per point, 2 = 16 lanes per point
+        const int forced = force ? atoi(force) : 0;
+        if (forced == 2 || (forced != 1 && n <= 16384))
+            points_dx_wide_kernel<<<(unsigned)((n + 15) / 16), 256, 0, s>>>(fc, make_level_set(grid), w, params->sdf_table, ws, d_p);
+        else
+            points_dx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(fc, make_level_set(grid), w, params->sdf_table, ws, d_p);
         ls2fm_prof_end(LS2FM_PROF_POSE, s);
     }
     if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
