@@ -142,7 +142,8 @@ points_bwd_kernel(FieldC fc, LevelScales lsc, int n_levels, WsLayout w, const Pa
     }
 }
 
-// ---- the same, 16 lanes per point (up to 16 384 points: the stage loops' point queries -- thread per point the 64-unit loop above
+// ---- the same, 16 lanes per point (up to 16 384 points -- alone it wins up to ~32 768 (44 against 54 us), but beside the render's
+// backward (the stage step's traced-depth node: 21 504 points) the thread-per-point form measured better, 0.870 against 0.884 ms: the stage loops' point queries -- thread per point the 64-unit loop above
 // is a 90 us latency chain in 84 workgroups).  Lane jl of a group reads the two channels of level jl, evaluates hidden units
 // jl + 16 q, and in ONE pass over j = 0 .. 63 (unit j's DA and GJ broadcast by DPP) advances de[k], rr[k] for k = jl, 16 + jl,
 // 32 + jl: every sum in the order of the thread-per-point kernel -- BIT-IDENTICAL records and rows.

@@ -292,7 +292,7 @@ sdf_eval_wide_kernel(LevelSet lv, FieldC fc, int bg_sdf, float bg_rad, const Pac
     if (i < n && jl == 0) sdf_out[i] = v;
 }
 
-// ---- sdf + the 16 features + the analytic normal, 16 lanes per point: the point queries of the stage loops (SDF.gradient /
+// ---- sdf + the 16 features + the analytic normal, 16 lanes per point (up to 32 768 points): the point queries of the stage loops (SDF.gradient /
 // get_surface_pts on a few thousand key points: the thread-per-point kernel is one 80 us latency chain however few the points).
 // Lane jl of a group gathers level jl and keeps its eight corner values; hidden units jl, jl + 16, .. as in group_sdf; then ONE
 // pass over j = 0 .. 63 with unit j's h and s' w1_0 broadcast by DPP, in which the lane advances the sdf row (every lane),
@@ -643,14 +643,17 @@ extern "C" int ls2fm_sdf_eval(const ls2fm_field_desc* field, const ls2fm_grid_de
     const FieldC fc = make_field_c(field);
     const LevelSet lv = make_level_set(grid);
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    const char* force = getenv("LS2FM_POINTS_KERNEL");           // tests: 1 = thread per point, 2 = 16 lanes per point, whatever n
+    const int forced = force ? atoi(force) : 0;
+    const bool wide_full = forced == 2 || (forced != 1 && n <= 32768);      // measured alone: 47 against 67 us at 32 768 points, 81 against 92 at 65 536
     ls2fm_prof_begin(LS2FM_PROF_SDF_EVAL, s);
     if (!normal && !feat && n <= 65536)       // sdf only, few points: latency-bound -> 16 lanes per point (bit-identical)
         sdf_eval_wide_kernel<<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk, params->sdf_table,
                                                                       p, n, sdf);
-    else if (n <= 16384 && normal)            // sdf + features + normal of a few thousand points (the loops' point queries)
+    else if (wide_full && normal)             // sdf + features + normal of up to 32 768 points (the loops' point queries)
         sdf_eval_wide_full_kernel<true><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk,
                                                                                   params->sdf_table, p, n, sdf, feat, normal);
-    else if (n <= 16384 && feat)
+    else if (wide_full && feat)
         sdf_eval_wide_full_kernel<false><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(lv, fc, field->bg_sdf, field->bg_rad, pk,
                                                                                    params->sdf_table, p, n, sdf, feat, nullptr);
     else if (normal)

@@ -99,7 +99,7 @@ def test_point_queries_leave_no_grad_paths_and_shapes_alone():
 
 @pytest.mark.parametrize("ds,m", [("ETH3D", 37), ("DTU", 3000), ("scannet", 16384)])
 def test_point_query_backward_kernels_are_bit_identical(ds, m, monkeypatch):
-    """up to 16 384 points the backward's per-point kernel runs 16 lanes per point (the stage loops' sizes), beyond it one
+    """up to 16 384 points the backward's per-point kernels run 16 lanes per point (the stage loops' sizes), beyond it one
     thread per point: forced onto the SAME points (LS2FM_POINTS_KERNEL) the two leave the same bits in every gradient -- table,
     MLP and the points themselves"""
     opt = make_options(ds, device=DEV)

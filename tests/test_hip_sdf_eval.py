@@ -111,9 +111,10 @@ def test_infer_sdf_small_and_large_calls_are_bit_identical():
 
 
 @pytest.mark.parametrize("dataset,bg", [("ETH3D", False), ("DTU", True), ("scannet", False)])
-def test_point_query_forward_small_and_large_calls_are_bit_identical(dataset, bg):
-    """sdf + features + normal of up to 16 384 points take the 16-lanes-per-point kernel (the stage loops' point queries): every
-    output of a point has the same bits there and inside a larger, thread-per-point call -- also with the background sphere"""
+def test_point_query_forward_small_and_large_calls_are_bit_identical(dataset, bg, monkeypatch):
+    """sdf + features + normal of up to 32 768 points take the 16-lanes-per-point kernel (the stage loops' point queries): every
+    output of a point has the same bits there and inside a thread-per-point call (forced: LS2FM_POINTS_KERNEL) of a larger
+    batch -- also with the background sphere"""
     from ls2fm.options import make_options
     from ls2fm.models.SDF import SDF
     opt = make_options(dataset, device=DEV)
@@ -128,8 +129,13 @@ def test_point_query_forward_small_and_large_calls_are_bit_identical(dataset, bg
         w[:, 3:] = (torch.randn(w[:, 3:].shape, generator=gen) * 0.05).to(DEV)
         p = ((torch.rand(40000, 3, generator=gen) * 2 - 1) * s).to(DEV)
         p[:64] *= 1.3                                  # some points outside the box (and beyond the background sphere)
+        monkeypatch.setenv("LS2FM_POINTS_KERNEL", "1")
         big = fused.sdf_eval(sdf, p, want_feat=True, want_normal=True)                 # 40 000 points: thread per point
         big_f = fused.sdf_eval(sdf, p, want_feat=True)
+        monkeypatch.delenv("LS2FM_POINTS_KERNEL")
+        wide = fused.sdf_eval(sdf, p, want_feat=True, want_normal=True)                # the same 40 000 points, 16 lanes each
+        for name, x, y in zip(("sdf", "feat", "normal"), wide, big):
+            assert torch.equal(x, y), (name, int((x != y).sum()))
         for a, b in ((0, 1), (0, 17), (5, 5000), (23616, 40000)):
             small = fused.sdf_eval(sdf, p[a:b].contiguous(), want_feat=True, want_normal=True)
             for name, x, y in zip(("sdf", "feat", "normal"), small, big):
