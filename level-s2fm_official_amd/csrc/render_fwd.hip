@@ -122,21 +122,31 @@ __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2
         const LayerRef L0 = layer_ref(P, which ? 2 : 0, ind, rad_in), L1 = layer_ref(P, which ? 3 : 1, ind, rad_in);
         const float* s0 = row_scale + row_base(which ? 2 : 0);
         const float* s1 = row_scale + row_base(which ? 3 : 1);
+        // the scaled layers once into LDS: the eight packing loops below then read LDS instead of making a global round trip each
+        // (for a point query's small gather launch this chain IS the launch: 25 us for 4096 points)
+        __shared__ float s_l0[kHidden * 36];          // [j][k < ind: v s0 | 35: b0]
+        __shared__ float s_l1[kOut * kHidden];        // [o][j]: v s1
+        for (int idx = tid; idx < kHidden * 36; idx += nt) {
+            const int j = idx / 36, k = idx % 36;
+            s_l0[idx] = k < ind ? L0.v[j * ind + k] * s0[j] : (k == 35 ? L0.b[j] : 0.f);
+        }
+        for (int idx = tid; idx < kOut * kHidden; idx += nt) s_l1[idx] = L1.v[idx] * s1[idx / kHidden];
+        __syncthreads();
         for (int idx = tid; idx < kHidden * kRecStride; idx += nt) {
             const int j = idx / kRecStride, k = idx % kRecStride;
             float val = 0.f;
-            if (k < ind) val = L0.v[j * ind + k] * s0[j];
-            else if (k == kRecB0) val = L0.b[j];
-            else if (k >= kRecW1 && k < kRecW1 + kOut) val = L1.v[(k - kRecW1) * kHidden + j] * s1[k - kRecW1];
+            if (k < ind) val = s_l0[j * 36 + k];
+            else if (k == kRecB0) val = s_l0[j * 36 + 35];
+            else if (k >= kRecW1 && k < kRecW1 + kOut) val = s_l1[(k - kRecW1) * kHidden + j];
             dst[idx] = val;
         }
         for (int o = tid; o < 32; o += nt) dst[kHidden * kRecStride + o] = o < kOut ? L1.b[o] : 0.f;
         if (!with_rad) continue;
         // MFMA-operand-ordered copies (shade kernels): see MfmaW
         auto w0p = [&](int j, int kp) -> float {
-            if (kp < 32) return 3 + kp < ind ? L0.v[j * ind + 3 + kp] * s0[j] : 0.f;
-            if (kp < 35) return L0.v[j * ind + (kp - 32)] * s0[j];
-            return kp == 35 ? L0.b[j] : 0.f;
+            if (kp < 32) return 3 + kp < ind ? s_l0[j * 36 + 3 + kp] : 0.f;
+            if (kp < 35) return s_l0[j * 36 + (kp - 32)];
+            return kp == 35 ? s_l0[j * 36 + 35] : 0.f;
         };
         MfmaW& mw = out->mw;
         for (int idx = tid; idx < 4 * 9 * 64; idx += nt) {
@@ -146,10 +156,10 @@ __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2
         for (int idx = tid; idx < 4 * 4 * 64; idx += nt) {
             const int m = idx / 256, r = (idx / 64) & 3, ln = idx & 63;
             const int hid = 16 * m + 4 * (ln >> 4) + r;
-            (which ? mw.geo : mw.sdf).w1a[m][r][ln] = L1.v[(1 + (ln & 15)) * kHidden + hid] * s1[1 + (ln & 15)];
+            (which ? mw.geo : mw.sdf).w1a[m][r][ln] = s_l1[(1 + (ln & 15)) * kHidden + hid];
             if (which == 1) mw.w0tx_geo[m][r][ln] = (ln & 15) < 3 ? w0p(hid, 32 + (ln & 15)) : 0.f;
             if (which == 0) {
-                mw.w10[m][r][ln] = L1.v[hid] * s1[0];
+                mw.w10[m][r][ln] = s_l1[hid];
                 for (int mk = 0; mk < 3; ++mk) {
                     const int kp = 16 * mk + (ln & 15);
                     mw.w0ta[mk][m][r][ln] = kp < 35 ? w0p(hid, kp) : 0.f;
@@ -170,10 +180,10 @@ __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2
             const int m = idx / (5 * 64), t = (idx / 64) % 5, ln = idx & 63;
             const int hid = 16 * m + (ln & 15);
             if (which) {
-                if (t < 4) out->bg.w1ta[m][t][ln] = L1.v[(1 + 4 * t + (ln >> 4)) * kHidden + hid] * s1[1 + 4 * t + (ln >> 4)];
+                if (t < 4) out->bg.w1ta[m][t][ln] = s_l1[(1 + 4 * t + (ln >> 4)) * kHidden + hid];
             } else {
                 const int o = 4 * t + (ln >> 4);
-                out->bs.w1ta[m][t][ln] = o < kOut ? L1.v[o * kHidden + hid] * s1[o] : 0.f;
+                out->bs.w1ta[m][t][ln] = o < kOut ? s_l1[o * kHidden + hid] : 0.f;
             }
         }
         for (int idx = tid; idx < 2 * 4 * 4 * 64; idx += nt) {
@@ -183,7 +193,7 @@ __device__ void prep_weights_task(const ls2fm_params& P, int in_dim, int in_dim2
             if (which) out->bg.w0ta[mk][m][r][ln] = v;
             else {
                 out->bs.w0ta[mk][m][r][ln] = v;
-                if (mk == 0) out->bs.w10[m][r][ln] = L1.v[hid] * s1[0];
+                if (mk == 0) out->bs.w10[m][r][ln] = s_l1[hid];
             }
         }
         if (tid == 0) mw.b10[which] = L1.b[0];
