@@ -407,16 +407,18 @@ class TracingConsistency:
         if torch.is_tensor(view):
             pick = lambda t: t.index_select(0, view)[0]
             if fixed is not None:
-                c, r = fixed.kp_center.index_select(0, view), fixed.kp_ray.index_select(0, view)
-                self.center.copy_(c); self.ray.copy_(r)
+                torch.index_select(fixed.kp_center, 0, view, out=self.center)
+                torch.index_select(fixed.kp_ray, 0, view, out=self.ray)
             elif self.views.kinv_host is not None and poses.shape[-1] == 4:
                 # one launch: the selected view's pose and key points -> its rays, written into the buffers the tracing reads
                 _cam.camera_rays(self.views.kinv_host, poses=poses, xy=self.views.kp_pad, view_sel=view, out=(self.center, self.ray))
             else:
                 c, r = keypoint_rays(pick(poses), self.views.intrinsic, pick(self.views.kp_pad))
                 self.center.copy_(c); self.ray.copy_(r)
-            self.target.copy_(self.views.xyzs[pick(self.views.id_pad)])
-            self.live.copy_(pick(self.views.kp_live))
+            # index_select straight INTO the persistent buffers: a `.copy_()` of a fresh result is a device-to-device memcpy node in
+            # a captured iteration -- 20 - 80 us each on this stack, against 4 us for the gather kernel writing in place
+            torch.index_select(self.views.xyzs, 0, pick(self.views.id_pad), out=self.target)
+            torch.index_select(self.views.kp_live, 0, view, out=self.live.view(1, -1))
             return
         c, r = keypoint_rays(poses[view], self.views.intrinsic, self.views.kp_pad[view])
         self.center.copy_(c); self.ray.copy_(r)
