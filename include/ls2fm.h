@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 6
+#define LS2FM_ABI_VERSION 7
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -496,6 +496,17 @@ int ls2fm_se3_exp_bwd(const float* se3, const float* d_poses, int32_t n, float* 
 int ls2fm_camera_rays(const float* poses, const float* se3, const float* kinv_host, const float* xy, const int64_t* pix,
                       int32_t width, int32_t xy_per_view, const int64_t* view_sel, int32_t n_views, int64_t n, float* centers,
                       float* rays, float* poses_out, void* stream);
+
+/* The tracing-consistency term of a stage-loop iteration -- the traced key points' surface points against their tracked 3-D
+ * points (pipelines/Camera.py:108-143 get_pts3D and the callers' loss lines, e.g. BA.py:155-161) -- as one launch each way:
+ *   surface_i = center_i + ray_i d_i ;  w_i = live_i / sum(live) ;  out[0] = sum_i |target_i - surface_i| w_i ;
+ *   out[1] = sum_i |sdf_last_i| w_i (0 when sdf_last is NULL) ;  out[2] = sum(live)            (fp64 fixed-order sums)
+ * center, ray, target [n,3], d, live, sdf_last [n] (device); out [3].  bwd: g [2] upstream of out[0], out[1] (device) ->
+ * d_d [n], d_sdf [n] (NULL with sdf_last NULL); d |e| / d d at e = 0 is 0, sign(0) = 0, as torch. */
+int ls2fm_tracing_term_fwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
+                           const float* sdf_last, int64_t n, float* out, void* stream);
+int ls2fm_tracing_term_bwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
+                           const float* sdf_last, int64_t n, const float* out, const float* g, float* d_d, float* d_sdf, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * How the table-gradient scatter (inside ls2fm_render_bwd / ls2fm_sdf_points_bwd) finishes the few coarse levels whose slabs

@@ -162,3 +162,94 @@ extern "C" int ls2fm_reproject_bwd(const float* points, const float* poses, cons
                                                                                  sums, d_reproj, d_points, d_poses);
     return ls2fm_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The tracing-consistency term of a stage-loop iteration (pipelines/Camera.py:139-143 `get_pts3D` + the callers' loss lines,
+// BA.py:155-161 / Registration): the traced key points' surface points against their tracked 3-D points,
+//      surface_i = center_i + ray_i d_i ;  w_i = live_i / sum(live) ;  tracing = sum_i |target_i - surface_i| w_i ;
+//      sdf_surf = sum_i |sdf_last_i| w_i
+// and its gradient w.r.t. the traced depths d and the last SDF values.  As torch ops (addcmul, sum, div, sub, norm, dot, abs, dot
+// and autograd's mirror) ~18 of a captured iteration's nodes, each >= 4.6 us on the device's timeline whatever its size; ONE
+// workgroup each way, fp64 fixed-order sums (deterministic).
+namespace {
+
+constexpr int kTtThreads = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int q = 0; q < kTtThreads / 64; ++q) t += red[q];
+    return t;
+}
+
+__global__ void __launch_bounds__(kTtThreads)
+tracing_term_fwd_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ d,
+                        const float* __restrict__ target, const float* __restrict__ live, const float* __restrict__ sdf_last, int64_t n,
+                        float* __restrict__ out) {
+    __shared__ double red[kTtThreads / 64];
+    const int tid = threadIdx.x;
+    double s_live = 0.0, s_tr = 0.0, s_sd = 0.0;
+    for (int64_t i = tid; i < n; i += kTtThreads) {
+        const float lv = live[i];
+        float q = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float e = target[3 * i + a] - fmaf(ray[3 * i + a], d[i], center[3 * i + a]);
+            q = fmaf(e, e, q);
+        }
+        s_live += (double)lv;
+        s_tr += (double)(sqrtf(q) * lv);
+        if (sdf_last) s_sd += (double)(fabsf(sdf_last[i]) * lv);
+    }
+    const double tl = block_sum(s_live, red, tid), tt = block_sum(s_tr, red, tid), ts = block_sum(s_sd, red, tid);
+    if (tid == 0) {
+        out[0] = (float)(tt / tl);
+        out[1] = (float)(ts / tl);
+        out[2] = (float)tl;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tracing_term_bwd_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ d,
+                        const float* __restrict__ target, const float* __restrict__ live, const float* __restrict__ sdf_last, int64_t n,
+                        const float* __restrict__ out, const float* __restrict__ g, float* __restrict__ d_d, float* __restrict__ d_sdf) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float w = live[i] / out[2];
+    float e[3], q = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        e[a] = target[3 * i + a] - fmaf(ray[3 * i + a], d[i], center[3 * i + a]);
+        q = fmaf(e[a], e[a], q);
+    }
+    const float len = sqrtf(q);
+    // d |e| / d d = -(e . ray) / |e|   (0 at e = 0, as torch's norm backward)
+    const float dot = fmaf(e[2], ray[3 * i + 2], fmaf(e[1], ray[3 * i + 1], e[0] * ray[3 * i]));
+    d_d[i] = len > 0.f ? -(g[0] * w) * dot / len : 0.f;
+    if (d_sdf) {
+        const float s = sdf_last[i];
+        d_sdf[i] = g[1] * w * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));
+    }
+}
+
+}  // namespace
+
+extern "C" int ls2fm_tracing_term_fwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
+                                      const float* sdf_last, int64_t n, float* out, void* stream) {
+    LS2FM_CHECK_ARG(n >= 1 && center && ray && d && target && live && out);
+    tracing_term_fwd_kernel<<<1, kTtThreads, 0, (hipStream_t)stream>>>(center, ray, d, target, live, sdf_last, n, out);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_tracing_term_bwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
+                                      const float* sdf_last, int64_t n, const float* out, const float* g, float* d_d, float* d_sdf,
+                                      void* stream) {
+    LS2FM_CHECK_ARG(n >= 1 && center && ray && d && target && live && out && g && d_d && ((sdf_last != nullptr) == (d_sdf != nullptr)));
+    tracing_term_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(center, ray, d, target, live, sdf_last, n, out, g,
+                                                                                        d_d, d_sdf);
+    return ls2fm_launch_status();
+}

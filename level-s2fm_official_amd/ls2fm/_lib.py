@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -148,6 +148,8 @@ _SIGNATURES = {
     "ls2fm_camera_rays": (c_int32, [_P, _P, POINTER(c_float), _P, _P, c_int32, c_int32, _P, c_int32, c_int64, _P, _P, _P, _P]),
     "ls2fm_se3_exp_fwd": (c_int32, [_P, c_int32, _P, _P]),
     "ls2fm_se3_exp_bwd": (c_int32, [_P, _P, c_int32, _P, _P]),
+    "ls2fm_tracing_term_fwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "ls2fm_tracing_term_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "ls2fm_set_scatter_mode": (c_int32, [c_int32]),
     "ls2fm_get_scatter_mode": (c_int32, []),
     "ls2fm_profile_enable": (c_int32, [c_int32]),

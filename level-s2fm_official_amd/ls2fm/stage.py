@@ -428,6 +428,16 @@ class TracingConsistency:
     def __call__(self, ret):
         early = self._early.take()
         d, sdf_last = early[:2] if early is not None else self.sdf.sphere_tracing(self.center, self.ray, self.sdf, static_trips=self.static)[:2]
+        if d.is_cuda and d.dtype == torch.float32:
+            # one node each way (ls2fm_tracing_term_fwd / _bwd): in a captured iteration every torch kernel of the lines below and
+            # of their autograd mirror is a graph node of >= 4.6 us, whatever its size
+            terms = _TracingTerm.apply(self.center, self.ray, d, self.target, self.live, sdf_last if self.use_sdfs else None)
+            ret["tracing_loss"] = terms[0]
+            loss = self.w_tracing * ret["tracing_loss"]
+            if self.use_sdfs:
+                ret["sdf_surf"] = terms[1]
+                loss = loss + self.w_surf * ret["sdf_surf"]
+            return loss
         # (few, fat torch ops: in a captured iteration every elementwise kernel here and in its backward is ~8 us of launch gap)
         surface = torch.addcmul(self.center[0], self.ray[0], d.reshape(-1, 1))
         weight = self.live / self.live.sum()                                    # no graph: 1 / count on the live key points
@@ -437,6 +447,41 @@ class TracingConsistency:
             ret["sdf_surf"] = torch.dot(sdf_last.reshape(-1).abs(), weight)
             loss = loss + self.w_surf * ret["sdf_surf"]
         return loss
+
+
+class _TracingTerm(torch.autograd.Function):
+    """the tracing-consistency sums of TracingConsistency.__call__ as one fused node (include/ls2fm.h: ls2fm_tracing_term_fwd /
+    _bwd): (tracing_loss, sdf_surf) from the traced depths d [.., n] and, optionally, the last SDF values; differentiable w.r.t.
+    both"""
+
+    @staticmethod
+    def forward(ctx, center, ray, d, target, live, sdf_last):
+        from . import _lib
+        lib = _lib.load()
+        n = live.numel()
+        c, r, t = center.detach().reshape(-1, 3).contiguous(), ray.detach().reshape(-1, 3).contiguous(), target.detach().contiguous()
+        dd, lv = d.detach().reshape(-1).contiguous(), live.detach().contiguous()
+        sl = None if sdf_last is None else sdf_last.detach().reshape(-1).contiguous()
+        out = torch.empty(3, device=d.device)
+        _lib.check(lib.ls2fm_tracing_term_fwd(_lib.ptr(c), _lib.ptr(r), _lib.ptr(dd), _lib.ptr(t), _lib.ptr(lv), _lib.ptr(sl), n,
+                                              _lib.ptr(out), _lib.stream_ptr()), "ls2fm_tracing_term_fwd")
+        ctx.save_for_backward(c, r, dd, t, lv, out, *([] if sl is None else [sl]))
+        ctx.shapes = (d.shape, None if sdf_last is None else sdf_last.shape)
+        return out[:2]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        c, r, dd, t, lv, out = ctx.saved_tensors[:6]
+        sl = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
+        g = g.contiguous()
+        d_d = torch.empty_like(dd)
+        d_s = None if sl is None else torch.empty_like(sl)
+        _lib.check(lib.ls2fm_tracing_term_bwd(_lib.ptr(c), _lib.ptr(r), _lib.ptr(dd), _lib.ptr(t), _lib.ptr(lv), _lib.ptr(sl), lv.numel(),
+                                              _lib.ptr(out), _lib.ptr(g), _lib.ptr(d_d), _lib.ptr(d_s), _lib.stream_ptr()),
+                   "ls2fm_tracing_term_bwd")
+        return None, None, d_d.view(ctx.shapes[0]), None, None, (None if d_s is None else d_s.view(ctx.shapes[1]))
 
 
 def _pick_rays(views, poses, rays_idx, se3=None, poses_out=None):

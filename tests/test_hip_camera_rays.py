@@ -110,4 +110,44 @@ def test_c_abi_argument_checks_of_the_round_4_entry_points():
     assert lib.ls2fm_set_scatter_mode(7) == -1 and lib.ls2fm_get_scatter_mode() == 1
     assert lib.ls2fm_adam_sched_decay(1, None, _lib.stream_ptr()) == -1
     assert lib.ls2fm_se3_exp_fwd(None, 2, None, _lib.stream_ptr()) == -1
+    assert lib.ls2fm_tracing_term_fwd(None, None, None, None, None, None, 4, None, _lib.stream_ptr()) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("use_sdfs", [False, True])
+def test_fused_tracing_term_matches_the_torch_lines(use_sdfs):
+    """ls2fm_tracing_term_fwd / _bwd against the torch lines they replace in TracingConsistency.__call__ (addcmul, live / sum,
+    norm, dot, abs, dot): values and the gradients w.r.t. the traced depths and the last SDF values, incl. a key point that
+    sits exactly on its target (norm backward at 0: zero) and padded (live = 0) rows"""
+    from ls2fm.stage import _TracingTerm
+    gen = torch.Generator().manual_seed(17)
+    n = 1500
+    center = torch.randn(1, n, 3, generator=gen).to(DEV)
+    ray = torch.randn(1, n, 3, generator=gen).to(DEV)
+    d0 = (torch.rand(1, n, generator=gen) * 3).to(DEV)
+    target = torch.randn(n, 3, generator=gen).to(DEV)
+    target[5] = (center[0, 5] + ray[0, 5] * d0[0, 5])
+    live = (torch.rand(n, generator=gen) > 0.2).float().to(DEV)
+    s0 = torch.randn(n, generator=gen).to(DEV)
+    s0[7] = 0.0
+    res = {}
+    for which in ("fused", "torch"):
+        d = d0.clone().requires_grad_(True)
+        sl = s0.clone().requires_grad_(True)
+        if which == "fused":
+            terms = _TracingTerm.apply(center, ray, d, target, live, sl if use_sdfs else None)
+            tl, ss = terms[0], terms[1]
+        else:
+            surface = torch.addcmul(center[0], ray[0], d.reshape(-1, 1))
+            weight = live / live.sum()
+            tl = torch.dot(torch.linalg.vector_norm(target - surface, dim=-1), weight)
+            ss = torch.dot(sl.reshape(-1).abs(), weight)
+        loss = 0.7 * tl + (0.3 * ss if use_sdfs else 0.0)
+        loss.backward()
+        res[which] = (tl.detach(), ss.detach(), d.grad.clone(), None if sl.grad is None else sl.grad.clone())
+    f, t = res["fused"], res["torch"]
+    assert abs(float(f[0]) - float(t[0])) < 2e-6 * abs(float(t[0]))
+    assert torch.allclose(f[2], t[2], rtol=2e-5, atol=1e-9) and float(f[2][0, 5]) == 0.0
+    if use_sdfs:
+        assert abs(float(f[1]) - float(t[1])) < 2e-6 * abs(float(t[1]))
+        assert torch.allclose(f[3], t[3], rtol=2e-5, atol=1e-9) and float(f[3][7]) == 0.0

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ls2fm.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared          # the python binding covers the whole header
-    assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == 7
     assert lib.ls2fm_status_string(-2) == b"unsupported configuration"
 
 
