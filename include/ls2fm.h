@@ -508,6 +508,13 @@ int ls2fm_tracing_term_fwd(const float* center, const float* ray, const float* d
 int ls2fm_tracing_term_bwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
                            const float* sdf_last, int64_t n, const float* out, const float* g, float* d_d, float* d_sdf, void* stream);
 
+/* SDF.get_surface_pts' projection line (models/SDF.py:104-110):  out = p - normals / |normals|.detach() * sdf ,  length = |normals|
+ * (p, normals, out [n,3]; sdf, length [n]) and its gradient w.r.t. normals and sdf (d p = g_out, the caller's); g_out / g_length
+ * may be NULL (no upstream for that output).  One launch each way instead of ~14 elementwise kernels. */
+int ls2fm_surface_pts_fwd(const float* p, const float* normals, const float* sdf, int64_t n, float* out, float* length, void* stream);
+int ls2fm_surface_pts_bwd(const float* normals, const float* sdf, const float* length, int64_t n, const float* g_out,
+                          const float* g_length, float* d_normals, float* d_sdf, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * How the table-gradient scatter (inside ls2fm_render_bwd / ls2fm_sdf_points_bwd) finishes the few coarse levels whose slabs
  * are split over several workgroups.  Process-wide; takes effect for the calls enqueued afterwards.

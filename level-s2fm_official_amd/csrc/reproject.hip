@@ -253,3 +253,62 @@ extern "C" int ls2fm_tracing_term_bwd(const float* center, const float* ray, con
                                                                                         d_d, d_sdf);
     return ls2fm_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SDF.get_surface_pts' last line (models/SDF.py:104-110 of the reference):  out = p - n / |n|.detach() * sdf ,  length = |n|
+// -- four elementwise torch kernels and ~10 of autograd's, one launch each way.  The norm is DETACHED inside the quotient: the
+// gradient reaches n through the product only, and through `length`.
+namespace {
+
+__global__ void __launch_bounds__(256)
+surface_pts_fwd_kernel(const float* __restrict__ p, const float* __restrict__ nrm, const float* __restrict__ sdf, int64_t n,
+                       float* __restrict__ out, float* __restrict__ length) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = nrm[3 * i], b = nrm[3 * i + 1], c = nrm[3 * i + 2];
+    const float len = sqrtf(a * a + b * b + c * c);
+    const float s = sdf[i];
+    out[3 * i] = p[3 * i] - a / len * s;
+    out[3 * i + 1] = p[3 * i + 1] - b / len * s;
+    out[3 * i + 2] = p[3 * i + 2] - c / len * s;
+    length[i] = len;
+}
+
+__global__ void __launch_bounds__(256)
+surface_pts_bwd_kernel(const float* __restrict__ nrm, const float* __restrict__ sdf, const float* __restrict__ length, int64_t n,
+                       const float* __restrict__ g_out, const float* __restrict__ g_len, float* __restrict__ d_n, float* __restrict__ d_sdf) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float len = length[i], s = sdf[i], gl = g_len ? g_len[i] : 0.f;
+    float ds = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float na = nrm[3 * i + a], go = g_out ? g_out[3 * i + a] : 0.f;
+        const float u = na / len;
+        ds = fmaf(-go, u, ds);
+        // out_a = p_a - n_a / len_detached * sdf ;  length = |n| (d |n| / d n = n / |n|; 0 at n = 0 as torch's norm backward)
+        d_n[3 * i + a] = -go * s / len + (len > 0.f ? gl * u : 0.f);
+    }
+    d_sdf[i] = ds;
+}
+
+}  // namespace
+
+extern "C" int ls2fm_surface_pts_fwd(const float* p, const float* normals, const float* sdf, int64_t n, float* out, float* length,
+                                     void* stream) {
+    LS2FM_CHECK_ARG(n >= 0);
+    if (n == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(p && normals && sdf && out && length);
+    surface_pts_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, normals, sdf, n, out, length);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_surface_pts_bwd(const float* normals, const float* sdf, const float* length, int64_t n, const float* g_out,
+                                     const float* g_length, float* d_normals, float* d_sdf, void* stream) {
+    LS2FM_CHECK_ARG(n >= 0);
+    if (n == 0) return LS2FM_OK;
+    LS2FM_CHECK_ARG(normals && sdf && length && d_normals && d_sdf);
+    surface_pts_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(normals, sdf, length, n, g_out, g_length,
+                                                                                       d_normals, d_sdf);
+    return ls2fm_launch_status();
+}

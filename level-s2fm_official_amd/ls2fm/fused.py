@@ -674,7 +674,7 @@ class _SdfPoints(torch.autograd.Function):
                                  ptr(normal), ptr(ws), stream_ptr()), "ls2fm_sdf_eval")
         ctx.meta = (fdesc, gdesc, float(sdf_field.beta_speed), n, tuple(xyz.shape))
         ctx.save_for_backward(p, *params)
-        z = p.new_zeros(())
+        z = p.new_empty(())                        # placeholder of an output nobody asked for (never read): no fill kernel
         return (sdf.view(*shape, 1), feat.view(*shape, -1) if want_feat else z, normal.view(*shape, 3) if want_normal else z)
 
     @staticmethod
@@ -706,6 +706,44 @@ class _SdfPoints(torch.autograd.Function):
         else:
             grads[7] = None                            # beta does not enter a point query: no gradient (not a zero tensor)
         return (None if d_p is None else d_p.view(xyz_shape), None, None, None, *grads)
+
+
+class _SurfacePts(torch.autograd.Function):
+    """SDF.get_surface_pts' projection line as one node each way (ls2fm_surface_pts_fwd / _bwd):
+    out = p - n / |n|.detach() * sdf,  length = |n|"""
+
+    @staticmethod
+    def forward(ctx, pts, normals, sdf):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        p = pts.detach().reshape(-1, 3).float().contiguous()
+        nr = normals.detach().reshape(-1, 3).float().contiguous()
+        sd = sdf.detach().reshape(-1).float().contiguous()
+        n = p.shape[0]
+        out, length = torch.empty_like(p), torch.empty(n, device=p.device)
+        check(lib.ls2fm_surface_pts_fwd(ptr(p), ptr(nr), ptr(sd), n, ptr(out), ptr(length), stream_ptr()), "ls2fm_surface_pts_fwd")
+        ctx.save_for_backward(nr, sd, length)
+        ctx.shapes = (tuple(pts.shape), tuple(normals.shape), tuple(sdf.shape))
+        return out.view(pts.shape), length.view(*pts.shape[:-1], 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out, g_len):
+        lib = _lib.load()
+        nr, sd, length = ctx.saved_tensors
+        if g_out is None and g_len is None:
+            return None, None, None
+        go = None if g_out is None else g_out.reshape(-1, 3).float().contiguous()
+        gl = None if g_len is None else g_len.reshape(-1).float().contiguous()
+        d_n, d_s = torch.empty_like(nr), torch.empty_like(sd)
+        check(lib.ls2fm_surface_pts_bwd(ptr(nr), ptr(sd), ptr(length), nr.shape[0], ptr(go), ptr(gl), ptr(d_n), ptr(d_s), stream_ptr()),
+              "ls2fm_surface_pts_bwd")
+        return (None if go is None else go.view(ctx.shapes[0])), d_n.view(ctx.shapes[1]), d_s.view(ctx.shapes[2])
+
+
+def surface_points(pts, normals, sdf):
+    """(pts - normals / |normals|.detach() * sdf, |normals|) with a graph, one launch each way"""
+    return _SurfacePts.apply(pts, normals, sdf)
 
 
 def query_points(sdf_field, xyz, want_feat=False, want_normal=False):

@@ -923,7 +923,10 @@ class BALoop:
             reproj, _ = reprojection_term(xyzs_new, poses, self.view_start, self._k_host, self.obs_uv, sdfs, 2 * self.sdf_threshold)
         else:
             reproj = self._reproj_torch(xyzs_new, poses, sdfs)
-        w_reproj = torch.where(reproj.detach() > 10, 10.0, 1.0) * (1.0 if self.w_reproj_lo else 0.0)       # BA.py:163-166
+        if getattr(self, "_w_hi", None) is None or self._w_hi.device != reproj.device:       # constants once, not two fill kernels per iteration
+            on = 1.0 if self.w_reproj_lo else 0.0
+            self._w_hi, self._w_lo = torch.full((), 10.0 * on, device=reproj.device), torch.full((), on, device=reproj.device)
+        w_reproj = torch.where(reproj.detach() > 10, self._w_hi, self._w_lo)                  # BA.py:163-166
         ret["reproj_error"], ret["w_reproj"] = reproj, w_reproj
         ret["sdf_surf"] = sdfs.abs().mean()
         self._new_points = xyzs_new.detach()
