@@ -515,6 +515,19 @@ int ls2fm_surface_pts_fwd(const float* p, const float* normals, const float* sdf
 int ls2fm_surface_pts_bwd(const float* normals, const float* sdf, const float* length, int64_t n, const float* g_out,
                           const float* g_length, float* d_normals, float* d_sdf, void* stream);
 
+/* The explicit-match terms of the two-view initialisation (pipelines/Initialization.py:154-160, 252-255; Camera.py:136, 168-178):
+ * n_seg <= 4 segments of n traced key points each (segment = source view); pts = center + ray d is projected through
+ * poses[seg] (the OTHER view's world-to-camera [3,4], device, no gradient) and K and compared with uv_obs:
+ *   out[0] = mean || uv(pts) - uv_obs ||   out[1] = mean |sdf_last|   over all n_seg * n points;  surface [n_seg * n, 3] = pts.
+ * center, ray [n_seg * n, 3], uv_obs [n_seg * n, 2] (device); d, sdf_last, d_d, d_sdf: HOST arrays of n_seg DEVICE pointers ([n] each);
+ * g [2] (device): upstream of out[0], out[1].  One launch each way instead of ~70 torch kernels. */
+int ls2fm_match_term_fwd(const float* center, const float* ray, const float* uv_obs, const float* poses, const float* intrinsic_host,
+                         int32_t n_seg, int64_t n, const float* const* d, const float* const* sdf_last, float* surface, float* out,
+                         void* stream);
+int ls2fm_match_term_bwd(const float* center, const float* ray, const float* uv_obs, const float* poses, const float* intrinsic_host,
+                         int32_t n_seg, int64_t n, const float* const* d, const float* const* sdf_last, const float* g,
+                         float* const* d_d, float* const* d_sdf, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * How the table-gradient scatter (inside ls2fm_render_bwd / ls2fm_sdf_points_bwd) finishes the few coarse levels whose slabs
  * are split over several workgroups.  Process-wide; takes effect for the calls enqueued afterwards.

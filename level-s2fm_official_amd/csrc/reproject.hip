@@ -312,3 +312,129 @@ extern "C" int ls2fm_surface_pts_bwd(const float* normals, const float* sdf, con
                                                                                        d_normals, d_sdf);
     return ls2fm_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The explicit-match terms of the two-view initialisation (pipelines/Initialization.py:154-160, 252-255 on Camera.py:136,
+// 168-178): the key points of view v are traced onto the surface (d, sdf_last from SDF.sphere_tracing), the surface points
+//      pts = center + ray d
+// are projected into the OTHER view (fixed poses) and compared with the matched key points there,
+//      reproj_error = mean || uv(pts) - key point || ,   sdf_surf = mean |sdf_last|      over the segments' points together.
+// As torch ops (two batched matrix products, divisions, norm, concatenations, means per view, and autograd's mirror) ~70 of a
+// captured iteration's graph nodes; ONE workgroup each way, fp64 fixed-order sums.  Up to kMtSeg segments (views) of n points.
+namespace {
+
+constexpr int kMtSeg = 4;
+struct MatchSegs { const float* d[kMtSeg]; const float* s[kMtSeg]; float* dd[kMtSeg]; float* ds[kMtSeg]; };
+
+struct MatchPt { float p[3], u[3], e[2], err, inv; };
+
+__device__ __forceinline__ MatchPt match_project(const float* __restrict__ center, const float* __restrict__ ray, float d,
+                                                 const float* __restrict__ pose, const Camera3& K, const float* __restrict__ uv_obs,
+                                                 int64_t i) {
+    MatchPt o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.p[a] = fmaf(ray[3 * i + a], d, center[3 * i + a]);
+    float xc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        xc[a] = fmaf(pose[4 * a + 2], o.p[2], fmaf(pose[4 * a + 1], o.p[1], pose[4 * a] * o.p[0])) + pose[4 * a + 3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.u[a] = fmaf(K.k[3 * a + 2], xc[2], fmaf(K.k[3 * a + 1], xc[1], K.k[3 * a] * xc[0]));
+    o.inv = 1.0f / (o.u[2] + 1e-6f);
+    o.e[0] = o.u[0] * o.inv - uv_obs[2 * i];
+    o.e[1] = o.u[1] * o.inv - uv_obs[2 * i + 1];
+    o.err = sqrtf(fmaf(o.e[1], o.e[1], o.e[0] * o.e[0]));
+    return o;
+}
+
+__global__ void __launch_bounds__(kTtThreads)
+match_term_fwd_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ uv_obs,
+                      const float* __restrict__ poses, Camera3 K, int n_seg, int64_t n, MatchSegs sg, float* __restrict__ surface,
+                      float* __restrict__ out) {
+    __shared__ double red[kTtThreads / 64];
+    __shared__ float s_pose[kMtSeg][12];
+    const int tid = threadIdx.x;
+    if (tid < 12 * n_seg) s_pose[tid / 12][tid % 12] = poses[tid];
+    __syncthreads();
+    double s_err = 0.0, s_sdf = 0.0;
+    for (int seg = 0; seg < n_seg; ++seg)
+        for (int64_t j = tid; j < n; j += kTtThreads) {
+            const int64_t i = (int64_t)seg * n + j;
+            const MatchPt o = match_project(center, ray, sg.d[seg][j], s_pose[seg], K, uv_obs, i);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) surface[3 * i + a] = o.p[a];
+            s_err += (double)o.err;
+            s_sdf += (double)fabsf(sg.s[seg][j]);
+        }
+    const double te = block_sum(s_err, red, tid), ts = block_sum(s_sdf, red, tid);
+    if (tid == 0) {
+        const double cnt = (double)n_seg * (double)n;
+        out[0] = (float)(te / cnt);
+        out[1] = (float)(ts / cnt);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+match_term_bwd_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ uv_obs,
+                      const float* __restrict__ poses, Camera3 K, int n_seg, int64_t n, MatchSegs sg, const float* __restrict__ g) {
+    const int seg = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int64_t i = (int64_t)seg * n + j;
+    const float* __restrict__ pose = poses + 12 * seg;
+    const float inv_cnt = 1.0f / ((float)n_seg * (float)n);
+    const MatchPt o = match_project(center, ray, sg.d[seg][j], pose, K, uv_obs, i);
+    float dd = 0.f;
+    if (o.err > 0.f) {                                   // norm backward at 0: zero (torch)
+        const float ge = g[0] * inv_cnt;
+        const float de0 = ge * o.e[0] / o.err, de1 = ge * o.e[1] / o.err;
+        const float du[3] = {de0 * o.inv, de1 * o.inv, -(de0 * o.u[0] + de1 * o.u[1]) * o.inv * o.inv};
+        float dxc[3], dp[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dxc[b] = fmaf(K.k[6 + b], du[2], fmaf(K.k[3 + b], du[1], K.k[b] * du[0]));        // K^T du
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dp[b] = fmaf(pose[8 + b], dxc[2], fmaf(pose[4 + b], dxc[1], pose[b] * dxc[0]));    // R^T
+        dd = fmaf(dp[2], ray[3 * i + 2], fmaf(dp[1], ray[3 * i + 1], dp[0] * ray[3 * i]));
+    }
+    sg.dd[seg][j] = dd;
+    const float s = sg.s[seg][j];
+    sg.ds[seg][j] = g[1] * inv_cnt * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));
+}
+
+bool load_segs(int32_t n_seg, const float* const* d, const float* const* s, float* const* dd, float* const* ds, MatchSegs* out) {
+    if (n_seg < 1 || n_seg > kMtSeg || !d || !s) return false;
+    for (int q = 0; q < kMtSeg; ++q) {
+        out->d[q] = q < n_seg ? d[q] : nullptr;
+        out->s[q] = q < n_seg ? s[q] : nullptr;
+        out->dd[q] = (q < n_seg && dd) ? dd[q] : nullptr;
+        out->ds[q] = (q < n_seg && ds) ? ds[q] : nullptr;
+        if (q < n_seg && (!out->d[q] || !out->s[q] || (dd && !out->dd[q]) || (ds && !out->ds[q]))) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int ls2fm_match_term_fwd(const float* center, const float* ray, const float* uv_obs, const float* poses,
+                                    const float* intrinsic_host, int32_t n_seg, int64_t n, const float* const* d,
+                                    const float* const* sdf_last, float* surface, float* out, void* stream) {
+    Camera3 K;
+    MatchSegs sg;
+    LS2FM_CHECK_ARG(n >= 1 && center && ray && uv_obs && poses && surface && out && load_intrinsic(intrinsic_host, &K));
+    LS2FM_CHECK_ARG(load_segs(n_seg, d, sdf_last, nullptr, nullptr, &sg));
+    match_term_fwd_kernel<<<1, kTtThreads, 0, (hipStream_t)stream>>>(center, ray, uv_obs, poses, K, n_seg, n, sg, surface, out);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_match_term_bwd(const float* center, const float* ray, const float* uv_obs, const float* poses,
+                                    const float* intrinsic_host, int32_t n_seg, int64_t n, const float* const* d,
+                                    const float* const* sdf_last, const float* g, float* const* d_d, float* const* d_sdf,
+                                    void* stream) {
+    Camera3 K;
+    MatchSegs sg;
+    LS2FM_CHECK_ARG(n >= 1 && center && ray && uv_obs && poses && g && d_d && d_sdf && load_intrinsic(intrinsic_host, &K));
+    LS2FM_CHECK_ARG(load_segs(n_seg, d, sdf_last, d_d, d_sdf, &sg));
+    match_term_bwd_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n_seg), 256, 0, (hipStream_t)stream>>>(center, ray, uv_obs, poses, K,
+                                                                                                            n_seg, n, sg, g);
+    return ls2fm_launch_status();
+}

@@ -152,6 +152,8 @@ _SIGNATURES = {
     "ls2fm_tracing_term_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "ls2fm_surface_pts_fwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
     "ls2fm_surface_pts_bwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "ls2fm_match_term_fwd": (c_int32, [_P, _P, _P, _P, POINTER(c_float), c_int32, c_int64, _P, _P, _P, _P, _P]),
+    "ls2fm_match_term_bwd": (c_int32, [_P, _P, _P, _P, POINTER(c_float), c_int32, c_int64, _P, _P, _P, _P, _P, _P]),
     "ls2fm_set_scatter_mode": (c_int32, [c_int32]),
     "ls2fm_get_scatter_mode": (c_int32, []),
     "ls2fm_profile_enable": (c_int32, [c_int32]),

@@ -484,6 +484,47 @@ class _TracingTerm(torch.autograd.Function):
         return None, None, d_d.view(ctx.shapes[0]), None, None, (None if d_s is None else d_s.view(ctx.shapes[1]))
 
 
+class _MatchTerm(torch.autograd.Function):
+    """the explicit-match terms of the two-view initialisation as one fused node (include/ls2fm.h: ls2fm_match_term_fwd / _bwd):
+    (reproj_error, sdf_surf) from the traced depths and last SDF values of each source view; `surface` receives the traced points"""
+
+    @staticmethod
+    def forward(ctx, fixed, surface, *ds):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        center, ray, uv_obs, poses, k_host, n = fixed
+        S = len(ds) // 2
+        d = [t.detach().reshape(-1).float().contiguous() for t in ds[:S]]
+        sl = [t.detach().reshape(-1).float().contiguous() for t in ds[S:]]
+        arr = lambda ts: (ctypes.c_void_p * S)(*[t.data_ptr() for t in ts])          # noqa: E731
+        out = torch.empty(2, device=center.device)
+        _lib.check(lib.ls2fm_match_term_fwd(_lib.ptr(center), _lib.ptr(ray), _lib.ptr(uv_obs), _lib.ptr(poses), k_host, S, n, arr(d), arr(sl),
+                                            _lib.ptr(surface), _lib.ptr(out), _lib.stream_ptr()), "ls2fm_match_term_fwd")
+        ctx.fixed, ctx.S = fixed, S
+        ctx.shapes = [t.shape for t in ds]
+        ctx.save_for_backward(*d, *sl)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        center, ray, uv_obs, poses, k_host, n = ctx.fixed
+        S = ctx.S
+        saved = ctx.saved_tensors
+        d, sl = list(saved[:S]), list(saved[S:])
+        dd, dsl = [torch.empty_like(t) for t in d], [torch.empty_like(t) for t in sl]
+        arr = lambda ts: (ctypes.c_void_p * S)(*[t.data_ptr() for t in ts])          # noqa: E731
+        g = g.contiguous()
+        _lib.check(lib.ls2fm_match_term_bwd(_lib.ptr(center), _lib.ptr(ray), _lib.ptr(uv_obs), _lib.ptr(poses), k_host, S, n, arr(d), arr(sl),
+                                            _lib.ptr(g), arr(dd), arr(dsl), _lib.stream_ptr()), "ls2fm_match_term_bwd")
+        grads = [t.view(sh) for t, sh in zip(dd + dsl, ctx.shapes)]
+        return (None, None, *grads)
+
+
 def _pick_rays(views, poses, rays_idx, se3=None, poses_out=None):
     """CameraSet.render's ray pick for given poses (Camera.py:457-463): the same pixels in every view.  se3 [V,6]: the poses are
     the exponentials of these parameters, formed in the same launch (and left in poses_out)"""
@@ -600,6 +641,17 @@ class InitLoop:
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "reproj_error")
         self._surface = self._finish = None
         self._early = [_EarlyTrace(sdf_field, slot=1), _EarlyTrace(sdf_field, slot=2)]
+        self._match = None
+        if self.poses.is_cuda and self.poses.dtype == torch.float32:
+            # the fixed operands of the fused match node: segment v = the key points of view v, seen through the OTHER view
+            with torch.no_grad():
+                n = views.keypoints[0].shape[0]
+                cen = torch.cat([self._kp_rays[v][0].reshape(-1, 3) for v in range(2)]).float().contiguous()
+                ray = torch.cat([self._kp_rays[v][1].reshape(-1, 3) for v in range(2)]).float().contiguous()
+                uv = torch.cat([views.keypoints[1 - v].reshape(-1, 2) for v in range(2)]).float().contiguous()
+                pose_o = torch.stack([self.poses[1 - v] for v in range(2)]).float().contiguous()
+            self._match = (cen, ray, uv, pose_o, host_intrinsic(views.intrinsic), n)
+            self._surface_buf = torch.zeros(2, n, 3, device=self.poses.device)
 
     def _prepare(self):
         if self.static:
@@ -608,6 +660,18 @@ class InitLoop:
 
     def _extra(self, ret):
         """the explicit-match terms (Initialization.py:154-160, 252-255), already weighted"""
+        if self._match is not None:
+            # one node each way for the whole block below (ls2fm_match_term_fwd / _bwd): ~70 graph nodes of a captured iteration
+            ds, sls, fins = [], [], []
+            for v in range(2):
+                center, ray = self._kp_rays[v]
+                early = self._early[v].take()
+                d, sdf_last, _, fin = early if early is not None else self.sdf.sphere_tracing(center, ray, self.sdf, static_trips=self.static)
+                ds.append(d); sls.append(sdf_last); fins.append(fin.reshape(-1).bool())
+            terms = _MatchTerm.apply(self._match, self._surface_buf.view(-1, 3), *ds, *sls)
+            ret["reproj_error"], ret["sdf_surf"] = terms[0], terms[1]
+            self._surface, self._finish = self._surface_buf, torch.stack(fins)
+            return self.w_reproj * ret["reproj_error"] + self.w_surf * ret["sdf_surf"]
         errs, sdfs, surface, finish = [], [], [], []
         for v in range(2):
             center, ray = self._kp_rays[v]

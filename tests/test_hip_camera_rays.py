@@ -151,3 +151,46 @@ def test_fused_tracing_term_matches_the_torch_lines(use_sdfs):
     if use_sdfs:
         assert abs(float(f[1]) - float(t[1])) < 2e-6 * abs(float(t[1]))
         assert torch.allclose(f[3], t[3], rtol=2e-5, atol=1e-9) and float(f[3][7]) == 0.0
+
+
+def test_fused_match_term_matches_the_torch_lines():
+    """ls2fm_match_term_fwd / _bwd against the torch lines of InitLoop._extra they replace (Camera.py:136, 168-178 +
+    Initialization.py:154-160): surface points, cross-view projection, pixel error and |sdf| means over both views, and the
+    gradients w.r.t. the traced depths and the last SDF values"""
+    from ls2fm.stage import _MatchTerm, host_intrinsic
+    se3, intr, H, W, g = _setup()
+    poses = cam.lie.se3_to_SE3(se3[:2]).contiguous()
+    gen = torch.Generator().manual_seed(23)
+    n = 700
+    cen = [torch.randn(1, n, 3, generator=gen).to(DEV) * 0.2 for _ in range(2)]
+    ray = [torch.nn.functional.normalize(torch.randn(1, n, 3, generator=gen), dim=-1).to(DEV) for _ in range(2)]
+    kps = [(torch.rand(n, 2, generator=gen) * torch.tensor([W, H])).to(DEV) for _ in range(2)]
+    d0 = [(torch.rand(1, n, generator=gen) * 2 + 1).to(DEV) for _ in range(2)]
+    s0 = [torch.randn(n, generator=gen).to(DEV) * 0.01 for _ in range(2)]
+    fixed = (torch.cat([c.reshape(-1, 3) for c in cen]).contiguous(), torch.cat([r.reshape(-1, 3) for r in ray]).contiguous(),
+             torch.cat([kps[1], kps[0]]).contiguous(), torch.stack([poses[1], poses[0]]).contiguous(), host_intrinsic(intr), n)
+    surf = torch.zeros(2, n, 3, device=DEV)
+    res = {}
+    for which in ("fused", "torch"):
+        d = [t.clone().requires_grad_(True) for t in d0]
+        sl = [t.clone().requires_grad_(True) for t in s0]
+        if which == "fused":
+            terms = _MatchTerm.apply(fixed, surf.view(-1, 3), *d, *sl)
+            re, ss = terms[0], terms[1]
+        else:
+            errs, sdfs, pts_all = [], [], []
+            for v in range(2):
+                pts = cen[v] + ray[v] * d[v].reshape(1, -1, 1)
+                o = 1 - v
+                uv = cam.cam2img(cam.world2cam(pts, poses[o:o + 1]), intr.unsqueeze(0))
+                uv = (uv / (uv[..., 2:] + 1e-6))[..., :2]
+                errs.append((uv[0] - kps[o]).norm(dim=-1)); sdfs.append(sl[v].reshape(-1)); pts_all.append(pts[0].detach())
+            re, ss = torch.cat(errs).mean(), torch.cat(sdfs).abs().mean()
+            ref_surf = torch.stack(pts_all)
+        (0.3 * re + 2.0 * ss).backward()
+        res[which] = (re.detach(), ss.detach(), [t.grad.clone() for t in d], [t.grad.clone() for t in sl])
+    f, t = res["fused"], res["torch"]
+    assert abs(float(f[0]) - float(t[0])) < 1e-5 * abs(float(t[0])) and abs(float(f[1]) - float(t[1])) < 1e-5 * abs(float(t[1]))
+    assert torch.allclose(surf, ref_surf, rtol=1e-6, atol=1e-6)
+    for a, b in zip(f[2] + f[3], t[2] + t[3]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-8), float((a - b).abs().max())
