@@ -104,6 +104,13 @@ class SDF(nn.Module):
         return g
 
     def get_surface_pts(self, pts):
+        if (self.point_queries == "fused" and torch.is_grad_enabled() and not pts.requires_grad and pts.is_cuda
+                and fused.can_query_points(self, pts) and not fused.can_eval_without_graph(self, pts)):
+            # the points carry no graph (BA's tracked points): the value and the normal come from ONE query node -- one forward,
+            # one backward pipeline instead of two over the same points (the sum of the two nodes' parameter gradients)
+            sdf, _, normals = fused.query_points(self, pts, want_normal=True)
+            pts.requires_grad_(True)                    # gradient() marks its argument (SDF.py:104, SURVEY C-9): same side effect
+            return fused.surface_points(pts, normals, sdf)
         sdf = self.infer_sdf(pts.detach(), mode="ret_sdf")
         normals = self.gradient(pts)
         wants_graph = pts.requires_grad or normals.requires_grad or sdf.requires_grad

@@ -118,3 +118,27 @@ def test_point_query_backward_kernels_are_bit_identical(ds, m, monkeypatch):
     for k, v in res["1"][1].items():
         assert torch.equal(v, res["2"][1][k]), k
     assert res["1"][1]["embed_fn.embedder_obj.params"].abs().max() > 0
+
+
+def test_surface_points_of_graphless_points_take_one_query_node():
+    """get_surface_pts on points WITHOUT a graph (BA's tracked points) evaluates value and normal in one query node: same
+    outputs, and parameter gradients equal to the sum the two separate nodes (points with a graph) leave"""
+    opt = make_options("ETH3D", device=DEV)
+    sdf, rad, ren = _randomized(opt, 95)
+    s = float(opt.data.bound_max[0])
+    pts = ((torch.rand(2500, 3, generator=torch.Generator().manual_seed(96)) * 2 - 1) * s).to(DEV)
+    sdf.point_queries = "fused"
+    res = {}
+    for which in ("one", "two"):
+        sdf.zero_grad()
+        p = pts.clone()
+        if which == "two":
+            p.requires_grad_(True)                       # the separate-node path
+        surf, nlen = sdf.get_surface_pts(p)
+        assert p.requires_grad                           # the reference's side effect (SDF.py:104) either way
+        again = sdf.infer_sdf(surf, mode="ret_sdf")
+        ((surf ** 2).mean() + 0.1 * nlen.mean() + again.abs().mean()).backward()
+        res[which] = (surf.detach(), nlen.detach(), named_grads(sdf))
+    assert rel_err(res["one"][0].cpu(), res["two"][0].cpu()) < 1e-6 and rel_err(res["one"][1].cpu(), res["two"][1].cpu()) < 1e-6
+    for k, v in res["one"][2].items():
+        assert rel_err(v, res["two"][2][k]) < 2e-5, k
