@@ -118,8 +118,13 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
                          loss->d_terms, loss->d_total, loss->d_depth_ref, loss->flags};
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
     // (leading workgroups of this launch zero the weight-gradient accumulators and the atomically flushed table ranges)
+    // the MLPs' weight gradients are contracted inside shade_bwd (LS2FM_FUSED_WGRAD=0: round 4's separate wgrad_mlp launches,
+    // for A/B measurements)
+    // (one-sample rays share the workspace layout of free points, which has no per-ray partials: wgrad_mlp.hip serves them)
+    static const int fused_env = [] { const char* e = getenv("LS2FM_FUSED_WGRAD"); return e ? atoi(e) : 1; }();
+    const int fused_wgrad = fused_env && field->n_samples > 1;
     ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,
-                           dual ? grads->rad_table : nullptr, s);
+                           dual ? grads->rad_table : nullptr, s, fused_wgrad);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
     if (opts && opts->depth_grad_ready && hipEventRecord((hipEvent_t)opts->depth_grad_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
     // the tracing's own backward (ls2fm_depth_backward): a second internal branch, forked here -- d_depth_ref is final.  Its
@@ -168,7 +173,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
     Ls2fmWgradParts parts{};
-    if (ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts, db ? &extra : nullptr) != LS2FM_OK)
+    if (ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts, db ? &extra : nullptr,
+                               fused_wgrad) != LS2FM_OK)
         return fail(forked, sc, LS2FM_ERR_LAUNCH);
     ls2fm_prof_begin(LS2FM_PROF_FINALIZE, gs);
     {   // sum of the partials + finalize tasks, one launch (the ticket word: slack of the reduced-gradient block, zeroed above)

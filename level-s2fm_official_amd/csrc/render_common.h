@@ -227,7 +227,37 @@ static inline int ls2fm_slab_shift(int dual) { return dual ? kSlabShift - 1 : kS
 constexpr int kWgradMlpBlocks = 256;   // persistent workgroups of wgrad_mlp: ONE per CU -- alone the kernels are slower than with two
                                       // (63 + 43 vs 52 + 34 us), but they run beside scatter_fill / slab_accumulate and leave them
                                       // more of the CU: step 0.656 -> 0.638 ms (graph), 128 or 192 workgroups are slower again
-int64_t ls2fm_wgrad_mlp_part_floats(int dual);
+// registers (= [R][64] rows) of one weight-gradient partial: dW0 tiles, dW1 tiles, dW1 row 0, db1
+constexpr int kRegsSdf = 48 + 16 + 16 + 5;
+constexpr int kRegsGeo = 48 + 16 + 4;
+constexpr int kRegsDec = 20;                     // 5 output tiles of the decoder columns
+// Round 5: the render's backward contracts the MLPs' weight gradients inside shade_bwd (shade_bwd.hip, 3.): one partial per
+// RAY (= workgroup), summed in two fixed-order levels -- kL1Seg segment sums (wgrad_l1 blocks of the wgrad_dec launch), then
+// wgrad_tail.
+constexpr int kL1Seg = 16;
+// partial buffers inside WsLayout::mpart (floats)
+struct WgPartLayout {
+    int64_t l1_sdf;      // [kL1Seg + kWgradMlpBlocks][kRegsSdf][64]: level-1 sums, then wgrad_mlp's own partials (point queries;
+                         //                                             the traced depth's extra tiles of a stage step)
+    int64_t l1_geo;      // [kL1Seg][kRegsGeo][64]   (point queries / round-4 form: [kWgradMlpBlocks] -- sized for the larger)
+    int64_t dec;         // [kWgradMlpBlocks][kRegsDec][64]
+    int64_t slot_sdf;    // [n_slots][kRegsSdf][64]
+    int64_t slot_geo;    // [n_slots][kRegsGeo][64]
+    int64_t total;
+    int n_slots;
+};
+static inline WgPartLayout make_wg_part_layout(int dual, int64_t n_rays, int n_samples) {
+    WgPartLayout L;
+    int64_t o = 0;
+    L.n_slots = n_samples > 1 ? (int)n_rays : 0;       // free points: wgrad_mlp.hip
+    L.l1_sdf = o; o += (int64_t)(kL1Seg + kWgradMlpBlocks) * kRegsSdf * 64;
+    L.l1_geo = o; o += dual ? (int64_t)kWgradMlpBlocks * kRegsGeo * 64 : 0;
+    L.dec = o; o += (int64_t)kWgradMlpBlocks * kRegsDec * 64;
+    L.slot_sdf = o; o += (int64_t)L.n_slots * kRegsSdf * 64;
+    L.slot_geo = o; o += dual ? (int64_t)L.n_slots * kRegsGeo * 64 : 0;
+    L.total = o;
+    return L;
+}
 
 // reduced raw weight gradients (floats)
 struct WgLayout {
@@ -276,7 +306,7 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.dlen = take(w.r_pad);      // pose gradients: d L / d |ray| through the interval lengths of the composite
     w.dzr = take(3 * w.r_pad);
     w.renc = take(27 * w.r_pad);
-    w.mpart = take(ls2fm_wgrad_mlp_part_floats(dual));
+    w.mpart = take(make_wg_part_layout(dual, n_rays, n_samples).total);
     w.wg = take(WgLayout::total);
     w.dbeta = take(2 * w.r_pad);     // one double per ray: d L / d beta partials (summed in fixed order by finalize)
     // bin meta (counts first) directly after wg / dbeta: one memset zeroes all three (render_bwd.hip)
@@ -329,10 +359,12 @@ __device__ __forceinline__ float ls2fm_sign(float d) { return d > 0.f ? 1.0f : (
 void ls2fm_scatter_zero_range(const ls2fm_grid_desc* grid, int64_t n_points, bool dual, int64_t* first, int64_t* count);
 
 // shade_bwd.hip
+// fused_wgrad: the MLPs' weight gradients are contracted inside the kernel (one partial per workgroup slot in WgPartLayout's
+// slot_sdf / slot_geo); 0: the v / gf / gf2 rows are stored for wgrad_mlp.hip (round-4 form, kept for A/B measurements)
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
                            const Upstream& up, int want_pose, const ls2fm_grid_desc* zero_grid, float* dtable1, float* dtable2,
-                           hipStream_t s);
+                           hipStream_t s, int fused_wgrad);
 
 // pose_grad.hip
 int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, const ls2fm_grid_desc* rad_grid, int dual,
@@ -341,13 +373,15 @@ int ls2fm_launch_pose_grad(const FieldC& fc, const ls2fm_grid_desc* sdf_grid, co
 
 // wgrad_mlp.hip.  `defer`: leave the sum of the partials to the caller (render_bwd.hip runs it in the finalize launch) and
 // describe them here
-struct Ls2fmWgradParts { const float* sdf; const float* geo; const float* dec; int nb_mlp, nb_dec, dual; };
+struct Ls2fmWgradParts { const float* sdf; const float* geo; const float* dec; int nb_sdf, nb_geo, nb_dec, dual; };
 // `extra`: a second set of per-sample rows (another workspace of the same layout family: the point-query backward of a traced
 // depth, points.hip) whose samples the SDF MLP's kernel contracts in the same launch, behind `ready` (event or null)
 struct Ls2fmWgradExtra { WsLayout w; const float* ws; void* ready; };
+// fused_wgrad: shade_bwd has left per-slot partials of both MLPs (above) -- no wgrad_mlp launch for the render's own samples
+// (only `extra`'s tiles, if any); the decoder launch sums the slots into kL1Seg segment sums in its trailing workgroups
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
                            const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only = false,
-                           Ls2fmWgradParts* defer = nullptr, const Ls2fmWgradExtra* extra = nullptr);
+                           Ls2fmWgradParts* defer = nullptr, const Ls2fmWgradExtra* extra = nullptr, int fused_wgrad = 0);
 
 // points.hip: the stages of ls2fm_sdf_points_bwd (see there)
 int ls2fm_points_bwd_front(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, const ls2fm_params* params, const float* p,

@@ -10,8 +10,17 @@
 //        DA = S1 . T + S2 . w1_0 . Q,  GJ = S1 . w1_0         (elementwise on accumulator registers)
 //        DE = W0'^T DA,  RR = W0'^T GJ            (encoding rows only: the payload of the table-gradient scatter)
 //        second field: A2, T2 = W1g^T GF2, DA2 = S1 . T2, DE2 = W0g'^T DA2
-//      Only the small per-sample upstream vectors (v, gf, gf2, dz, p) are stored for the weight-gradient kernels
-//      (wgrad_mlp.hip re-derives the hidden-layer operands instead of reading them back from HBM).
+//   3. (WG) the WEIGHT GRADIENTS of both Geometry MLPs, contracted where their operands already live: DA, GJ, H leave the
+//      accumulator registers through a 3.8 KB wave-private LDS tile (the contraction index of dW is the SAMPLE, which sits
+//      on the wrong side of the accumulator layout: written [feature][sample], read back as one ds_read_b128 per lane),
+//      U, V, GF take the same trip once per tile, and
+//        dW0' += DA U^T + GJ V^T  (64 x 36)   dW1[1..16] += GF H^T  (16 x 64)   dW1[0] += gf0 H + S1 . Q   db1 += sum GF
+//      accumulate in 85 (68) registers per wave over the wave's 64 samples; the workgroup's waves are summed through LDS
+//      and leave ONE partial per workgroup slot (fixed-order sums downstream: wgrad_l1 + wgrad_tail, deterministic).
+//      No separate weight-gradient kernel re-derives the hidden layer (round 4: wgrad_mlp x 2, 95 us alone and 150 us beside
+//      the table scatter), and the v / gf / gf2 rows (36 MB) are never stored.  One 16-column tile at a time then (NC = 1):
+//      the accumulators take the registers the second tile's operands had.
+//      Without WG (point queries keep wgrad_mlp.hip) the small per-sample upstream vectors (v, gf, gf2, dz, p) are stored.
 // MFMA-ordered weights are staged into LDS once per workgroup.  fp32 MFMA: exact fp32 products / sums.
 #include "bin_items.h"
 
@@ -23,7 +32,10 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-constexpr int NC = 2;          // 16-sample column tiles per pass (two passes per wave)
+constexpr int kTLd = 20;       // floats per row of the wave-private transpose tile: 16 samples + 4 pad (16-B aligned rows)
+constexpr int kTRows = 48;     // da | gj | h of one hidden block (U / V: 36 rows, GF: 20)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // fp64 wave scans for the d beta path (below)
 __device__ __forceinline__ double wave_scan_incl_f64(double v, int lane) {
@@ -45,14 +57,72 @@ __device__ __forceinline__ double wave_suffix_excl_f64(double v, int lane) {
     return s;
 }
 
+// (WG) end of a pass: this wave's accumulators in the partial's row order (wgrad_tail.h: reduce_partials_row), with the row sums
+// over the 16 sample lanes for dW1[0] / db1; the workgroup's waves are summed through `buf` (s_w: the pass is done with its
+// weights) in a fixed order, and wave 0 stores the ray's partial
+template <bool GEO>
+__device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][3], const f32x4 (&acc1)[4], const float (&w1r0)[4][4],
+                                         const float (&gsum)[5], float* __restrict__ buf, float* __restrict__ dst,
+                                         int wave, int n_waves, int lane) {
+    constexpr int R = GEO ? kRegsGeo : kRegsSdf;
+    float regs[R];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int mk = 0; mk < 3; ++mk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) regs[(m * 3 + mk) * 4 + q] = acc0[m][mk][q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) regs[48 + m * 4 + q] = acc1[m][q];
+        if (!GEO) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = w1r0[m][q];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                regs[64 + m * 4 + q] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < (GEO ? 4 : 5); ++t) {
+        float v = gsum[t];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        regs[(GEO ? 64 : 80) + t] = v;
+    }
+    for (int wv = n_waves - 1; wv >= 1; --wv) {
+        __syncthreads();                     // (first trip: every wave is done with the pass's weights)
+        if (wave == wv) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) buf[q * 64 + lane] = regs[q];
+        }
+        __syncthreads();
+        if (wave == wv - 1) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) regs[q] += buf[q * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) dst[q * 64] = regs[q];
+    }
+}
+
 // POSE: center / ray require gradients (BA "sfm_refine" with one camera, BA.py:153-154) -- the only case that needs the rows of
 // W0'^T DA that belong to the MLP's position inputs: 16 more MFMAs per hidden block and 8 more registers.
-template <bool DUAL, int MAXT, bool POSE>
+// WG: weight gradients contracted here (header, 3.), one partial per ray.  MAXT = 128: rays of up to 128 samples, 4 workgroups
+// of 2 waves per CU.  (A workgroup walking several rays and keeping one partial was tried first: the loop-invariant kernel
+// arguments it keeps in scalar registers across the loop spill into vector registers -- 92 .. 136 B of scratch per lane.)
+template <bool DUAL, int MAXT, bool POSE, bool WG>
 __global__ void __launch_bounds__(MAXT, 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
-                 Upstream up, float* __restrict__ out, ZeroJob zero) {
+                 Upstream up, float* __restrict__ out, ZeroJob zero, int64_t n_rays, float* __restrict__ slot_sdf,
+                 float* __restrict__ slot_geo) {
     constexpr bool want_pose = POSE;
+    constexpr int NC = WG ? 1 : 2;               // 16-sample column tiles in flight per wave (a wave owns four)
+    constexpr int kUnrollM = WG ? 4 : 1;         // the accumulators of a hidden block are registers: its loop is unrolled
     // leading workgroups: the zero fills the rest of the backward needs (weight-gradient accumulators, point-split coarse
     // levels of the gradient tables) -- no memset / kernel launches and no cross-stream edge in front of the scatter
     if ((int)blockIdx.x < zero.blocks) {
@@ -64,10 +134,14 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     __shared__ double s_pd[MAXT / 64][2];        // fp64 twin of the composite scans (d beta): tau totals, sum of U w
     __shared__ int s_bound[32];                  // per-level max of a single scatter contribution (bits of a float >= 0)
     __shared__ float s_y[MAXT][8];               // per sample: dz(3), g_n(3), g_sdf
-    __shared__ float s_w[kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB)
+    __shared__ float s_wc[3][68];                // collapsed decoder (Packed::wc)
+    __shared__ float s_w[kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB); WG: also the
+                                                 // buffer of the cross-wave sum of the weight-gradient registers
+    __shared__ __attribute__((aligned(16))) float s_t[WG ? MAXT / 64 : 1][WG ? kTRows * kTLd : 4];   // wave-private transpose tiles
+    static_assert(kRegsSdf * 64 <= kMfmaBwdSdfFloats && kRegsGeo * 64 <= kMfmaBwdSdfFloats, "register sums fit in s_w");
     const int N = fc.n_samples;
-    const int64_t r = (int64_t)blockIdx.x - zero.blocks;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x - zero.blocks;
     const int jl = lane & 15, g = lane >> 4;
     const int64_t P = w.p_pad;
     const uint32_t P32 = (uint32_t)w.p_pad;
@@ -84,6 +158,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         for (int q = n; q < kMfmaBwdSdfFloats / 4; q += blockDim.x) dst[q] = src[q];
     }
     if (n < 32) s_bound[n] = 0;
+    // the decoder's feature columns, read per lane (o = 4t + g) in every tile: from LDS (one base register + immediate offsets;
+    // as global loads the compiler kept fifteen 64-bit addresses alive across the tile loop -- and spilled them)
+    for (int q = n; q < 3 * 68; q += blockDim.x) (&s_wc[0][0])[q] = (&pk->wc[0][0])[q];
 
     // =========================================================================== 1. one thread per sample
     {
@@ -307,8 +384,24 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     // this lane's levels are the same in every half and column (l = 8 mk + 2 g + hv): keep the running maxima of the
     // contribution bounds in registers and publish them once per pass (a per-item LDS atomicMax: 16 lanes per address)
     float bnd[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // (WG) this wave's weight-gradient accumulators of the field of this pass, over its 64 samples
+    f32x4 acc0[WG ? 4 : 1][WG ? 3 : 1], acc1[WG ? 4 : 1];
+    float w1r0[WG ? 4 : 1][4], gsum[5];
+    if (WG) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mk = 0; mk < 3; ++mk) acc0[m][mk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w1r0[m][q] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) gsum[t] = 0.f;
+    }
+    float* __restrict__ xt = s_t[WG ? wave : 0];
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < 4 / NC; ++half) {
         uint32_t is[NC];                  // point index (32-bit offsets: uniform base + VGPR offset addressing)
         bool live_c[NC];
         float pw[NC][3], xg[NC][3], dz[NC][3], gns[NC][3], gnk[NC][3], gsdf[NC];
@@ -365,25 +458,28 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 if (o == 0) v = fc.kappa * gsdf[cc];
                 else if (o < kOut) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) v = fmaf(pk->wc[k][32 + o], dz[cc][k], v);
+                    for (int k = 0; k < 3; ++k) v = fmaf(s_wc[k][32 + o], dz[cc][k], v);
                 }
                 gfb[t][cc] = v;
             }
         }
         // per-sample operands of the weight-gradient GEMMs that exist only in this layout
-        const float g1[NC] = {fabsf(gns[0][0]) + fabsf(gns[0][1]) + fabsf(gns[0][2]),
-                              fabsf(gns[1][0]) + fabsf(gns[1][1]) + fabsf(gns[1][2])};
+        float g1[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) g1[cc] = fabsf(gns[cc][0]) + fabsf(gns[cc][1]) + fabsf(gns[cc][2]);
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc)
             if (live_c[cc]) {
+                if (!WG) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int kp = 4 * t + g;                             // k' -> the reference's input column
-                    if (kp < 35) o_v[(uint32_t)(kp < 32 ? 3 + kp : kp - 32) * P32 + is[cc]] = vb[t][cc];
+                    for (int t = 0; t < 9; ++t) {
+                        const int kp = 4 * t + g;                             // k' -> the reference's input column
+                        if (kp < 35) o_v[(uint32_t)(kp < 32 ? 3 + kp : kp - 32) * P32 + is[cc]] = vb[t][cc];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 5; ++t)
+                        if (4 * t + g < kOut) o_gf[(uint32_t)(4 * t + g) * P32 + is[cc]] = gfb[t][cc];
                 }
-#pragma unroll
-                for (int t = 0; t < 5; ++t)
-                    if (4 * t + g < kOut) o_gf[(uint32_t)(4 * t + g) * P32 + is[cc]] = gfb[t][cc];
                 if (g < 3) {
                     const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
                     (out + w.p3)[(uint32_t)g * P32 + is[cc]] = pg;
@@ -400,6 +496,30 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 dst[1] = make_float4(gns[cc][1], gns[cc][2], 0.f, 0.f);
             }
 
+        // (WG) U, V, GF of this tile as operands of the contraction over the samples: row jl (+ 16 mk), samples 4g .. 4g + 3.
+        // A wave's DS operations execute in order: a tile's rows are rewritten right behind the reads of the previous rows.
+        float4 b_u[3], b_v[3], a_gf;
+        if (WG) {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row2 = jl < 4 ? 32 + jl : 35;                  // rows 32..35 exist; the other lanes' values are dropped
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = ub[t][0];
+            __builtin_amdgcn_wave_barrier();
+            b_u[0] = ld4(xt + jl * kTLd + 4 * g); b_u[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_u[2] = ld4(xt + row2 * kTLd + 4 * g);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = vb[t][0];
+            __builtin_amdgcn_wave_barrier();
+            b_v[0] = ld4(xt + jl * kTLd + 4 * g); b_v[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_v[2] = ld4(xt + row2 * kTLd + 4 * g);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { xt[(4 * t + g) * kTLd + jl] = gfb[t][0]; gsum[t] += gfb[t][0]; }
+            __builtin_amdgcn_wave_barrier();
+            a_gf = ld4(xt + (1 + jl) * kTLd + 4 * g);
+            __builtin_amdgcn_wave_barrier();
+            if (jl >= 4) { b_u[2] = z4; b_v[2] = z4; }
+        }
+        const float gf0 = WG ? fc.kappa * gsdf[0] : 0.f;
         // ---- SDF field
         f32x4 de[2][NC], rr[2][NC];
 #pragma unroll
@@ -408,7 +528,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) { de[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; rr[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
+#pragma unroll kUnrollM
         for (int m = 0; m < 4; ++m) {
             f32x4 aa[NC], qq[NC], tt[NC];
 #pragma unroll
@@ -438,6 +558,12 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     softplus100(aa[cc][q], h, s1, s2);
                     da[cc][q] = fmaf(s1, tt[cc][q], s2 * w10 * qq[cc][q]);
                     gj[cc][q] = s1 * w10;
+                    if (WG) {       // this hidden block's DA | GJ | H, [hidden unit 4g + q][sample jl]
+                        xt[(4 * g + q) * kTLd + jl] = da[cc][q];
+                        xt[(16 + 4 * g + q) * kTLd + jl] = gj[cc][q];
+                        xt[(32 + 4 * g + q) * kTLd + jl] = h;
+                        w1r0[m][q] += fmaf(gf0, h, s1 * qq[cc][q]);
+                    }
                 }
             }
 #pragma unroll
@@ -458,6 +584,24 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) dex[cc] = mfma4(at, da[cc][q], dex[cc]);
                 }
+            }
+            if (WG) {
+                // contraction over the tile's 16 samples: the lane supplies row jl, samples 4g .. 4g + 3 of every operand (the
+                // tile's trip through LDS was in flight during the DE / RR products above)
+                __builtin_amdgcn_wave_barrier();
+                const float4 a_da = ld4(xt + jl * kTLd + 4 * g), a_gj = ld4(xt + (16 + jl) * kTLd + 4 * g), b_h = ld4(xt + (32 + jl) * kTLd + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+                f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c2 = acc0[m][2], c3 = acc1[m];
+                c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c2 = mfma4(a_da.x, b_u[2].x, c2); c3 = mfma4(a_gf.x, b_h.x, c3);
+                c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c2 = mfma4(a_da.y, b_u[2].y, c2); c3 = mfma4(a_gf.y, b_h.y, c3);
+                c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c2 = mfma4(a_da.z, b_u[2].z, c2); c3 = mfma4(a_gf.z, b_h.z, c3);
+                c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c2 = mfma4(a_da.w, b_u[2].w, c2); c3 = mfma4(a_gf.w, b_h.w, c3);
+                c0 = mfma4(a_gj.x, b_v[0].x, c0); c1 = mfma4(a_gj.x, b_v[1].x, c1); c2 = mfma4(a_gj.x, b_v[2].x, c2);
+                c0 = mfma4(a_gj.y, b_v[0].y, c0); c1 = mfma4(a_gj.y, b_v[1].y, c1); c2 = mfma4(a_gj.y, b_v[2].y, c2);
+                c0 = mfma4(a_gj.z, b_v[0].z, c0); c1 = mfma4(a_gj.z, b_v[1].z, c1); c2 = mfma4(a_gj.z, b_v[2].z, c2);
+                c0 = mfma4(a_gj.w, b_v[0].w, c0); c1 = mfma4(a_gj.w, b_v[1].w, c1); c2 = mfma4(a_gj.w, b_v[2].w, c2);
+                acc0[m][0] = c0; acc0[m][1] = c1; acc0[m][2] = c2; acc1[m] = c3;
+                __builtin_amdgcn_sched_barrier(0);       // (the unrolled hidden blocks are not interleaved: their temporaries would add up)
             }
         }
         if (want_pose && g == 0) {
@@ -503,11 +647,26 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 for (int t = 0; t < 4; ++t) {
                     float v = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) v = fmaf(pk->wc[k][49 + 4 * t + g], dz[cc][k], v);
+                    for (int k = 0; k < 3; ++k) v = fmaf(s_wc[k][49 + 4 * t + g], dz[cc][k], v);
                     gf2b[t][cc] = v;
-                    if (live_c[cc]) o_gf2[(uint32_t)(1 + 4 * t + g) * P32 + is[cc]] = v;
+                    if (!WG && live_c[cc]) o_gf2[(uint32_t)(1 + 4 * t + g) * P32 + is[cc]] = v;
                 }
-                if (live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
+                if (!WG && live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
+            }
+            float4 b_u[3], a_gf;
+            if (WG) {
+                const int row2 = jl < 4 ? 32 + jl : 35;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = ub[t][0];
+                __builtin_amdgcn_wave_barrier();
+                b_u[0] = ld4(xt + jl * kTLd + 4 * g); b_u[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_u[2] = ld4(xt + row2 * kTLd + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { xt[(4 * t + g) * kTLd + jl] = gf2b[t][0]; gsum[t] += gf2b[t][0]; }
+                __builtin_amdgcn_wave_barrier();
+                a_gf = ld4(xt + jl * kTLd + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+                if (jl >= 4) b_u[2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             f32x4 de2[2][NC];
 #pragma unroll
@@ -516,7 +675,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) de2[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll kUnrollM
             for (int m = 0; m < 4; ++m) {
                 f32x4 aa[NC], tt[NC];
 #pragma unroll
@@ -541,6 +700,10 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         float h, s1, s2;
                         softplus100(aa[cc][q], h, s1, s2);
                         da[cc][q] = s1 * tt[cc][q];
+                        if (WG) {
+                            xt[(4 * g + q) * kTLd + jl] = da[cc][q];
+                            xt[(32 + 4 * g + q) * kTLd + jl] = h;
+                        }
                     }
                 }
 #pragma unroll
@@ -558,6 +721,18 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 #pragma unroll
                         for (int cc = 0; cc < NC; ++cc) dex[cc] = mfma4(at, da[cc][q], dex[cc]);
                     }
+                }
+                if (WG) {
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 a_da = ld4(xt + jl * kTLd + 4 * g), b_h = ld4(xt + (32 + jl) * kTLd + 4 * g);
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c2 = acc0[m][2], c3 = acc1[m];
+                    c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c2 = mfma4(a_da.x, b_u[2].x, c2); c3 = mfma4(a_gf.x, b_h.x, c3);
+                    c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c2 = mfma4(a_da.y, b_u[2].y, c2); c3 = mfma4(a_gf.y, b_h.y, c3);
+                    c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c2 = mfma4(a_da.z, b_u[2].z, c2); c3 = mfma4(a_gf.z, b_h.z, c3);
+                    c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c2 = mfma4(a_da.w, b_u[2].w, c2); c3 = mfma4(a_gf.w, b_h.w, c3);
+                    acc0[m][0] = c0; acc0[m][1] = c1; acc0[m][2] = c2; acc1[m] = c3;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (want_pose && g == 0) {
@@ -590,6 +765,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             const int l = 8 * mk + 2 * g + hv;
             if (2 * l < (pass == 0 ? ch1 : ch2)) atomicMax(&s_bound[16 * pass + l], __float_as_int(bnd[mk][hv]));
         }
+    if constexpr (WG) {
+        float* __restrict__ dst = (pass == 0 ? slot_sdf : slot_geo) + r * ((pass == 0 ? kRegsSdf : kRegsGeo) * 64) + lane;
+        if (pass == 0) wg_flush<false>(acc0, acc1, w1r0, gsum, s_w, dst, wave, n_waves, lane);
+        else wg_flush<true>(acc0, acc1, w1r0, gsum, s_w, dst, wave, n_waves, lane);
+    }
     }
     // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
     __syncthreads();
@@ -601,7 +781,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, int ch1, int ch2, const WsLayout& w,
                            const Packed* pk, const float* center, const float* ray, int64_t n_rays, float* ws,
                            const Upstream& up, int want_pose, const ls2fm_grid_desc* zero_grid, float* dtable1, float* dtable2,
-                           hipStream_t s) {
+                           hipStream_t s, int fused_wgrad) {
     const int threads = (fc.n_samples + 63) / 64 * 64;
     ZeroJob zero{};
     zero.blocks = 64;
@@ -614,13 +794,21 @@ int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, i
         zero.nb = count / 2;
         if (dtable2) { zero.c = reinterpret_cast<float4*>(dtable2 + 2 * first); zero.nc = count / 2; }
     }
+    const WgPartLayout pl = make_wg_part_layout(dual, n_rays, fc.n_samples);
+    float* slot_sdf = ws + w.mpart + pl.slot_sdf;
+    float* slot_geo = ws + w.mpart + pl.slot_geo;
+    const unsigned grid = (unsigned)(n_rays + zero.blocks);
+#define LS2FM_SHADE_BWD2(DUAL, MAXT, POSE, WG)                                                                                \
+    shade_bwd_kernel<DUAL, MAXT, POSE, WG><<<grid, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero, \
+                                                                   n_rays, slot_sdf, slot_geo)
 #define LS2FM_SHADE_BWD(DUAL, MAXT)                                                                                          \
     do {                                                                                                                    \
-        if (want_pose) shade_bwd_kernel<DUAL, MAXT, true><<<(unsigned)(n_rays + zero.blocks), threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero); \
-        else shade_bwd_kernel<DUAL, MAXT, false><<<(unsigned)(n_rays + zero.blocks), threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero); \
+        if (fused_wgrad) { if (want_pose) LS2FM_SHADE_BWD2(DUAL, MAXT, true, true); else LS2FM_SHADE_BWD2(DUAL, MAXT, false, true); } \
+        else { if (want_pose) LS2FM_SHADE_BWD2(DUAL, MAXT, true, false); else LS2FM_SHADE_BWD2(DUAL, MAXT, false, false); } \
     } while (0)
-    if (dual) { if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
-    else      { if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
+    if (dual) { if (threads <= 128) LS2FM_SHADE_BWD(true, 128); else if (threads <= 256) LS2FM_SHADE_BWD(true, 256); else LS2FM_SHADE_BWD(true, 512); }
+    else      { if (threads <= 128) LS2FM_SHADE_BWD(false, 128); else if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD
+#undef LS2FM_SHADE_BWD2
     return LS2FM_OK;
 }

@@ -254,8 +254,46 @@ __device__ __forceinline__ float4 mask4(const float4 v, int64_t s, int64_t n, bo
     return make_float4((on && s < n) ? v.x : 0.f, (on && s + 1 < n) ? v.y : 0.f, (on && s + 2 < n) ? v.z : 0.f, (on && s + 3 < n) ? v.w : 0.f);
 }
 
+// Level 1 of the fixed-order sum of shade_bwd's per-ray weight-gradient partials (shade_bwd.hip, 3.): job (row k, segment sg)
+// adds row k of the rays [sg * per, (sg + 1) * per) -- wave v takes the rays v, v + 4, ... of the segment, eight loads in
+// flight, then the four waves' sums are added in order -- and leaves row k of segment sum sg.  The order of the additions is a
+// function of (n_rays, kL1Seg) alone: deterministic.
+struct L1Job { const float* slot_sdf; const float* slot_geo; float* l1_sdf; float* l1_geo; int n_slots, dual; };
+
+__device__ void wgrad_l1_job(const L1Job& jb, int job) {
+    __shared__ float s_l1[kWmWaves][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = kRegsSdf + (jb.dual ? kRegsGeo : 0);
+    int k = job % rows;
+    const int sg = job / rows;
+    const bool geo = k >= kRegsSdf;
+    if (geo) k -= kRegsSdf;
+    const int R = geo ? kRegsGeo : kRegsSdf;
+    const float* __restrict__ src = (geo ? jb.slot_geo : jb.slot_sdf) + (int64_t)k * 64 + lane;
+    const int per = (jb.n_slots + kL1Seg - 1) / kL1Seg;
+    const int lo = sg * per, hi = min(lo + per, jb.n_slots);
+    float acc = 0.f;
+    int b = lo + wave;
+    for (; b + 7 * kWmWaves < hi; b += 8 * kWmWaves) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + u * kWmWaves) * (R * 64)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < hi; b += kWmWaves) acc += src[(int64_t)b * (R * 64)];
+    s_l1[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0)
+        (geo ? jb.l1_geo : jb.l1_sdf)[((int64_t)sg * R + k) * 64 + lane] = (s_l1[0][lane] + s_l1[1][lane]) + (s_l1[2][lane] + s_l1[3][lane]);
+}
+
 __global__ void __launch_bounds__(kWmThreads)
-wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__ ws, float* __restrict__ part) {
+wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__ ws, float* __restrict__ part, int dec_blocks, L1Job l1) {
+    if ((int)blockIdx.x >= dec_blocks) {          // trailing workgroups: level-1 sums of shade_bwd's partials
+        wgrad_l1_job(l1, (int)blockIdx.x - dec_blocks);
+        return;
+    }
     __shared__ float red[kRegsDec * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jl = lane & 15, g = lane >> 4;
@@ -266,7 +304,7 @@ wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__
     const int n_tiles_p = (int)((w.p + 15) / 16), n_tiles_r = (int)((n_rays + 15) / 16);
     // software-pipelined: the NEXT tile's four operand loads are in flight during this tile's twelve MFMAs (a wave has ~8
     // tiles: with the loads issued and awaited tile by tile the kernel was eight exposed memory round trips, 21 us for 21 MB)
-    const int step = gridDim.x * kWmWaves;
+    const int step = dec_blocks * kWmWaves;
     const int64_t s_last = P - 4;                  // rows are p_pad long (a multiple of 64)
     const float* __restrict__ row_a = ws + w.dz + (jl < 3 ? jl : 0) * P;
     const float* __restrict__ row_b0 = ws + w.fe + jl * P;
@@ -304,7 +342,7 @@ wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__
     {
         const int64_t r_last = w.r_pad - 4;
 #pragma unroll 1
-        for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_r; tile += gridDim.x * kWmWaves) {
+        for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_r; tile += dec_blocks * kWmWaves) {
             const int64_t s = (int64_t)tile * 16 + 4 * g;
             const float4 ra = load4_raw(ws + w.dzr + (jl < 3 ? jl : 0) * w.r_pad, s, r_last), rb0 = load4_raw(ws + w.renc + jl * w.r_pad, s, r_last),
                          rb1 = load4_raw(ws + w.renc + (16 + jl < kView ? 16 + jl : 0) * w.r_pad, s, r_last);
@@ -336,43 +374,51 @@ wgrad_reduce_all_kernel(WgradParts wp, float* __restrict__ wg) {
 
 }  // namespace
 
-int64_t ls2fm_wgrad_mlp_part_floats(int dual) {
-    return (int64_t)kWgradMlpBlocks * 64 * (kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec);
-}
-
 // enqueue every weight-gradient kernel of the backward (+ the reduction of their partials) on `s`
 int ls2fm_launch_wgrad_mlp(const FieldC& fc, int dual, int ch1, int ch2, const WsLayout& w, const Packed* pk, const float* center,
                            const float* ray, int64_t n_rays, float* ws, hipStream_t s, bool sdf_only, Ls2fmWgradParts* defer,
-                           const Ls2fmWgradExtra* extra) {
-    const int n_tiles = (int)((w.p + 15) / 16);
+                           const Ls2fmWgradExtra* extra, int fused_wgrad) {
+    const WgPartLayout pl = make_wg_part_layout(dual, n_rays, sdf_only ? 1 : fc.n_samples);
+    // fused: the render's own samples were contracted by shade_bwd; only `extra`'s tiles (if any) are left for wgrad_mlp
+    const int n_tiles = fused_wgrad ? 0 : (int)((w.p + 15) / 16);
     const int n_tiles_b = extra ? (int)((extra->w.p + 15) / 16) : 0;
     int blocks = (n_tiles + n_tiles_b + kWmWaves - 1) / kWmWaves;
     if (blocks > kWgradMlpBlocks) blocks = kWgradMlpBlocks;
-    const int dec_blocks = blocks;
-    float* part1 = ws + w.mpart;
-    float* part2 = part1 + (int64_t)kWgradMlpBlocks * 64 * kRegsSdf;
-    float* part3 = part2 + (int64_t)kWgradMlpBlocks * 64 * (dual ? kRegsGeo : 0);
+    int dec_blocks = (int)(((w.p + 15) / 16 + kWmWaves - 1) / kWmWaves);
+    if (dec_blocks > kWgradMlpBlocks) dec_blocks = kWgradMlpBlocks;
+    float* l1_sdf = ws + w.mpart + pl.l1_sdf;
+    float* l1_geo = ws + w.mpart + pl.l1_geo;
+    // wgrad_mlp's own partials: behind the level-1 segment sums (SDF MLP) / in the second MLP's block (never both forms)
+    float* part1 = l1_sdf + (int64_t)kL1Seg * 64 * kRegsSdf;
+    float* part2 = l1_geo;
+    float* part3 = ws + w.mpart + pl.dec;
     // second MLP first: the order only matters through how the two kernels share the CUs with scatter_fill / slab_accumulate
     // on the other queue -- measured (A/B on one box, graph replay of the benchmark step) 0.579 vs 0.583 ms
-    if (dual) {
+    if (dual && !fused_wgrad) {
         ls2fm_prof_begin(LS2FM_PROF_WGRAD_GEO, s);
         wgrad_mlp_kernel<true, false><<<blocks, kWmThreads, 0, s>>>(fc, ch2, w, pk, center, ray, ws, part2, n_tiles, w, ws, 0);
         ls2fm_prof_end(LS2FM_PROF_WGRAD_GEO, s);
     }
     // the second set's rows are written on another stream: its samples join this launch behind their event
     if (extra && extra->ready && hipStreamWaitEvent(s, (hipEvent_t)extra->ready, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;
-    ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, s);
-    if (extra)
-        wgrad_mlp_kernel<false, true><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles, extra->w, extra->ws, n_tiles_b);
-    else
-        wgrad_mlp_kernel<false, false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles, w, ws, 0);
-    ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
+    if (blocks > 0) {
+        ls2fm_prof_begin(LS2FM_PROF_WGRAD_MLP, s);
+        if (extra)
+            wgrad_mlp_kernel<false, true><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles, extra->w, extra->ws, n_tiles_b);
+        else
+            wgrad_mlp_kernel<false, false><<<blocks, kWmThreads, 0, s>>>(fc, ch1, w, pk, center, ray, ws, part1, n_tiles, w, ws, 0);
+        ls2fm_prof_end(LS2FM_PROF_WGRAD_MLP, s);
+    }
     ls2fm_prof_begin(LS2FM_PROF_WGRAD_TAIL, s);
     if (sdf_only) {          // point queries: no decoder columns, the SDF MLP's partials only (blocks [0, kRegsSdf) of the reduction)
-        wgrad_reduce_all_kernel<<<kRegsSdf, kWmThreads, 0, s>>>(WgradParts{part1, part2, part3, blocks, 0, 0}, ws + w.wg);
+        wgrad_reduce_all_kernel<<<kRegsSdf, kWmThreads, 0, s>>>(WgradParts{part1, part2, part3, blocks, 0, 0, 0}, ws + w.wg);
     } else {
-        wgrad_dec_kernel<<<dec_blocks, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3);
-        const WgradParts wp{part1, part2, part3, blocks, dec_blocks, dual};
+        L1Job l1{ws + w.mpart + pl.slot_sdf, ws + w.mpart + pl.slot_geo, l1_sdf, l1_geo, pl.n_slots, dual};
+        const int l1_jobs = fused_wgrad ? kL1Seg * (kRegsSdf + (dual ? kRegsGeo : 0)) : 0;
+        wgrad_dec_kernel<<<dec_blocks + l1_jobs, kWmThreads, 0, s>>>(w, dual, n_rays, ws, part3, dec_blocks, l1);
+        // fused: the SDF MLP's partials are the kL1Seg segment sums followed by wgrad_mlp's `blocks` partials of the extra tiles
+        const WgradParts wp = fused_wgrad ? WgradParts{l1_sdf, l1_geo, part3, kL1Seg + blocks, kL1Seg, dec_blocks, dual}
+                                          : WgradParts{part1, part2, part3, blocks, blocks, dec_blocks, dual};
         if (defer) *defer = wp;
         else wgrad_reduce_all_kernel<<<kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec, kWmThreads, 0, s>>>(wp, ws + w.wg);
     }

@@ -9,9 +9,6 @@ namespace {
 
 constexpr int kWmThreads = 256;
 constexpr int kWmWaves = kWmThreads / 64;
-constexpr int kRegsSdf = 48 + 16 + 16 + 5;       // dW0 tiles, dW1 tiles, dW1 row 0, db1
-constexpr int kRegsGeo = 48 + 16 + 4;
-constexpr int kRegsDec = 20;                     // 5 output tiles
 constexpr int kFinalizeTasks = 7;
 
 // The reduced-gradient block crosses workgroups INSIDE one launch (wgrad_tail_kernel, render_bwd.hip): rows are written with
@@ -38,13 +35,13 @@ __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg
     const float* __restrict__ part_sdf = wp.sdf;
     const float* __restrict__ part_geo = wp.geo;
     const float* __restrict__ part_dec = wp.dec;
-    const int nb_mlp = wp.nb_mlp, nb_dec = wp.nb_dec, dual = wp.dual;
+    const int nb_dec = wp.nb_dec, dual = wp.dual;
     __shared__ float s_sum[kWmWaves][64];
     int kind = 0;
     if (k >= kRegsSdf) { k -= kRegsSdf; kind = 1; if (!dual || k >= kRegsGeo) { k -= dual ? kRegsGeo : 0; kind = 2; } }
     const float* part = kind == 0 ? part_sdf : (kind == 1 ? part_geo : part_dec);
     const int R = kind == 0 ? kRegsSdf : (kind == 1 ? kRegsGeo : kRegsDec);
-    const int nb = kind == 2 ? nb_dec : nb_mlp;
+    const int nb = kind == 2 ? nb_dec : (kind == 1 ? wp.nb_geo : wp.nb_sdf);
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, jl = lane & 15, g = lane >> 4;
     float s0 = 0.f, s1 = 0.f;
     int b = grp;
