@@ -32,10 +32,46 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+#ifndef LS2FM_PROBE
+#define LS2FM_PROBE 0
+#endif
+constexpr bool kProbeNoContract = (LS2FM_PROBE & 1) != 0, kProbeNoTrans = (LS2FM_PROBE & 2) != 0, kProbeNC1 = (LS2FM_PROBE & 4) != 0;
+constexpr bool kProbeNoPos = (LS2FM_PROBE & 8) != 0, kProbeStage1 = (LS2FM_PROBE & 32) != 0;
 constexpr int kTLd = 20;       // floats per row of the wave-private transpose tile: 16 samples + 4 pad (16-B aligned rows)
 constexpr int kTRows = 48;     // da | gj | h of one hidden block (U / V: 36 rows, GF: 20)
+constexpr int kSwWg = kMfmaBwdSdfFloats - 4 * 4 * 64 + 64;       // WG: W1[0] as 64 floats instead of its operand-ordered 4 KB
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// lane J of this lane's 16-lane row (DPP row_share: folds into the consuming VALU instruction)
+template <int J> __device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a row, in every lane (DPP row rotations: no trip through the LDS crossbar as __shfl_xor takes)
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+}
+// the four position / bias columns of dW0' (k' = 32 .. 35) on the VALU, in the TRANSPOSED layout the contraction's operands have
+// (lane: hidden unit jl, samples 4g .. 4g + 3): as MFMA tiles they were eight (four) products per hidden block for 4 live columns
+// of 16.  u2 / v2: lanes jl < 4 of a row hold U / V rows 32 + jl at the row's four samples.
+// s += x * (lane A of this lane's row).u  as ONE instruction (v_fmac_f32 with a DPP row_share source).  Written as asm on
+// purpose: as a builtin broadcast + fmaf the compiler hoists the 28 broadcasts of a tile out of the hidden-block loop and keeps
+// them in 28 registers -- which the kernel does not have (scratch spills inside the MFMA loop: 105 -> 183 us)
+template <int A> __device__ __forceinline__ void fmac_row(float& s, float u, float x) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(u), "v"(x), "n"(A));
+}
+template <int A, bool WITH_V>
+__device__ __forceinline__ float pos_col(float s, const float4& a_da, const float4& a_gj, const float4& u2, const float4& v2) {
+    fmac_row<A>(s, u2.x, a_da.x); fmac_row<A>(s, u2.y, a_da.y); fmac_row<A>(s, u2.z, a_da.z); fmac_row<A>(s, u2.w, a_da.w);
+    if (WITH_V) { fmac_row<A>(s, v2.x, a_gj.x); fmac_row<A>(s, v2.y, a_gj.y); fmac_row<A>(s, v2.z, a_gj.z); fmac_row<A>(s, v2.w, a_gj.w); }
+    return s;
+}
 
 // fp64 wave scans for the d beta path (below)
 __device__ __forceinline__ double wave_scan_incl_f64(double v, int lane) {
@@ -61,35 +97,56 @@ __device__ __forceinline__ double wave_suffix_excl_f64(double v, int lane) {
 // over the 16 sample lanes for dW1[0] / db1; the workgroup's waves are summed through `buf` (s_w: the pass is done with its
 // weights) in a fixed order, and wave 0 stores the ray's partial
 template <bool GEO>
-__device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][3], const f32x4 (&acc1)[4], const float (&w1r0)[4][4],
-                                         const float (&gsum)[5], float* __restrict__ buf, float* __restrict__ dst,
-                                         int wave, int n_waves, int lane) {
+__device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 (&acc1)[4], const float (&pacc)[4][4],
+                                         float w1p, float gs16, float g0s, float* __restrict__ buf,
+                                         float* __restrict__ dst, int wave, int n_waves, int lane) {
     constexpr int R = GEO ? kRegsGeo : kRegsSdf;
+    const int jl = lane & 15, g = lane >> 4;
     float regs[R];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int mk = 0; mk < 3; ++mk)
+        for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
             for (int q = 0; q < 4; ++q) regs[(m * 3 + mk) * 4 + q] = acc0[m][mk][q];
+        // position / bias columns: pacc[m][a] = this lane's sample group's part of dW0'[16m + jl][32 + a]; summed over the four
+        // groups, then moved into the tile layout of the partial (lane (g, jl < 4), row q: dW0'[16m + 4g + q][32 + jl])
+        float tot[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float v = pacc[m][a];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            tot[a] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int src = 16 * g + 4 * g + q;
+            const float t0 = __shfl(tot[0], src, 64), t1 = __shfl(tot[1], src, 64), t2 = __shfl(tot[2], src, 64), t3 = __shfl(tot[3], src, 64);
+            regs[(m * 3 + 2) * 4 + q] = jl == 0 ? t0 : (jl == 1 ? t1 : (jl == 2 ? t2 : t3));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) regs[48 + m * 4 + q] = acc1[m][q];
-        if (!GEO) {
+        if (!GEO) {          // dW1[0][16m + 4g + q]: the row sums are packed one per lane, jl = 4m + q
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = w1r0[m][q];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                regs[64 + m * 4 + q] = v;
-            }
+            for (int q = 0; q < 4; ++q) regs[64 + m * 4 + q] = __shfl(w1p, 16 * g + 4 * m + q, 64);
         }
     }
+    {   // db1: gs16 = this lane's sample group's part of sum_s GF[o = 1 + jl][s]; g0s = this lane's samples' gf[0] (every group
+        // holds a copy: group 0's is taken)
+        float v = gs16;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        float v0 = g0s;
 #pragma unroll
-    for (int t = 0; t < (GEO ? 4 : 5); ++t) {
-        float v = gsum[t];
+        for (int o = 8; o > 0; o >>= 1) v0 += __shfl_xor(v0, o, 64);
+        v0 = __shfl(v0, 0, 64);
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        regs[(GEO ? 64 : 80) + t] = v;
+        for (int t = 0; t < (GEO ? 4 : 5); ++t) {
+            const int o = GEO ? 1 + 4 * t + g : 4 * t + g;                  // the row this lane's group reports (wgrad_tail.h)
+            const float x = __shfl(v, 16 * g + ((o - 1) & 15), 64);
+            regs[(GEO ? 64 : 80) + t] = o == 0 ? v0 : x;
+        }
     }
     for (int wv = n_waves - 1; wv >= 1; --wv) {
         __syncthreads();                     // (first trip: every wave is done with the pass's weights)
@@ -121,7 +178,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                  Upstream up, float* __restrict__ out, ZeroJob zero, int64_t n_rays, float* __restrict__ slot_sdf,
                  float* __restrict__ slot_geo) {
     constexpr bool want_pose = POSE;
-    constexpr int NC = WG ? 1 : 2;               // 16-sample column tiles in flight per wave (a wave owns four)
+    constexpr int NC = (WG || kProbeNC1) ? 1 : 2;               // 16-sample column tiles in flight per wave (a wave owns four)
     constexpr int kUnrollM = WG ? 4 : 1;         // the accumulators of a hidden block are registers: its loop is unrolled
     // leading workgroups: the zero fills the rest of the backward needs (weight-gradient accumulators, point-split coarse
     // levels of the gradient tables) -- no memset / kernel launches and no cross-stream edge in front of the scatter
@@ -135,10 +192,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     __shared__ int s_bound[32];                  // per-level max of a single scatter contribution (bits of a float >= 0)
     __shared__ float s_y[MAXT][8];               // per sample: dz(3), g_n(3), g_sdf
     __shared__ float s_wc[3][68];                // collapsed decoder (Packed::wc)
-    __shared__ float s_w[kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB); WG: also the
-                                                 // buffer of the cross-wave sum of the weight-gradient registers
+    __shared__ float s_w[WG ? kSwWg : kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB; WG:
+                                                 // 22 KB, W1[0] compact); WG: also the buffer of the cross-wave sum of the
+                                                 // weight-gradient registers
     __shared__ __attribute__((aligned(16))) float s_t[WG ? MAXT / 64 : 1][WG ? kTRows * kTLd : 4];   // wave-private transpose tiles
-    static_assert(kRegsSdf * 64 <= kMfmaBwdSdfFloats && kRegsGeo * 64 <= kMfmaBwdSdfFloats, "register sums fit in s_w");
+    static_assert(kRegsSdf * 64 <= kSwWg && kRegsGeo * 64 <= kSwWg && kMfmaBwdGeoFloats <= kSwWg, "register sums / second field's weights fit in s_w");
     const int N = fc.n_samples;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
     const int64_t r = (int64_t)blockIdx.x - zero.blocks;
@@ -155,7 +213,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     {   // stage the SDF field's operand-ordered weights (consumed after the barriers of part 1)
         const float4* src = reinterpret_cast<const float4*>(&pk->bs);
         float4* dst = reinterpret_cast<float4*>(s_w);
-        for (int q = n; q < kMfmaBwdSdfFloats / 4; q += blockDim.x) dst[q] = src[q];
+        constexpr int n_stage = WG ? kMfmaBwdSdfFloats - 4 * 4 * 64 : kMfmaBwdSdfFloats;       // (w10 is the last member)
+        for (int q = n; q < n_stage / 4; q += blockDim.x) dst[q] = src[q];
+        if (WG && n < 64) s_w[n_stage + n] = pk->bs.w10[n >> 4][n & 3][16 * ((n >> 2) & 3)];      // W1[0][hidden unit n]
     }
     if (n < 32) s_bound[n] = 0;
     // the decoder's feature columns, read per lane (o = 4t + g) in every tile: from LDS (one base register + immediate offsets;
@@ -366,10 +426,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     }
 
     // =========================================================================== 2. MFMA lanes
+    if (kProbeStage1) return;
     const float* __restrict__ s_w0a = s_w;                              // [m][t][lane]
     const float* __restrict__ s_w1ta = s_w + 4 * 9 * 64;                // [m][5][lane]
     const float* __restrict__ s_w0ta = s_w1ta + 4 * 5 * 64;             // [mk][m][r][lane]
-    const float* __restrict__ s_w10 = s_w0ta + 2 * 4 * 4 * 64;          // [m][r][lane]
+    const float* __restrict__ s_w10 = s_w0ta + 2 * 4 * 4 * 64;          // [m][r][lane]; WG: [hidden unit]
     // pass 0: the SDF field for both halves of the wave's samples; pass 1 (dual): the second field for both halves -- each
     // field's weights are staged into LDS once per workgroup
 #pragma unroll 1
@@ -385,19 +446,18 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     // contribution bounds in registers and publish them once per pass (a per-item LDS atomicMax: 16 lanes per address)
     float bnd[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     // (WG) this wave's weight-gradient accumulators of the field of this pass, over its 64 samples
-    f32x4 acc0[WG ? 4 : 1][WG ? 3 : 1], acc1[WG ? 4 : 1];
-    float w1r0[WG ? 4 : 1][4], gsum[5];
+    // (the row sums dW1[0] and db1 are packed: one value per lane, see wg_flush)
+    f32x4 acc0[WG ? 4 : 1][WG ? 2 : 1], acc1[WG ? 4 : 1];
+    float pacc[WG ? 4 : 1][4], w1p = 0.f, gs16 = 0.f, g0s = 0.f;
     if (WG) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             acc1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mk = 0; mk < 3; ++mk) acc0[m][mk] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int mk = 0; mk < 2; ++mk) acc0[m][mk] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w1r0[m][q] = 0.f;
+            for (int a = 0; a < 4; ++a) pacc[m][a] = 0.f;
         }
-#pragma unroll
-        for (int t = 0; t < 5; ++t) gsum[t] = 0.f;
     }
     float* __restrict__ xt = s_t[WG ? wave : 0];
 #pragma unroll 1
@@ -499,9 +559,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         // (WG) U, V, GF of this tile as operands of the contraction over the samples: row jl (+ 16 mk), samples 4g .. 4g + 3.
         // A wave's DS operations execute in order: a tile's rows are rewritten right behind the reads of the previous rows.
         float4 b_u[3], b_v[3], a_gf;
-        if (WG) {
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int row2 = jl < 4 ? 32 + jl : 35;                  // rows 32..35 exist; the other lanes' values are dropped
+        if (WG && kProbeNoTrans) { b_u[0] = b_u[1] = b_u[2] = b_v[0] = b_v[1] = b_v[2] = a_gf = make_float4(1.f, 2.f, 3.f, 4.f); }
+        if (WG && !kProbeNoTrans) {
+            const int row2 = jl < 4 ? 32 + jl : 35;                  // rows 32..35 exist: lanes jl < 4 are the ones pos_col reads
 #pragma unroll
             for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = ub[t][0];
             __builtin_amdgcn_wave_barrier();
@@ -513,11 +573,12 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             b_v[0] = ld4(xt + jl * kTLd + 4 * g); b_v[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_v[2] = ld4(xt + row2 * kTLd + 4 * g);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { xt[(4 * t + g) * kTLd + jl] = gfb[t][0]; gsum[t] += gfb[t][0]; }
+            for (int t = 0; t < 5; ++t) xt[(4 * t + g) * kTLd + jl] = gfb[t][0];
             __builtin_amdgcn_wave_barrier();
             a_gf = ld4(xt + (1 + jl) * kTLd + 4 * g);
             __builtin_amdgcn_wave_barrier();
-            if (jl >= 4) { b_u[2] = z4; b_v[2] = z4; }
+            gs16 += (a_gf.x + a_gf.y) + (a_gf.z + a_gf.w);           // db1[1 + jl], this group's four samples
+            g0s += fc.kappa * gsdf[0];                               // db1[0]
         }
         const float gf0 = WG ? fc.kappa * gsdf[0] : 0.f;
         // ---- SDF field
@@ -533,6 +594,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
             f32x4 aa[NC], qq[NC], tt[NC];
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) { aa[cc] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[cc] = aa[cc]; tt[cc] = aa[cc]; }
+            // (three independent accumulator chains side by side: a dependent f32 MFMA issues after 40 cycles, an independent
+            // one after 32)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float a = s_w0a[(m * 9 + t) * 64 + lane];
@@ -541,28 +604,30 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     aa[cc] = mfma4(a, ub[t][cc], aa[cc]);
                     qq[cc] = mfma4(a, vb[t][cc], qq[cc]);
                 }
-            }
+                if (t < 5) {
+                    const float a1 = s_w1ta[(m * 5 + t) * 64 + lane];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const float a = s_w1ta[(m * 5 + t) * 64 + lane];
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) tt[cc] = mfma4(a, gfb[t][cc], tt[cc]);
+                    for (int cc = 0; cc < NC; ++cc) tt[cc] = mfma4(a1, gfb[t][cc], tt[cc]);
+                }
             }
             float da[NC][4], gj[NC][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float w10 = s_w10[(m * 4 + q) * 64 + lane];
+                const float w10 = WG ? s_w10[16 * m + 4 * g + q] : s_w10[(m * 4 + q) * 64 + lane];
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     float h, s1, s2;
                     softplus100(aa[cc][q], h, s1, s2);
                     da[cc][q] = fmaf(s1, tt[cc][q], s2 * w10 * qq[cc][q]);
                     gj[cc][q] = s1 * w10;
-                    if (WG) {       // this hidden block's DA | GJ | H, [hidden unit 4g + q][sample jl]
+                    if (WG && !kProbeNoTrans) {       // this hidden block's DA | GJ | H, [hidden unit 4g + q][sample jl]
                         xt[(4 * g + q) * kTLd + jl] = da[cc][q];
                         xt[(16 + 4 * g + q) * kTLd + jl] = gj[cc][q];
                         xt[(32 + 4 * g + q) * kTLd + jl] = h;
-                        w1r0[m][q] += fmaf(gf0, h, s1 * qq[cc][q]);
+                        // dW1[0][16m + 4g + q] += sum over the tile's samples of gf0 H + S1 . Q: a row sum, packed one per lane
+                        // (sixteen per-lane accumulators instead: spills; the summands through the LDS tile as a fourth block: +7 us)
+                        const float rs = row_sum16(fmaf(gf0, h, s1 * qq[cc][q]));
+                        w1p += jl == 4 * m + q ? rs : 0.f;
                     }
                 }
             }
@@ -585,22 +650,28 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     for (int cc = 0; cc < NC; ++cc) dex[cc] = mfma4(at, da[cc][q], dex[cc]);
                 }
             }
-            if (WG) {
+            if (WG && !kProbeNoContract) {
                 // contraction over the tile's 16 samples: the lane supplies row jl, samples 4g .. 4g + 3 of every operand (the
                 // tile's trip through LDS was in flight during the DE / RR products above)
                 __builtin_amdgcn_wave_barrier();
                 const float4 a_da = ld4(xt + jl * kTLd + 4 * g), a_gj = ld4(xt + (16 + jl) * kTLd + 4 * g), b_h = ld4(xt + (32 + jl) * kTLd + 4 * g);
                 __builtin_amdgcn_wave_barrier();
-                f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c2 = acc0[m][2], c3 = acc1[m];
-                c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c2 = mfma4(a_da.x, b_u[2].x, c2); c3 = mfma4(a_gf.x, b_h.x, c3);
-                c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c2 = mfma4(a_da.y, b_u[2].y, c2); c3 = mfma4(a_gf.y, b_h.y, c3);
-                c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c2 = mfma4(a_da.z, b_u[2].z, c2); c3 = mfma4(a_gf.z, b_h.z, c3);
-                c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c2 = mfma4(a_da.w, b_u[2].w, c2); c3 = mfma4(a_gf.w, b_h.w, c3);
-                c0 = mfma4(a_gj.x, b_v[0].x, c0); c1 = mfma4(a_gj.x, b_v[1].x, c1); c2 = mfma4(a_gj.x, b_v[2].x, c2);
-                c0 = mfma4(a_gj.y, b_v[0].y, c0); c1 = mfma4(a_gj.y, b_v[1].y, c1); c2 = mfma4(a_gj.y, b_v[2].y, c2);
-                c0 = mfma4(a_gj.z, b_v[0].z, c0); c1 = mfma4(a_gj.z, b_v[1].z, c1); c2 = mfma4(a_gj.z, b_v[2].z, c2);
-                c0 = mfma4(a_gj.w, b_v[0].w, c0); c1 = mfma4(a_gj.w, b_v[1].w, c1); c2 = mfma4(a_gj.w, b_v[2].w, c2);
-                acc0[m][0] = c0; acc0[m][1] = c1; acc0[m][2] = c2; acc1[m] = c3;
+                f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c3 = acc1[m];
+                c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c3 = mfma4(a_gf.x, b_h.x, c3);
+                c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c3 = mfma4(a_gf.y, b_h.y, c3);
+                c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c3 = mfma4(a_gf.z, b_h.z, c3);
+                c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c3 = mfma4(a_gf.w, b_h.w, c3);
+                c0 = mfma4(a_gj.x, b_v[0].x, c0); c1 = mfma4(a_gj.x, b_v[1].x, c1);
+                c0 = mfma4(a_gj.y, b_v[0].y, c0); c1 = mfma4(a_gj.y, b_v[1].y, c1);
+                c0 = mfma4(a_gj.z, b_v[0].z, c0); c1 = mfma4(a_gj.z, b_v[1].z, c1);
+                c0 = mfma4(a_gj.w, b_v[0].w, c0); c1 = mfma4(a_gj.w, b_v[1].w, c1);
+                acc0[m][0] = c0; acc0[m][1] = c1; acc1[m] = c3;
+                if (!kProbeNoPos) {
+                pacc[m][0] = pos_col<0, true>(pacc[m][0], a_da, a_gj, b_u[2], b_v[2]);
+                pacc[m][1] = pos_col<1, true>(pacc[m][1], a_da, a_gj, b_u[2], b_v[2]);
+                pacc[m][2] = pos_col<2, true>(pacc[m][2], a_da, a_gj, b_u[2], b_v[2]);
+                pacc[m][3] = pos_col<3, false>(pacc[m][3], a_da, a_gj, b_u[2], b_v[2]);       // (V has no bias row)
+                }
                 __builtin_amdgcn_sched_barrier(0);       // (the unrolled hidden blocks are not interleaved: their temporaries would add up)
             }
         }
@@ -654,7 +725,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 if (!WG && live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
             }
             float4 b_u[3], a_gf;
-            if (WG) {
+            if (WG && kProbeNoTrans) { b_u[0] = b_u[1] = b_u[2] = a_gf = make_float4(1.f, 2.f, 3.f, 4.f); }
+            if (WG && !kProbeNoTrans) {
                 const int row2 = jl < 4 ? 32 + jl : 35;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = ub[t][0];
@@ -662,11 +734,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 b_u[0] = ld4(xt + jl * kTLd + 4 * g); b_u[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_u[2] = ld4(xt + row2 * kTLd + 4 * g);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { xt[(4 * t + g) * kTLd + jl] = gf2b[t][0]; gsum[t] += gf2b[t][0]; }
+                for (int t = 0; t < 4; ++t) xt[(4 * t + g) * kTLd + jl] = gf2b[t][0];
                 __builtin_amdgcn_wave_barrier();
                 a_gf = ld4(xt + jl * kTLd + 4 * g);
                 __builtin_amdgcn_wave_barrier();
-                if (jl >= 4) b_u[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                gs16 += (a_gf.x + a_gf.y) + (a_gf.z + a_gf.w);
             }
             f32x4 de2[2][NC];
 #pragma unroll
@@ -700,7 +772,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         float h, s1, s2;
                         softplus100(aa[cc][q], h, s1, s2);
                         da[cc][q] = s1 * tt[cc][q];
-                        if (WG) {
+                        if (WG && !kProbeNoTrans) {
                             xt[(4 * g + q) * kTLd + jl] = da[cc][q];
                             xt[(32 + 4 * g + q) * kTLd + jl] = h;
                         }
@@ -722,16 +794,22 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         for (int cc = 0; cc < NC; ++cc) dex[cc] = mfma4(at, da[cc][q], dex[cc]);
                     }
                 }
-                if (WG) {
+                if (WG && !kProbeNoContract) {
                     __builtin_amdgcn_wave_barrier();
                     const float4 a_da = ld4(xt + jl * kTLd + 4 * g), b_h = ld4(xt + (32 + jl) * kTLd + 4 * g);
                     __builtin_amdgcn_wave_barrier();
-                    f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c2 = acc0[m][2], c3 = acc1[m];
-                    c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c2 = mfma4(a_da.x, b_u[2].x, c2); c3 = mfma4(a_gf.x, b_h.x, c3);
-                    c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c2 = mfma4(a_da.y, b_u[2].y, c2); c3 = mfma4(a_gf.y, b_h.y, c3);
-                    c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c2 = mfma4(a_da.z, b_u[2].z, c2); c3 = mfma4(a_gf.z, b_h.z, c3);
-                    c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c2 = mfma4(a_da.w, b_u[2].w, c2); c3 = mfma4(a_gf.w, b_h.w, c3);
-                    acc0[m][0] = c0; acc0[m][1] = c1; acc0[m][2] = c2; acc1[m] = c3;
+                    f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c3 = acc1[m];
+                    c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c3 = mfma4(a_gf.x, b_h.x, c3);
+                    c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c3 = mfma4(a_gf.y, b_h.y, c3);
+                    c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c3 = mfma4(a_gf.z, b_h.z, c3);
+                    c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c3 = mfma4(a_gf.w, b_h.w, c3);
+                    acc0[m][0] = c0; acc0[m][1] = c1; acc1[m] = c3;
+                    if (!kProbeNoPos) {
+                    pacc[m][0] = pos_col<0, false>(pacc[m][0], a_da, a_da, b_u[2], b_u[2]);
+                    pacc[m][1] = pos_col<1, false>(pacc[m][1], a_da, a_da, b_u[2], b_u[2]);
+                    pacc[m][2] = pos_col<2, false>(pacc[m][2], a_da, a_da, b_u[2], b_u[2]);
+                    pacc[m][3] = pos_col<3, false>(pacc[m][3], a_da, a_da, b_u[2], b_u[2]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -767,8 +845,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         }
     if constexpr (WG) {
         float* __restrict__ dst = (pass == 0 ? slot_sdf : slot_geo) + r * ((pass == 0 ? kRegsSdf : kRegsGeo) * 64) + lane;
-        if (pass == 0) wg_flush<false>(acc0, acc1, w1r0, gsum, s_w, dst, wave, n_waves, lane);
-        else wg_flush<true>(acc0, acc1, w1r0, gsum, s_w, dst, wave, n_waves, lane);
+        if (pass == 0) wg_flush<false>(acc0, acc1, pacc, w1p, gs16, g0s, s_w, dst, wave, n_waves, lane);
+        else wg_flush<true>(acc0, acc1, pacc, w1p, gs16, g0s, s_w, dst, wave, n_waves, lane);
     }
     }
     // per-ray bounds of the scatter contributions (max over the ray's samples), [level][ray]
