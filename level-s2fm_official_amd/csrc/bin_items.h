@@ -15,7 +15,11 @@ constexpr int kBins = kSlabBins;
 #endif
 constexpr int kCountThreads = LS2FM_FILL_TILE;
 constexpr int kFillThreads = LS2FM_FILL_TILE;    // one sample point per thread
-constexpr int kFillCap = kFillThreads * 17 / 4;       // items staged in LDS per workgroup (4 per point + split pairs)
+constexpr int kFillCap = kFillThreads * 17 / 4;       // items of a workgroup in the common case (4 per point + split pairs)
+#ifndef LS2FM_FILL_WIN
+#define LS2FM_FILL_WIN (LS2FM_FILL_TILE * 17 / 8)
+#endif
+constexpr int kFillWin = LS2FM_FILL_WIN;              // items staged in LDS per window pass of scatter_fill (two passes in the common case)
 #ifndef LS2FM_ACC_THREADS
 #define LS2FM_ACC_THREADS 1024
 #endif
@@ -231,6 +235,8 @@ struct ScanJob { BinMeta bm; int n_levels; };          // bm.tile == nullptr: no
 
 inline int* scan_ticket(const BinMeta& bm) { return reinterpret_cast<int*>(bm.level_bound) + 48; }
 __device__ __forceinline__ int* scan_ticket_dev(const BinMeta& bm) { return reinterpret_cast<int*>(bm.level_bound) + 48; }
+// unit counter of the persistent slab_accumulate launch (bin_scatter.hip): zeroed by the scatter_fill launch in front of it
+__host__ __device__ __forceinline__ int* acc_claim(const BinMeta& bm) { return reinterpret_cast<int*>(bm.level_bound) + 50; }
 
 __device__ __forceinline__ int wave_scan_incl_i32(int v, int lane) {
 #pragma unroll

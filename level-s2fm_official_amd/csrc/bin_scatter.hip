@@ -38,22 +38,40 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ fill
 // rpt[point] = {x y z gn0 | gn1 gn2 - -}; rec1[level][point] = {de0 de1 rr0 rr1}; rec2[level][point] = {de0 de1}
+// Round 5: the sorted items leave through a WINDOW of the workgroup's sorted order (kFillWin slots of LDS, as many passes as
+// the workgroup's item count needs: two at the benchmark) instead of one staging area for all of them: 22 KB instead of 41 KB
+// of LDS -- 7 workgroups per CU instead of 3 for a kernel that is a chain of round trips and barriers, not a throughput --
+// and no overflow path (any item count is served).  Every item's slot is fixed once (rank = LDS atomic) and kept in registers;
+// a window pass re-derives the item's indices (eight hashes) and stages the items whose slot falls into the window.  The
+// run offsets (two dependent global loads per slab) are requested at the very top, ahead of the records.
+#ifndef LS2FM_FILL_PROBE
+#define LS2FM_FILL_PROBE 0
+#endif
+#ifndef LS2FM_FILL_MINW
+#define LS2FM_FILL_MINW 1
+#endif
 template <bool DUAL>
-__global__ void __launch_bounds__(kFillThreads)
+__global__ void __launch_bounds__(kFillThreads, LS2FM_FILL_MINW)
 scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
                     int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
                     const float* __restrict__ rec2, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad,
-                    BinMeta bm, int level_base) {
+                    BinMeta bm, int level_base, int reverse) {
     typedef typename ItemOf<DUAL>::type ItemT;
     __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
-    __shared__ int lds_off[kBins];       // first LDS slot of the slab's run
+    __shared__ int lds_off[kBins];       // first slot (in the workgroup's sorted order) of the slab's run
     __shared__ int base[kBins];          // first global item index of the slab's run
     __shared__ int run_len[kBins];       // items of this workgroup in the slab's run
-    __shared__ ItemT s_items[kFillCap];
-    __shared__ uint32_t s_gidx[kFillCap];
+    constexpr int kWin = DUAL ? kFillWin : kFillCap;      // (single field, 20-byte items: one pass -- two measured 52 -> 57 us)
+    __shared__ ItemT s_items[kWin];
+    __shared__ uint32_t s_gidx[kWin];
     __shared__ int s_total;
     ItemT* __restrict__ g_items = reinterpret_cast<ItemT*>(bm.items);
-    const int tid = threadIdx.x, lane = tid & 63, l = level_base + (int)blockIdx.y;
+    // levels are walked last to first: the accumulate launch reads the lists first to last, i.e. most recently written first
+    const int tid = threadIdx.x, lane = tid & 63, l = level_base + (reverse ? (int)(gridDim.y - 1u - blockIdx.y) : (int)blockIdx.y);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *acc_claim(bm) = 0;      // unit counter of the accumulate launch behind this one
+    static_assert(kBins <= kFillThreads, "one thread per slab for the run offsets");
+    int pre_base = 0;
+    if (tid < kBins) pre_base = bm.start[l * kBins + tid] + bm.tile[((int64_t)l * bm.n_tiles + blockIdx.x) * kBins + tid];
     for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
     __syncthreads();
     const LevelC L = make_level_c(lv, l, sshift);
@@ -62,9 +80,14 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     uint32_t g[3] = {0u, 0u, 0u};
     float w[3] = {0.f, 0.f, 0.f}, d0 = 0.f, d1 = 0.f, r0 = 0.f, r1 = 0.f, e0 = 0.f, e1 = 0.f, qd[3] = {0.f, 0.f, 0.f};
     if (live) {
+#if (LS2FM_FILL_PROBE & 2)
+        const float fi = (float)(i % 977) * 1.0e-3f;      // timing probe: no record loads
+        const float4 a = make_float4(fi, 0.5f * fi + 0.1f, 0.3f, 0.1f), c = make_float4(0.2f, 0.3f, 0.f, 0.f), b = make_float4(fi, fi, 0.1f, 0.2f);
+#else
         const float4 a = reinterpret_cast<const float4*>(rpt)[2 * i];
         const float4 c = reinterpret_cast<const float4*>(rpt)[2 * i + 1];
         const float4 b = reinterpret_cast<const float4*>(rec1)[(int64_t)l * p_pad + i];
+#endif
         const float x[3] = {a.x, a.y, a.z};                 // the grid-normalised position the forward classified (same bits)
 #pragma unroll
         for (int q = 0; q < 3; ++q) pos_fract(x[q], L.scale, g[q], w[q]);
@@ -79,7 +102,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     const RunFlags rf = wave_runs(g, live, lane, DUAL ? kMergeMinDual : kMergeMinSingle);
     for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
     __syncthreads();
-    // runs: LDS offsets (exclusive prefix over the slabs, wave 0) and one global reservation per slab
+    // runs: offsets in the sorted order (exclusive prefix over the slabs, wave 0)
     if (tid < 64) {
         int run = 0;
 #pragma unroll
@@ -93,13 +116,11 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         if (lane == 0) s_total = run;
     }
     __syncthreads();
-    for (int b = tid; b < kBins; b += kFillThreads) {
-        const int n = hist[b];
-        base[b] = bm.start[l * kBins + b] + bm.tile[((int64_t)l * bm.n_tiles + blockIdx.x) * kBins + b];
-        run_len[b] = n;
+    if (tid < kBins) {                   // (slab tid: this thread is its only reader and writer here)
+        run_len[tid] = hist[tid];
+        base[tid] = pre_base;
+        hist[tid] = 0;
     }
-    __syncthreads();
-    for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
     __syncthreads();
     // per corner pair c = by + 2 bz: the factored payload (A, B[, C]) and the two x-corners' explicit values
     //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
@@ -133,30 +154,19 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         }
     }
     if (rf.cont != 0ull) run_sums<NV>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
-    for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
-        constexpr int S = DUAL ? 8 : 4;
-        ItemT it;
-        it.ij = i0 | (i1 << 16);
-        if constexpr (DUAL) {
-            if (rf.merged) {               // half item of a merged run: the summed values of ONE x-corner, wx = 0 / 1, B = 0
-                const bool second = i0 == 0xFFFFu;
-                it.wx = second ? 1.0f : 0.0f;
-                it.a0 = val[S * c + (second ? 2 : 0)];
-                it.a1 = val[S * c + (second ? 3 : 1)];
-                it.b0 = 0.f;
-                it.b1 = 0.f;
-                it.c0 = val[S * c + (second ? 6 : 4)];
-                it.c1 = val[S * c + (second ? 7 : 5)];
-            } else {
-                it.wx = w[0];
-                it.a0 = fa[c][0]; it.a1 = fa[c][1];
-                it.b0 = fb[c][0]; it.b1 = fb[c][1];
-                it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
-            }
-        } else {
-            it.v00 = val[S * c + 0]; it.v01 = val[S * c + 1];
-            it.v10 = val[S * c + 2]; it.v11 = val[S * c + 3];
-        }
+    // every item's slot in the workgroup's sorted order: slot_a[c] = the pair's item (or its first half), slot_b[c] = its second half
+    // (named scalars, 16 bits per slot: as arrays indexed by the lambda's pair number they went to scratch memory)
+    uint32_t sl0 = 0u, sl1 = 0u, sl2 = 0u, sl3 = 0u;
+    auto put_slot = [&](unsigned c, bool second, int slot) {
+        const uint32_t v = second ? (uint32_t)slot << 16 : (uint32_t)slot;
+        if (c == 0) sl0 |= v; else if (c == 1) sl1 |= v; else if (c == 2) sl2 |= v; else sl3 |= v;
+    };
+    auto get_slot = [&](unsigned c, bool second) {
+        const uint32_t v = c == 0 ? sl0 : (c == 1 ? sl1 : (c == 2 ? sl2 : sl3));
+        return (int)(second ? v >> 16 : v & 0xFFFFu);
+    };
+    static_assert(kFillThreads * 8 <= 0xFFFF, "slots fit 16 bits");
+    for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned c, uint32_t i0, uint32_t) {
         int rank = atomicAdd(&hist[slab], 1);
         // long runs (coarse levels: consecutive samples of a ray fall into the same cell) are stored permuted, so that
         // the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same entry (same-address
@@ -164,14 +174,48 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         const int n_run = run_len[slab];
         if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
         const int slot = lds_off[slab] + rank;
-        const uint32_t gi = (uint32_t)(base[slab] + rank);
-        if (slot < kFillCap) { s_items[slot] = it; s_gidx[slot] = gi; }
-        else g_items[gi] = it;                          // more split pairs than the staging area holds: direct write
+        put_slot(c, i0 == 0xFFFFu, slot);
     });
-    __syncthreads();
-    // runs of one slab are contiguous in LDS and in memory: consecutive threads write consecutive items
-    const int staged = s_total < kFillCap ? s_total : kFillCap;
-    for (int q = tid; q < staged; q += kFillThreads) g_items[s_gidx[q]] = s_items[q];
+    const int total = s_total;
+    for (int win = 0; win < total; win += kWin) {
+        if (win > 0) __syncthreads();                     // the previous window has been written out
+        for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
+            constexpr int S = DUAL ? 8 : 4;
+            const int rel = get_slot(c, i0 == 0xFFFFu) - win;
+            if (rel < 0 || rel >= kWin) return;
+            ItemT it;
+            it.ij = i0 | (i1 << 16);
+            if constexpr (DUAL) {
+                if (rf.merged) {               // half item of a merged run: the summed values of ONE x-corner, wx = 0 / 1, B = 0
+                    const bool second = i0 == 0xFFFFu;
+                    it.wx = second ? 1.0f : 0.0f;
+                    it.a0 = val[S * c + (second ? 2 : 0)];
+                    it.a1 = val[S * c + (second ? 3 : 1)];
+                    it.b0 = 0.f;
+                    it.b1 = 0.f;
+                    it.c0 = val[S * c + (second ? 6 : 4)];
+                    it.c1 = val[S * c + (second ? 7 : 5)];
+                } else {
+                    it.wx = w[0];
+                    it.a0 = fa[c][0]; it.a1 = fa[c][1];
+                    it.b0 = fb[c][0]; it.b1 = fb[c][1];
+                    it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
+                }
+            } else {
+                it.v00 = val[S * c + 0]; it.v01 = val[S * c + 1];
+                it.v10 = val[S * c + 2]; it.v11 = val[S * c + 3];
+            }
+            s_items[rel] = it;
+            s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
+        });
+        __syncthreads();
+        // runs of one slab are contiguous in the sorted order and in memory: consecutive threads write consecutive items
+        const int staged = total - win < kWin ? total - win : kWin;
+#if (LS2FM_FILL_PROBE & 1)
+        if (staged < 0)                    // timing probe: no item stores
+#endif
+        for (int q = tid; q < staged; q += kFillThreads) g_items[s_gidx[q]] = s_items[q];
+    }
     // the level's first workgroup also reduces the per-ray bounds of a single contribution (written by shade_bwd) to the
     // level's bound: the accumulate workgroups read two floats instead of n_rays each
     if (blockIdx.x == 0) {
@@ -378,6 +422,285 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ accumulate, persistent
+// Round 5.  Per-slab stamps of the kernel above (profiles/r04_acc_stamps.txt): 4.8 us prologue (dispatch of a 1024-thread /
+// 128 KB workgroup, two dependent scalar loads, the first item loads' round trip, 128 KB of LDS to zero) + 4.2 us of LDS atomics
+// + 1.4 us flush: more than half of a hashed slab's workgroup is latency nothing overlaps, because a 128 KB workgroup is alone on
+// its CU.  Here ONE workgroup per CU stays resident and walks slabs ("units", claimed from a counter: the units differ 4x in
+// length):
+//   * the item loads form one continuous stream of batches across unit boundaries -- while a unit's last batch is being added,
+//     the NEXT unit's first batch is already in flight (its meta was read one unit ahead, the unit after that is being claimed);
+//   * the flush clears the accumulators it reads: the LDS is zeroed once per workgroup, not once per slab;
+//   * barriers wait for the LDS only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also drain the prefetched loads.
+// The sums are the same exactly rounded integers in any order: results are bit-identical to the kernel above.
+struct AccUnit {
+    int l, part, parts, wg, n_items, j_lo, j_hi, uid;  // l < 0: no unit
+    uint32_t slab;
+    float bound1, bound2;                              // the level's bounds of a single contribution (read a unit ahead)
+    const void* list;
+};
+
+#ifndef LS2FM_ACC_NT
+#define LS2FM_ACC_NT 0
+#endif
+// an item of a slab's list (read exactly once, by one workgroup): optionally as non-temporal loads
+__device__ __forceinline__ Item load_item(const Item* p) {
+#if LS2FM_ACC_NT
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    union { u32x4 q[2]; Item it; } u;
+    u.q[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    u.q[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + 1);
+    return u.it;
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ ItemS load_item(const ItemS* p) {
+#if LS2FM_ACC_NT
+    union { uint32_t w[5]; ItemS it; } u;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) u.w[q] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p) + q);
+    return u.it;
+#else
+    return *p;
+#endif
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the same barrier, also completing the scalar loads of acc_unit_fetch<.., ASYNC = true> (they count in lgkmcnt): the values
+// pass through the statement, so that nothing consuming them can be scheduled in front of it
+__device__ __forceinline__ void acc_unit_arrive(int& count, int& start, float& b1, float& b2) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(count), "+s"(start), "+s"(b1), "+s"(b2) :: "memory");
+}
+
+// A unit's descriptor in two steps: acc_unit_fetch issues the four loads (item count and list start of the slab, the level's
+// bounds), acc_unit_finish consumes them -- the persistent kernel puts a slab's flush between the two.
+struct AccUnitRaw { int l, wg, parts, slab, count, start, uid; float bound1, bound2; };
+
+template <bool DUAL, bool ASYNC>
+__device__ __forceinline__ AccUnitRaw acc_unit_fetch(const SlabPlan& plan, const BinMeta& bm, int block_base, int unit, int n_units) {
+    AccUnitRaw r;
+    r.l = -1; r.wg = 0; r.parts = 1; r.slab = 0; r.count = 0; r.start = 0; r.uid = 0; r.bound1 = r.bound2 = 0.f;
+    if (unit >= n_units) return r;
+    const int bid = block_base + unit;
+    r.uid = bid;
+    // level of the unit: plan.first is non-decreasing (levels beyond the grid's start at the total) -- counted, not searched (a
+    // search is up to 16 DEPENDENT scalar loads from the kernel arguments, ~1.5 us per unit)
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q <= LS2FM_MAX_LEVELS; ++q) l += bid >= plan.first[q] ? 1 : 0;
+    r.l = l;
+    r.parts = plan.parts[l];
+    r.wg = bid - plan.first[l];
+    r.slab = r.parts == 1 ? r.wg : __builtin_amdgcn_readfirstlane(r.wg / r.parts);      // (the division runs on the vector ALU)
+    const int* pc = bm.count + l * kBins + r.slab;
+    const int* ps = bm.start + l * kBins + r.slab;
+    const float* pb = bm.level_bound + l;
+    if (ASYNC) {
+        // SCALAR loads issued by hand and not waited for here: acc_unit_arrive (s_waitcnt lgkmcnt(0), the barrier behind the flush)
+        // completes them.  As compiler-issued loads they were vector loads (the kernel writes global memory: no scalar-load
+        // proof), either turned into scalar registers on the spot -- a round trip in FRONT of the flush -- or, kept in vector
+        // registers, waited for behind the flush's stores, which share vmcnt with them.  The values were written by earlier
+        // launches: the scalar cache cannot hold stale copies.
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(r.count) : "s"(pc) : "memory");
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(r.start) : "s"(ps) : "memory");
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(r.bound1) : "s"(pb) : "memory");
+        if (DUAL) asm volatile("s_load_dword %0, %1, 0x40" : "=s"(r.bound2) : "s"(pb) : "memory");
+    } else {
+        r.count = *pc;
+        r.start = *ps;
+        r.bound1 = pb[0];
+        r.bound2 = DUAL ? pb[16] : 0.f;
+    }
+    return r;
+}
+
+template <typename ItemT>
+__device__ __forceinline__ AccUnit acc_unit_finish(const AccUnitRaw& r, const BinMeta& bm) {
+    AccUnit u;
+    u.l = r.l; u.parts = r.parts; u.wg = r.wg; u.slab = (uint32_t)r.slab; u.part = r.wg % r.parts; u.uid = r.uid;
+    u.n_items = r.count; u.bound1 = r.bound1; u.bound2 = r.bound2;
+    u.list = reinterpret_cast<const ItemT*>(bm.items) + r.start;
+    if (u.parts == 1) { u.j_lo = 0; u.j_hi = u.n_items; }
+    else {            // floor(n part / parts) without a 64-bit division: n = q parts + r
+        const uint32_t q = (uint32_t)u.n_items / (uint32_t)u.parts, rem = (uint32_t)u.n_items % (uint32_t)u.parts;
+        u.j_lo = (int)(q * (uint32_t)u.part + rem * (uint32_t)u.part / (uint32_t)u.parts);
+        u.j_hi = (int)(q * (uint32_t)(u.part + 1) + rem * (uint32_t)(u.part + 1) / (uint32_t)u.parts);
+    }
+    return u;
+}
+
+#ifndef LS2FM_ACC_PROBE
+#define LS2FM_ACC_PROBE 0
+#endif
+#ifdef LS2FM_STAMPS
+#define PACC_STAMP(uid, k) do { if (threadIdx.x == 0 && (uid) < 4096) g_acc_stamps[8 * (uid) + (k)] = wall_clock64(); } while (0)
+#else
+#define PACC_STAMP(uid, k) do {} while (0)
+#endif
+
+template <bool DUAL, bool ADD_INTO>
+__global__ void __launch_bounds__(kAccThreads)
+slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
+                                  float* __restrict__ dtable2, int block_base, int n_units, int combine, int* __restrict__ claim) {
+    typedef typename ItemOf<DUAL>::type ItemT;
+    constexpr int F = DUAL ? 4 : 2;
+    constexpr int BT = kAccBatch * kAccThreads;
+    __shared__ __attribute__((aligned(16))) u64 acc[kAccSlots];
+    __shared__ int s_claim;
+    const int tid = threadIdx.x;
+    const int G = (int)gridDim.x;
+    const int E = 1 << sshift;
+    // units 0 .. 2G-1 are handed out statically (b, G + b), the rest through the counter (zeroed by scatter_fill's first workgroup)
+    AccUnit cur = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, (int)blockIdx.x, n_units), bm);
+    AccUnit nxt = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, G + (int)blockIdx.x, n_units), bm);
+    ItemT buf[kAccBatch];
+    {
+        const ItemT* __restrict__ list = reinterpret_cast<const ItemT*>(cur.list);
+        const int j_last = cur.j_hi > cur.j_lo ? cur.j_hi - 1 : cur.j_lo;
+#pragma unroll
+        for (int u = 0; u < kAccBatch; ++u) {
+            const int j = cur.j_lo + tid + u * kAccThreads;
+            buf[u] = load_item(list + (j < cur.j_hi ? j : j_last));
+        }
+    }
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int e = tid; e < kAccSlots / 2; e += kAccThreads) reinterpret_cast<uint4*>(acc)[e] = z;
+    }
+    lds_barrier();
+    while (cur.l >= 0) {
+        // the unit after the next: claimed now, read behind this unit's streaming phase
+        int claimed = 0;
+        const int l = cur.l;
+        PACC_STAMP(cur.uid, 0);
+        float to_fixed1, to_fixed2;
+        double to_float1, to_float2;
+        quantum_of(cur.bound1, plan.headroom_bits, to_fixed1, to_float1);
+        quantum_of(cur.bound2, plan.headroom_bits, to_fixed2, to_float2);
+        auto add_item = [&](const ItemT& it) {
+            const uint32_t i0 = it.ij & 0xFFFFu, i1 = it.ij >> 16;
+            if constexpr (DUAL) {
+                const float px0 = 1.0f - it.wx;
+                if (i0 != 0xFFFFu) {
+                    u64* slot = acc + i0;
+                    add_fixed(slot, fmaf(px0, it.a0, -it.b0), to_fixed1);
+                    add_fixed(slot + E, fmaf(px0, it.a1, -it.b1), to_fixed1);
+                    add_fixed(slot + 2 * E, px0 * it.c0, to_fixed2);
+                    add_fixed(slot + 3 * E, px0 * it.c1, to_fixed2);
+                }
+                if (i1 != 0xFFFFu) {
+                    u64* slot = acc + i1;
+                    add_fixed(slot, fmaf(it.wx, it.a0, it.b0), to_fixed1);
+                    add_fixed(slot + E, fmaf(it.wx, it.a1, it.b1), to_fixed1);
+                    add_fixed(slot + 2 * E, it.wx * it.c0, to_fixed2);
+                    add_fixed(slot + 3 * E, it.wx * it.c1, to_fixed2);
+                }
+            } else {
+                if (i0 != 0xFFFFu) {
+                    add_fixed(acc + i0, it.v00, to_fixed1);
+                    add_fixed(acc + E + i0, it.v01, to_fixed1);
+                }
+                if (i1 != 0xFFFFu) {
+                    add_fixed(acc + i1, it.v10, to_fixed1);
+                    add_fixed(acc + E + i1, it.v11, to_fixed1);
+                }
+            }
+        };
+        // ---- streaming: batches of this unit; behind the last one the first batch of the next unit is requested
+        int b0 = cur.j_lo;
+        do {
+            ItemT now[kAccBatch];
+#pragma unroll
+            for (int u = 0; u < kAccBatch; ++u) now[u] = buf[u];
+            const bool more = b0 + BT < cur.j_hi;                       // (uniform)
+            const ItemT* __restrict__ list_n = reinterpret_cast<const ItemT*>(more ? cur.list : nxt.list);
+            const int lo_n = more ? b0 + BT : nxt.j_lo, hi_n = more ? cur.j_hi : nxt.j_hi;
+            const int last_n = hi_n > lo_n ? hi_n - 1 : lo_n;
+#pragma unroll
+            for (int u = 0; u < kAccBatch; ++u) {                        // unconditional loads, masked where they are used
+                const int j = lo_n + tid + u * kAccThreads;
+                buf[u] = load_item(list_n + (j < hi_n ? j : last_n));
+            }
+            // The claim: lane 0 of wave 0, issued WITHOUT waiting for the returned value (as a builtin under `if (tid == 0)` the
+            // compiler waits for it at the end of the branch: one memory round trip per unit in front of wave 0's adds), BEHIND
+            // the batch loads just issued: every vmcnt the compiler computes for loads older than the atomic is merely one too
+            // strict, and loads younger than it complete after it (in-order return) -- its bookkeeping stays valid.
+            if (tid < 64 && b0 == cur.j_lo) {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %1, exec\n\t"
+                             "s_mov_b64 exec, 1\n\t"
+                             "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+                             "s_mov_b64 exec, %1"
+                             : "=&v"(claimed), "=&s"(saved) : "v"(0), "v"(1), "s"(claim) : "memory");
+            }
+#if (LS2FM_ACC_PROBE & 1)
+            if (now[0].ij == 0x12345678u)        // timing probe: (almost) no LDS atomics
+#endif
+#pragma unroll
+            for (int u = 0; u < kAccBatch; ++u)
+                if (b0 + tid + u * kAccThreads < cur.j_hi) add_item(now[u]);
+            b0 += BT;
+        } while (b0 < cur.j_hi);
+        PACC_STAMP(cur.uid, 1);
+        if (tid < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) :: "memory");
+            if (tid == 0) s_claim = claimed;
+        }
+        lds_barrier();
+        PACC_STAMP(cur.uid, 2);
+        AccUnitRaw nraw = acc_unit_fetch<DUAL, true>(plan, bm, block_base, 2 * G + __builtin_amdgcn_readfirstlane(s_claim), n_units);
+        // ---- flush + clear
+        const uint32_t size = lv.size[l];
+        const uint32_t lo = cur.slab << sshift;
+        const uint32_t hi = lo + (1u << sshift) < size ? lo + (1u << sshift) : size;
+        if (cur.parts > 1 && combine) {          // partials for slab_combine_kernel (ADD_INTO: an empty slab's are never read)
+            if (!(ADD_INTO && cur.n_items == 0)) {
+                uint4* mine = reinterpret_cast<uint4*>(bm.part_acc + (size_t)(plan.scratch[l] + cur.wg) * kAccSlots);
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                for (int e = tid; e < kAccSlots / 2; e += kAccThreads) {
+                    mine[e] = reinterpret_cast<const uint4*>(acc)[e];
+                    reinterpret_cast<uint4*>(acc)[e] = z;
+                }
+            }
+        } else if (!(ADD_INTO && cur.n_items == 0)) {
+            float* dst1 = dtable1 + 2ull * (lv.offset[l] + lo);
+            float* dst2 = DUAL ? dtable2 + 2ull * (lv.offset[l] + lo) : nullptr;
+            for (int entry = tid; entry < (int)(hi - lo); entry += kAccThreads) {
+                u64 tot[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) { tot[f] = acc[f * E + entry]; acc[f * E + entry] = 0ull; }
+                float2 v1 = make_float2((float)((double)(long long)tot[0] * to_float1), (float)((double)(long long)tot[1] * to_float1));
+                float* d1 = dst1 + 2 * entry;
+                if (cur.parts > 1) {
+                    if (tot[0] != 0ull) atomicAdd(d1, v1.x);
+                    if (tot[1] != 0ull) atomicAdd(d1 + 1, v1.y);
+                } else if (ADD_INTO) {
+                    if ((tot[0] | tot[1]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d1); v1.x += o.x; v1.y += o.y; *reinterpret_cast<float2*>(d1) = v1; }
+                } else *reinterpret_cast<float2*>(d1) = v1;
+                if constexpr (DUAL) {
+                    float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
+                    float* d2 = dst2 + 2 * entry;
+                    if (cur.parts > 1) {
+                        if (tot[2] != 0ull) atomicAdd(d2, v2.x);
+                        if (tot[3] != 0ull) atomicAdd(d2 + 1, v2.y);
+                    } else if (ADD_INTO) {
+                        if ((tot[2] | tot[3]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d2); v2.x += o.x; v2.y += o.y; *reinterpret_cast<float2*>(d2) = v2; }
+                    } else *reinterpret_cast<float2*>(d2) = v2;
+                }
+            }
+        }
+        PACC_STAMP(cur.uid, 3);
+#ifdef LS2FM_STAMPS
+        if (tid == 0 && cur.uid < 4096) { g_acc_stamps[8 * cur.uid + 4] = l; g_acc_stamps[8 * cur.uid + 5] = cur.j_hi - cur.j_lo; g_acc_stamps[8 * cur.uid + 7] = blockIdx.x; }
+#endif
+        acc_unit_arrive(nraw.count, nraw.start, nraw.bound1, nraw.bound2);
+        PACC_STAMP(cur.uid, 6);
+        cur = nxt;
+        nxt = acc_unit_finish<ItemT>(nraw, bm);
+    }
+}
+
 // ---- the point-split slabs' partials -> table entries (combine form).  Block = 1024 entries of one split slab.
 struct CombinePlan { int first[LS2FM_MAX_LEVELS + 1]; };      // first block of every level (levels with parts == 1: none)
 
@@ -468,8 +791,10 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
     if (level_hi < 0) level_hi = grid->n_levels;
     if (level_hi <= level_lo) return LS2FM_OK;
     const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo));
-    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo);
-    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo);
+    // (most recently written lists are read first: slab_accumulate 101 -> 98 us at C2; LS2FM_FILL_REVERSE=0 for the A/B)
+    static const int reverse = [] { const char* e = getenv("LS2FM_FILL_REVERSE"); return e ? atoi(e) : 1; }();
+    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo, reverse);
+    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo, reverse);
     return ls2fm_launch_status();
 }
 
@@ -556,7 +881,23 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     if (level_hi < 0) level_hi = grid->n_levels;
     const int base = h.plan.first[level_lo], blocks = h.plan.first[level_hi] - base;
     if (blocks <= 0) return LS2FM_OK;
-    if (dual)
+    // persistent form (default): one resident workgroup per CU walks the units; LS2FM_ACC_PERSISTENT=0: a workgroup per unit
+    static const int persistent = [] { const char* e = getenv("LS2FM_ACC_PERSISTENT"); return e ? atoi(e) : 1; }();
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    if (persistent) {
+        const int g = blocks < n_cus ? blocks : n_cus;
+        int* claim = acc_claim(bm);
+        if (dual)
+            (add_into ? slab_accumulate_persistent_kernel<true, true> : slab_accumulate_persistent_kernel<true, false>)<<<g, kAccThreads, 0, stream>>>(
+                lv, h.plan, bm, sshift, dtable1, dtable2, base, blocks, combine, claim);
+        else
+            (add_into ? slab_accumulate_persistent_kernel<false, true> : slab_accumulate_persistent_kernel<false, false>)<<<g, kAccThreads, 0, stream>>>(
+                lv, h.plan, bm, sshift, dtable1, nullptr, base, blocks, combine, claim);
+    } else if (dual)
         (add_into ? slab_accumulate_kernel<true, true> : slab_accumulate_kernel<true, false>)<<<blocks, kAccThreads, 0, stream>>>(
             lv, h.plan, bm, sshift, dtable1, dtable2, base, combine);
     else

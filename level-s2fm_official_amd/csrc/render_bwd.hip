@@ -172,6 +172,10 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // the one fork of the backward: weight-gradient GEMMs -> reduce -> finalize run on the side stream, beside the table scatters
     forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
+    // The side chain is enqueued IN FRONT of the scatter.  (Behind it -- LS2FM_SIDE_FIRST=0, tried in round 5 now that the chain is
+    // short: the scatter then keeps shade_bwd's hardware queue in a hipGraph replay -- measured 0.526 against 0.509 ms per step.)
+    static const int side_first = [] { const char* e = getenv("LS2FM_SIDE_FIRST"); return e ? atoi(e) : 1; }();
+    auto launch_side = [&]() -> int {
     Ls2fmWgradParts parts{};
     if (ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts, db ? &extra : nullptr,
                                fused_wgrad) != LS2FM_OK)
@@ -186,6 +190,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     }
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return fail(forked, sc, LS2FM_ERR_LAUNCH);
+    return LS2FM_OK;
+    };
+    if (side_first) { const int st = launch_side(); if (st != LS2FM_OK) return st; }
 
     // hash-table gradients: payloads sorted by slab (scatter_fill), then one streaming pass per LDS-owned slab
     // (slab_accumulate; bin_scatter.hip); tables overwritten in full; dual field: both grids share geometry, hence items.
@@ -194,6 +201,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // tables while the later groups are still being scattered.
     {
         int groups = opts ? opts->n_level_groups : 1;
+        static const int groups_env = [] { const char* e = getenv("LS2FM_LEVEL_GROUPS"); return e ? atoi(e) : 0; }();
+        if (groups <= 1 && groups_env > 1 && !db) groups = groups_env;       // (measurement switch: no events, same results)
         groups = groups < 1 ? 1 : (groups > LS2FM_MAX_LEVEL_GROUPS ? LS2FM_MAX_LEVEL_GROUPS : groups);
         if (groups > L1) groups = L1;
         for (int gi = 0; gi < groups; ++gi) {
@@ -212,6 +221,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
                 return fail(forked, sc, LS2FM_ERR_LAUNCH);
         }
     }
+    if (!side_first) { const int st = launch_side(); if (st != LS2FM_OK) return st; }
     if (db) {
         // the tracing's table gradient, added into the table the scatter above has just written: behind it (an event when the
         // branch has a stream of its own)
