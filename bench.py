@@ -191,11 +191,14 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce after the backward instead of the "
                     "level-group reductions issued from inside it")
     ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
-    ap.add_argument("--exchange", choices=("shard", "allreduce"), default="shard",
-                    help="N > 1: how the ranks exchange a step's gradients.  shard (default): reduce-scatter of the flat gradient "
-                         "buffer -> Adam on this rank's 1/N of the parameters (ls2fm.dist.ShardedAdam) -> all-gather of the updated "
-                         "shards; allreduce: sum all-reduce of the gradients, no update in the step (--no-shard)")
+    ap.add_argument("--exchange", choices=("shard", "allreduce"), default="allreduce",
+                    help="N > 1: how the ranks exchange a step's gradients.  allreduce (default; BASELINE.json's step: fwd + bwd + "
+                         "RCCL sum all-reduce of the flat gradient buffer, no optimizer in the step -- like for like with the N = 1 "
+                         "line, launched the same way: eager with the level-group overlap, or one hipGraph replay); shard: "
+                         "reduce-scatter -> Adam on this rank's 1/N of the parameters (ls2fm.dist.ShardedAdam) -> all-gather of the "
+                         "updated shards: the step then CONTAINS the update (`update_in_step: true` in the line)")
     ap.add_argument("--no-shard", dest="exchange", action="store_const", const="allreduce")
+    ap.add_argument("--shard", dest="exchange", action="store_const", const="shard")
     ap.add_argument("--shard-groups", type=int, default=1,
                     help="N > 1, --exchange shard: level groups of the PIPELINED exchange (per group, issued from inside the backward: "
                          "reduce-scatter -> Adam on this rank's slice -> all-gather); 1 (default: the form that measured faster on a one-rank RCCL group, "
@@ -311,15 +314,17 @@ def main():
         return loss
 
     mode = "graph" if args.graph else args.launch
-    if multi and mode != "graph":
-        mode = "eager"                  # N > 1 default: eager.  `--launch graph` captures the WHOLE sharded step -- render, the
-                                        # RCCL collectives on the communication stream, the sharded update -- into one hipGraph
-                                        # (measured with a one-rank RCCL group: 0.79 -> 0.74 ms/step; opt-in until it has run
-                                        # on a real multi-GPU node)
+    if shard and mode != "graph":
+        mode = "eager"                  # sharded exchange: eager unless asked.  `--launch graph` captures the WHOLE sharded step --
+                                        # render, the RCCL collectives, the sharded update -- into one hipGraph (measured with a
+                                        # one-rank RCCL group: 0.79 -> 0.74 ms/step)
     if local_opt is not None:
-        mode = "eager"                  # the like-for-like N = 1 point of the eager N > 1 lines
-    if reducer is not None and mode == "graph":
-        mode = "eager"                  # the all-reduce form issues async collectives with host-side waits: not captured
+        mode = "eager"                  # the like-for-like N = 1 point of the eager sharded lines
+    if multi and backend != "nccl":
+        mode = "eager"                  # (gloo moves device tensors through the host: nothing a hipGraph could record)
+    # all-reduce form (the default): launched like the N = 1 line -- `auto` probes eager (level-group reductions issued from
+    # inside the backward, beside the scatter of the later groups) against ONE hipGraph replay of render + all-reduce of the flat
+    # gradient buffer (RCCL's kernels are recorded into the graph; no overlap inside a capture, ls2fm.fused)
     # every step -- eager or captured -- runs on ONE non-default stream: autograd's gradient accumulators stay tied to
     # the stream of their first backward, and mixing streams costs synchronisations (and breaks captures)
     s_main = torch.cuda.Stream(device=dev)
@@ -328,18 +333,18 @@ def main():
     use_graph = False
 
     def whole_step():
-        """what a graph captures: the render step and, under the sharded exchange, the exchange + update behind it"""
+        """what a graph captures: the render step and the gradient exchange behind it (sharded form: + the update)"""
         render_step()
         if sharded_opt is not None:
             sharded_opt.step()
+        if reducer is not None:
+            reducer.all_reduce()
 
     def step(eager=False):
         if use_graph and not eager:
             captured.replay()
         else:
             whole_step()
-        if reducer is not None:
-            reducer.all_reduce()
         if local_opt is not None:
             local_opt.step()
 
@@ -411,7 +416,9 @@ def main():
                              "the backward" if shard and sharded_opt.n_groups > 1 else "reduce-scatter + sharded Adam + all-gather") if shard else
                             ("all-reduce" if args.no_overlap else f"all-reduce, {args.overlap_groups} level groups overlapped with the backward"),
                     "gradient_bytes": flat_bytes, "bytes_on_wire_per_gpu": 2 * (world - 1) / world * flat_bytes}
-        if (shard and sharded_opt.n_groups <= 1) or (not shard and args.no_overlap):
+        if not shard:
+            exchange["form"] = ("all-reduce of the flat gradient buffer inside the captured step" if use_graph else exchange["form"])
+        if (shard and sharded_opt.n_groups <= 1) or (not shard and (args.no_overlap or use_graph)):
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -496,6 +503,8 @@ def main():
         # inside); its cost is measured here, after the timed region: the paired Adam job that also writes the copy against the
         # two plain jobs (learning rate 0: the weights do not move).
         out["mirror_upkeep"] = {"in_timed_region": local_opt is not None, "adam_pair_extra_us": mirror_upkeep_us(sdf, rad, dev)}
+        # the training-relevant figure one field away: a step of a training loop also pays the copy's upkeep (in its optimizer pass)
+        out["ms_per_step_incl_mirror_upkeep"] = ms_per_step + (0.0 if local_opt is not None else out["mirror_upkeep"]["adam_pair_extra_us"] * 1e-3)
     if rank == 0:
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:

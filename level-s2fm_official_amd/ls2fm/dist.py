@@ -544,14 +544,23 @@ class ShardedAdam:
             # every .grad still a view of it at this optimizer's offsets)
             flat_now = getattr(self.params[0], "_ls2fm_grad_flat", None)
             base = None if flat_now is None else flat_now.data_ptr()
-            if flat_now is not pp["inflight"] or any(
+            inflight, pp["inflight"] = pp["inflight"], None     # (kept until here: wait_params() between backward and step() is legal)
+            if flat_now is not inflight or any(
                     p.grad is None or getattr(p, "_ls2fm_grad_flat", None) is not flat_now or p.grad.data_ptr() != base + 4 * o
                     for p, o in zip(self.params, self.offsets)):
                 raise RuntimeError("ls2fm.dist.ShardedAdam(n_groups >= 2): the fused render must be the only gradient producer of a "
                                    "step whose exchange is issued from inside its backward; this step accumulated gradients from "
-                                   "another node.  Use n_groups=1 for such steps")
+                                   "another node.  Use n_groups=1 (or in_backward=False) for such steps.  NOTE: the update of this "
+                                   "step has already run inside the backward, from the render's gradients alone -- the parameters "
+                                   "are modified; restore them from a checkpoint if the step must not count")
         else:                                                  # gradients from elsewhere (composed form, several nodes): same
-            flat_g = self._flat_gradient()                     # per-group chain, issued now
+            # per-group chain, issued now.  (round-4 advisor) In-place all-reduces a fused backward launched itself
+            # (enable_table_overlap combined with this optimizer) must not be in flight on the buffer that is scattered next --
+            # the same guard as the monolithic step()
+            if _pending_of(self.params):
+                raise RuntimeError("ls2fm.dist.ShardedAdam: enable_table_overlap() launches all-reduces of the gradient buffer; use one "
+                                   "exchange or the other")
+            flat_g = self._flat_gradient()
             dev = self.flat.device
             if self.flat.is_cuda and not torch.cuda.is_current_stream_capturing():
                 cur, comm = torch.cuda.current_stream(dev), comm_stream(dev)
@@ -621,7 +630,8 @@ class ShardedAdam:
         if self._pipe is not None and self._pipe["done"] is not None:
             torch.cuda.current_stream(self.flat.device).wait_event(self._pipe["done"])     # device-side wait: the host goes on
             self._pipe["done"] = None
-            self._pipe["inflight"] = None
+            if not self._pipe["launched"]:                     # (an exchange step() has not consumed yet keeps its identity)
+                self._pipe["inflight"] = None
 
     def _flat_gradient(self):
         """the flat gradient buffer the fused backward wrote (every .grad a view at this optimizer's offsets), else a packed copy"""

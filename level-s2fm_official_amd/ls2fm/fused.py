@@ -525,8 +525,11 @@ class _Render(torch.autograd.Function):
         # multi-GPU: scatter the levels in groups and all-reduce a group's table slices while the next group is scattered
         from . import dist as _dist
         n_groups = int(getattr(ps[0], "_ls2fm_overlap_groups", 0)) if _dist.is_distributed() else 0
-        if n_groups > 1 and getattr(ps[0], "_ls2fm_group_exchange", None) is not None and torch.cuda.is_current_stream_capturing():
-            n_groups = 0                           # (captured steps: the optimizer issues its chain at step(), ls2fm.dist)
+        if n_groups > 1 and torch.cuda.is_current_stream_capturing():
+            # captured steps: a pipelined sharded optimizer issues its chain at step(), a GradAllReducer reduces the flat buffer
+            # as one message on the capturing stream (ls2fm.dist) -- a communication-stream branch that forks again into RCCL's
+            # own stream is the depth-three fork tree that takes a capture down on ROCm 7.2
+            n_groups = 0
         if n_groups > 1 and getattr(ps[0], "_ls2fm_group_exchange", None) is not None and fl is not None and fl.depth_node is not None:
             # a traced-depth node rides in this backward (ls2fm_depth_backward adds into the tables BEHIND the scatter: a group's
             # slices would not be final at its event): a pipelined sharded optimizer then exchanges at its step() instead
@@ -564,14 +567,20 @@ class _Render(torch.autograd.Function):
                                    ptr(ctx.ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_bwd")
         if keep is not None:
             d_dref = None                              # consumed inside the call: the tracing node gets no gradient through autograd
-        if not events:
-            _publish_pass_gradients(ps, flat)          # (level groups: reductions of `flat` are already in flight -- no late adds)
+        exchanging = False
         if events:
             tables = [grads[0]] + ([grads[_RAD_TABLE_AT]] if dual else [])
-            # a pipelined sharded optimizer takes the groups itself (reduce-scatter -> Adam -> all-gather per group); else all-reduces
+            # a pipelined sharded optimizer takes the groups itself (reduce-scatter -> Adam -> all-gather per group); else all-reduces.
+            # A hook that DECLINES (another layout, a capture) exchanges everything at its step(): nothing is launched here then
+            # (round-4 advisor: falling through to the all-reduce form summed the gradients twice)
             hook = getattr(ps[0], "_ls2fm_group_exchange", None)
-            if hook is None or not hook(flat, tables, list(g1.offset), events, g1.n_levels):
+            if hook is None:
                 _dist.launch_group_reductions(flat, tables, list(g1.offset), events, g1.n_levels, owners=ps)
+                exchanging = True
+            else:
+                exchanging = bool(hook(flat, tables, list(g1.offset), events, g1.n_levels))
+        if not exchanging:
+            _publish_pass_gradients(ps, flat)          # (level groups: reductions of `flat` are already in flight -- no late adds)
         if want_pose:
             d_center, d_ray = d_center.view(ctx.pose_shape), d_ray.view(ctx.pose_shape)
         if d_dref is not None:

@@ -105,9 +105,13 @@ class SDF(nn.Module):
 
     def get_surface_pts(self, pts):
         if (self.point_queries == "fused" and torch.is_grad_enabled() and not pts.requires_grad and pts.is_cuda
-                and fused.can_query_points(self, pts) and not fused.can_eval_without_graph(self, pts)):
+                and pts.dtype == torch.float32 and fused.can_query_points(self, pts) and not fused.can_eval_without_graph(self, pts)):
             # the points carry no graph (BA's tracked points): the value and the normal come from ONE query node -- one forward,
-            # one backward pipeline instead of two over the same points (the sum of the two nodes' parameter gradients)
+            # one backward pipeline instead of two over the same points (the sum of the two nodes' parameter gradients).
+            # The PARAMETER gradients are those of the two-node form; `pts` is marked afterwards, as gradient() marks its argument,
+            # but on this path `pts.grad` only receives the direct term of pts - n / |n| * sdf (the points had no graph when the
+            # field was queried: the second-order path through the normals is not recorded) -- a caller that needs d / d pts
+            # marks the points BEFORE the call and gets the two-node form below.  fp32 only: other dtypes take the general form.
             sdf, _, normals = fused.query_points(self, pts, want_normal=True)
             pts.requires_grad_(True)                    # gradient() marks its argument (SDF.py:104, SURVEY C-9): same side effect
             return fused.surface_points(pts, normals, sdf)

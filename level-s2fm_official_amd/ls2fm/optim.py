@@ -134,9 +134,19 @@ class FusedAdam(torch.optim.Optimizer):
             for p, old in held.items():
                 st = self.state.get(p)
                 if not st:
+                    # (round-4 advisor) live state, nothing in the checkpoint: the reference's loader would drop the entry and Adam
+                    # restart it from zero moments -- the same here, but IN the tensors a captured graph may hold: zeroed, kept
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if torch.is_tensor(old.get(k)):
+                            old[k].zero_()
+                    old["step"] = 0
+                    self.state[p] = old
                     continue
                 for k in ("exp_avg", "exp_avg_sq"):
-                    if torch.is_tensor(old.get(k)) and torch.is_tensor(st.get(k)) and old[k].shape == st[k].shape:
+                    if torch.is_tensor(old.get(k)) and torch.is_tensor(st.get(k)):
+                        if old[k].shape != st[k].shape:
+                            raise RuntimeError(f"ls2fm.optim.FusedAdam.load_state_dict: '{k}' of a parameter has shape "
+                                               f"{tuple(st[k].shape)} in the checkpoint, {tuple(old[k].shape)} here")
                         old[k].copy_(st[k])
                         st[k] = old[k]
                 st["step"] = int(st["step"])

@@ -406,9 +406,18 @@ class TracingConsistency:
         captured step and follow the tensor's value at every replay).  fixed: a `_FixedPoseRays` of these poses."""
         if torch.is_tensor(view):
             pick = lambda t: t.index_select(0, view)[0]
+
+            def into(src, index, out):
+                # `out=` neither casts nor broadcasts, and a shape mismatch makes torch RESIZE the out tensor -- new storage, while
+                # a captured graph and the early tracing hold the old address (round-4 advisor): refuse instead
+                want = (index.numel(),) + tuple(src.shape[1:])
+                if src.dtype != out.dtype or tuple(out.shape) != want:
+                    raise RuntimeError(f"ls2fm.stage.TracingConsistency.select: source {tuple(src.shape)} {src.dtype} does not "
+                                       f"fit the persistent buffer {tuple(out.shape)} {out.dtype}")
+                torch.index_select(src, 0, index, out=out)
             if fixed is not None:
-                torch.index_select(fixed.kp_center, 0, view, out=self.center)
-                torch.index_select(fixed.kp_ray, 0, view, out=self.ray)
+                into(fixed.kp_center, view, self.center)
+                into(fixed.kp_ray, view, self.ray)
             elif self.views.kinv_host is not None and poses.shape[-1] == 4:
                 # one launch: the selected view's pose and key points -> its rays, written into the buffers the tracing reads
                 _cam.camera_rays(self.views.kinv_host, poses=poses, xy=self.views.kp_pad, view_sel=view, out=(self.center, self.ray))
@@ -417,8 +426,8 @@ class TracingConsistency:
                 self.center.copy_(c); self.ray.copy_(r)
             # index_select straight INTO the persistent buffers: a `.copy_()` of a fresh result is a device-to-device memcpy node in
             # a captured iteration -- 20 - 80 us each on this stack, against 4 us for the gather kernel writing in place
-            torch.index_select(self.views.xyzs, 0, pick(self.views.id_pad), out=self.target)
-            torch.index_select(self.views.kp_live, 0, view, out=self.live.view(1, -1))
+            into(self.views.xyzs, pick(self.views.id_pad), self.target)
+            into(self.views.kp_live, view, self.live.view(1, -1))
             return
         c, r = keypoint_rays(poses[view], self.views.intrinsic, self.views.kp_pad[view])
         self.center.copy_(c); self.ray.copy_(r)

@@ -2,7 +2,8 @@
 (torch.distributed.run, one process per rank) with LS2FM_BENCH_BACKEND=gloo -- RCCL refuses two ranks per device, gloo carries
 device tensors.  The figures of such a run mean nothing (both ranks share the GPU, the all-reduce goes through the host); what
 is tested is the control flow the 2/4/8-GPU runs take: process-group set-up, sharded rays, the gradient exchange -- the default
-reduce-scatter -> sharded Adam -> all-gather (monolithic, or --shard-groups 2: pipelined by level group), and (--no-shard) the all-reduce, flat or overlapped from inside the backward --,
+all-reduce (the metric's step: no optimizer inside; overlapped from inside the backward, or flat with --no-overlap) and (--shard) reduce-scatter -> sharded
+Adam -> all-gather (monolithic, or --shard-groups 2: pipelined by level group) --,
 barriers, the block-count and max-over-ranks reductions, ONE JSON line on rank 0."""
 import json
 import os
@@ -22,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("extra", [[], ["--shard-groups", "2"], ["--no-shard"], ["--no-shard", "--no-overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--shard"], ["--shard", "--shard-groups", "2"]])
 def test_bench_two_ranks_one_gpu(extra):
     env = dict(os.environ, LS2FM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -36,7 +37,24 @@ def test_bench_two_ranks_one_gpu(extra):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["launch"] == "eager"
     assert d["config"]["parallelism"].startswith("dp2")
-    assert ("reduce-scatter" in d["config"]["workload"]) == ("--no-shard" not in extra)
+    # the default is BASELINE.json's step: fwd + bwd + gradient all-reduce, no optimizer inside it; --shard is the opt-in form
+    assert ("reduce-scatter" in d["config"]["workload"]) == ("--shard" in extra)
+    assert d["update_in_step"] == ("--shard" in extra)
+
+
+def test_bench_one_rank_rccl_default_form_is_the_metrics_step():
+    """`--force-dist` (one-rank RCCL group: the collectives are identities, everything else is real): the default N > 1 form is
+    fwd + bwd + all-reduce of the flat gradient buffer, launched like the N = 1 line -- also as ONE hipGraph replay with the
+    RCCL all-reduce recorded in it -- and carries no optimizer update"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LS2FM_DIST_SINGLE="1", MASTER_PORT=str(_free_port()))
+    for launch in ("eager", "graph"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "2",
+                              "--rays", "256", "--samples", "32", "--no-cpu-baseline", "--launch", launch],
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["update_in_step"] is False and "all-reduce" in d["exchange"]["form"]
+        assert d["launch"].startswith("hipGraph" if launch == "graph" else "eager")
 
 
 def test_bench_c1_and_inference_lines():
