@@ -262,11 +262,26 @@ class GradAllReducer:
             if self.average:
                 whole.div_(world)
             return
-        handles = [dist.all_reduce(p.grad, async_op=True) for p in self.big if p.grad is not None]
-        flat = self._shared_flat()
+        # the fields' gradients in the fused backward's flat buffer + a few loose parameters outside it (the pose groups of a
+        # BA stage): the buffer as ONE message, the loose ones packed into a second small one
+        big, small = self.big, self.small
+        fields = [p for p in self.params if getattr(p, "_ls2fm_grad_flat", None) is not None and p.grad is not None]
+        part = self._flat_holding(fields) if fields else None
+        if part is not None:
+            covered = sum((p.grad.numel() + 3) // 4 * 4 for p in fields)
+            if part.numel() not in (covered, max(covered, int(getattr(fields[0], "_ls2fm_flat_total", 0)))):
+                part = None                                # something else lives in the buffer
+        handles = []
+        if part is not None:
+            held = {id(p) for p in fields}
+            big = [p for p in big if id(p) not in held]
+            small = [p for p in small if id(p) not in held]
+            handles.append(dist.all_reduce(part, async_op=True))
+        handles += [dist.all_reduce(p.grad, async_op=True) for p in big if p.grad is not None]
+        flat = self._flat_holding(small) if (small and part is None) else None
         packed = flat is None
         if packed:
-            live = [p for p in self.small if p.grad is not None]
+            live = [p for p in small if p.grad is not None]
             n = sum(p.numel() for p in live)
             if self._flat is None or self._flat.numel() != n:
                 self._flat = torch.empty(n, device=live[0].device, dtype=torch.float32) if live else None
@@ -281,7 +296,7 @@ class GradAllReducer:
             h.wait()
         if packed and flat is not None:
             at = 0
-            for p in self.small:
+            for p in small:
                 if p.grad is not None:
                     p.grad.copy_(flat[at:at + p.numel()].view_as(p.grad))
                     at += p.numel()

@@ -31,7 +31,13 @@ _TRACE_STREAMS = {}
 
 def _trace_stream(device, slot=0):
     """the stream(s) sphere tracings are launched on beside the render's forward: slot 0 the render rays', slots 1.. the key-point
-    tracings of a loop's extra terms (latency-bound kernels of a few workgroups each: they overlap each other almost for free)"""
+    tracings of a loop's extra terms (latency-bound kernels of a few workgroups each: they overlap each other almost for free).
+    None (= the current stream) inside a hipGraph capture under torch.distributed: the tracing max-reduces its trip count over the
+    ranks on the stream it runs on, and a side-stream branch that forks again into RCCL's own stream is the depth-three fork tree
+    that takes a capture down on ROCm 7.2 (csrc/streams.hip)."""
+    from . import dist as _dist
+    if _dist.is_distributed() and torch.cuda.is_current_stream_capturing():
+        return None
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     if (idx, slot) not in _TRACE_STREAMS:
@@ -145,7 +151,8 @@ class RenderStage:
 
     def __init__(self, opt, renderer, sdf_field, rad_field, weights=None, lr=1e-2, lr_end=1e-4, max_iter=1000, betas=(0.9, 0.999),
                  eps=1e-8, extra_params=(), capture=False, extra_loss=None, lr_color=None, eikonal_over="bg", reducer=None,
-                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None, share_gradients=False, shard_groups=1):
+                 sharded=False, async_gather=False, extra_prepare=None, input_fn=None, share_gradients=False, shard_groups=1,
+                 shard_views=False):
         """lr / lr_color: the reference's two field groups (`[{sdf_func.parameters(), lr_sdf}, {color_func.parameters(),
         lr_color}]`, BA.py:79-83; lr_color=None: one rate); extra_params: tensors (one more group at `lr`) or
         `{"params": [...], "lr": x}` dicts (the pose groups of BA.py:60-75).  ONE ExponentialLR factor for all groups,
@@ -156,7 +163,15 @@ class RenderStage:
         `ls2fm.dist.ShardedAdam` (reduce-scatter of the flat gradient buffer, Adam on this rank's 1/world of the parameters,
         all-gather of the updated shards; async_gather: the all-gather runs on the communication stream until the next step's
         first parameter read; shard_groups >= 2: the exchange is pipelined by level groups of the two tables, `ShardedAdam`).
-        Fields only: pose groups (extra_params) take the all-reduce form."""
+        Fields only: pose groups (extra_params) take the all-reduce form.
+        reducer="auto": a GradAllReducer over this stage's parameters when a process group is up (else none).
+        shard_views=True (with a process group of W ranks): the step's [B,R,3] batch is the GLOBAL one, identical on every rank,
+        and rank r renders views r, r + W, ... of it (B % W == 0) -- BASELINE.json configs[3]: a BA step with the rays of 8
+        registered views sharded over 8 GPUs; the loss head divides by global counts, the all-reduce sums the shards' gradients.
+        `extra_loss` (terms formed outside the render: point side, re-projection, tracing consistency) is evaluated on every rank
+        over the same inputs and enters the backward with weight 1 / W, so that the summed gradient is the single-process one;
+        the returned `loss_all` is the global value on every rank.  capture=True under torch.distributed needs the RCCL ("nccl")
+        backend: the step's collectives -- loss counts, trip count, gradient all-reduce -- are recorded into the hipGraph."""
         self.opt, self.renderer, self.sdf, self.rad = opt, renderer, sdf_field, rad_field
         dev = next(sdf_field.parameters()).device
         w = weights or {}
@@ -174,7 +189,8 @@ class RenderStage:
         self.sharded = bool(sharded)
         if self.sharded:
             if len(groups) > 2 or capture:
-                raise NotImplementedError("ls2fm.stage.RenderStage(sharded=True): the two field groups only, eager steps only")
+                raise NotImplementedError("ls2fm.stage.RenderStage(sharded=True): the two field groups only, eager steps only "
+                                          "(pose groups and captured steps take the all-reduce form: reducer=\"auto\")")
             from .dist import ShardedAdam
             self.optim = ShardedAdam.for_fields(sdf_field, rad_field, lr=lr, lr_color=lr_color, betas=betas, eps=eps,
                                                 scheduled_gamma=self.gamma, async_gather=async_gather, n_groups=shard_groups,
@@ -195,7 +211,13 @@ class RenderStage:
         # ALL their field queries in `extra_prepare`, i.e. ahead of the render (the loops below)
         self.share_gradients = bool(share_gradients)
         self.eikonal_over = eikonal_over
+        if isinstance(reducer, str):
+            if reducer != "auto":
+                raise ValueError(f"ls2fm.stage.RenderStage: reducer={reducer!r}")
+            from . import dist as _dist
+            reducer = _dist.GradAllReducer(self.params) if (_dist.is_distributed() and not self.sharded) else None
         self.reducer = reducer
+        self.shard_views = bool(shard_views)
         self._graph = None
         self._table_versions = None
         self._one = torch.ones((), device=dev)
@@ -209,16 +231,27 @@ class RenderStage:
                                "head normalises by global counts, the gradients must be summed over the ranks before the update")
         for p in self.params:
             p.grad = None
+        world = 1
+        if self.shard_views and _dist.is_distributed():
+            import torch.distributed as tdist
+            world, rank = tdist.get_world_size(), tdist.get_rank()
+            if centers.shape[0] % world:
+                raise RuntimeError(f"ls2fm.stage.RenderStage(shard_views=True): {centers.shape[0]} views over {world} ranks")
+            if world > 1:                  # views rank, rank + world, ...: strided views of the global batch, made contiguous
+                centers, rays, rgbs_gt = (t[rank::world].contiguous() for t in (centers, rays, rgbs_gt))
         if self.extra_prepare is not None and static_trips:
             self.extra_prepare()
         ret = render_losses(self.opt, self.renderer, self.sdf, self.rad, self.head, centers, rays, rgbs_gt, static_trips=static_trips,
                             eikonal_over=self.eikonal_over)
+        loss_bwd = ret["loss_all"]
         if self.extra_loss is not None:
             ret["loss_extra"] = self.extra_loss(ret)
+            # (replicated on every rank of a view-sharded step: 1 / world of it per rank in the backward, the whole in the log)
+            loss_bwd = ret["loss_all"] + (ret["loss_extra"] if world == 1 else ret["loss_extra"] * (1.0 / world))
             ret["loss_all"] = ret["loss_all"] + ret["loss_extra"]
         from . import fused as _fused
         with _fused.pass_gradient_sharing(self.share_gradients and static_trips and self.extra_prepare is not None):
-            ret["loss_all"].backward(gradient=self._one)
+            loss_bwd.backward(gradient=self._one)
         if self.reducer is not None:
             self.reducer.all_reduce()
         self.optim.step()
@@ -280,8 +313,13 @@ class RenderStage:
     def _capture(self, fn):
         from . import dist as _dist
         if _dist.is_distributed():
-            raise NotImplementedError("ls2fm.stage.RenderStage(capture=True) under torch.distributed: the step's collectives "
-                                      "(loss counts, trip count, gradient exchange) are not replayed from a hipGraph; use capture=False")
+            import torch.distributed as tdist
+            if tdist.get_backend() != "nccl" or self.sharded:
+                raise NotImplementedError("ls2fm.stage.RenderStage(capture=True) under torch.distributed needs the RCCL (\"nccl\") "
+                                          "backend and the all-reduce form (reducer=...): its collectives -- loss counts, trip count, "
+                                          "gradient all-reduce -- are then recorded into the hipGraph; gloo moves tensors through "
+                                          "the host, and the sharded update keeps per-rank state the snapshot around a capture does "
+                                          "not cover.  Use capture=False")
         from .graph import CapturedStep
         # the capture warms the step up by running it for real: parameters, Adam state and the schedule are put back
         # afterwards (in place: the graph holds their addresses), so that this call, too, is exactly one step
@@ -578,7 +616,9 @@ class RefineLoop:
     `torch.randperm(H * W)` head and a host-side random view per iteration (no device synchronisation either way)."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, max_iter, rand_rays,
-                 capture=False, static_trips=None):
+                 capture=False, static_trips=None, distributed=False):
+        """distributed=True (a process group is up; every rank holds the same views, weights and per-iteration picks): the render
+        rays are sharded by view, the gradients all-reduced (RenderStage(shard_views=True, reducer="auto"))"""
         get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
         self.views, self.max_iter, self.rand_rays = views, int(max_iter), int(rand_rays)
         from . import fused as _fused
@@ -586,7 +626,8 @@ class RefineLoop:
         self.extra = TracingConsistency(sdf_field, views, get("tracing_loss"), get("sdf_surf"), static_trips=static)
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self.extra, eikonal_over="all", extra_prepare=self.extra.prepare,
-                                 input_fn=self._inputs, share_gradients=bool(static))
+                                 input_fn=self._inputs, share_gradients=bool(static), shard_views=bool(distributed),
+                                 reducer="auto" if distributed else None)
         self.poses = views.poses if views.poses.shape[-1] == 4 else _cam.lie.se3_to_SE3(views.poses)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss")
         # an iteration's picks as device tensors, updated in place: the ray pick and the key-point rays are formed INSIDE the step
@@ -932,7 +973,10 @@ class BALoop:
     (BA.py:181)."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, lr_pose_r, lr_pose_t,
-                 max_iter, rand_rays, capture=False, static_trips=None):
+                 max_iter, rand_rays, capture=False, static_trips=None, distributed=False):
+        """distributed=True: BASELINE.json configs[3] -- the render rays of the registered views sharded by view over the ranks of
+        the process group, one gradient all-reduce per iteration (fields' flat buffer + the pose groups); the point side,
+        re-projection and tracing consistency are evaluated on every rank (same inputs) with weight 1 / world in the backward"""
         get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
         self.opt, self.sdf, self.views = opt, sdf_field, views
         self.max_iter, self.rand_rays = int(max_iter), int(rand_rays)
@@ -960,7 +1004,8 @@ class BALoop:
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="bg",
                                  extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)],
-                                 extra_prepare=self._prepare, input_fn=self._inputs, share_gradients=bool(static))
+                                 extra_prepare=self._prepare, input_fn=self._inputs, share_gradients=bool(static),
+                                 shard_views=bool(distributed), reducer="auto" if distributed else None)
         self._idx = torch.zeros(self.rand_rays // se3.shape[0], dtype=torch.long, device=se3.device)
         self._view = torch.zeros(1, dtype=torch.long, device=se3.device)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")

@@ -277,3 +277,80 @@ def test_one_rank_rccl_sharded_stage(tmp_path):
     a real RCCL communicator (world size 1: all this box allows)"""
     mp.spawn(_stage_worker, args=(1, _free_port(), str(tmp_path), "nccl", True), nprocs=1, join=True)
     assert (tmp_path / "stage_ok0").exists()
+
+
+# ---- the stage LOOPS under data parallelism (BASELINE.json configs[3]: a Neural BA step with the rays of the registered views
+# sharded over the GPUs, RCCL gradient all-reduce; pipelines/BA.py:110-188)
+def _loop_worker(rank, world, port, out_dir, backend, which, capture):
+    """5 iterations of BALoop / RefineLoop with the render rays sharded by view over `world` ranks (every rank: the same views,
+    weights and per-iteration picks; point side / re-projection / tracing consistency replicated with weight 1 / world in the
+    backward; ONE gradient all-reduce per iteration: the fields' flat buffer + the pose groups) against the single-process loop"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "level-s2fm_official_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      LS2FM_DIST_SINGLE="1" if world == 1 else "0")
+    torch.cuda.set_device(0)
+    import numpy as np
+    from conftest import load_golden
+    from ls2fm import stage
+    from test_hip_stage_loops import _scene
+    n_it = 5
+
+    def build(distributed, cap):
+        g = load_golden("stage_ba_dtu_dual" if which == "ba" else "stage_refine_dtu_dual")
+        meta, opt, sdf, rad, ren, views, picks = _scene(g)
+        o = meta["optim"]
+        if which == "ba":
+            views.poses = torch.from_numpy(g["se3"]).to("cuda")
+            loop = stage.BALoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                                lr_color=o["lr_color"], lr_pose_r=o["lr_pose_r"], lr_pose_t=o["lr_pose_t"], max_iter=o["max_iter"],
+                                rand_rays=meta["rand_rays"], capture=cap, distributed=distributed)
+        else:
+            loop = stage.RefineLoop(opt, ren, sdf, rad, views, weights=meta["weights"], lr_sdf=o["lr_sdf"], lr_sdf_end=o["lr_sdf_end"],
+                                    lr_color=o["lr_color"], max_iter=o["max_iter"], rand_rays=meta["rand_rays"], capture=cap,
+                                    distributed=distributed)
+        return loop, sdf, rad, picks
+
+    loop_a, sdf_a, rad_a, picks = build(False, capture)
+    logs_a = {k: v.cpu().numpy() for k, v in loop_a.run(n_iters=n_it, picks=picks).items()}
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        loop_b, sdf_b, rad_b, _ = build(True, capture)
+        assert loop_b.stage.reducer is not None and loop_b.stage.shard_views
+        logs_b = {k: v.cpu().numpy() for k, v in loop_b.run(n_iters=n_it, picks=picks).items()}
+        torch.cuda.synchronize()
+        assert (loop_b.stage._graph is not None) == capture
+        for k in ("all", "PSNR", "rgb_loss", "eikonal_loss"):               # every rank reports the GLOBAL value
+            assert np.all(np.abs(logs_b[k] - logs_a[k]) <= 3e-3 * np.abs(logs_a[k]) + 1e-6), (k, logs_b[k], logs_a[k])
+        for k in ("sdf_surf", "tracing_loss") + (("reproj_error",) if which == "ba" else ()):
+            assert np.all(np.abs(logs_b[k] - logs_a[k]) <= 2e-2 * np.abs(logs_a[k]) + 2e-4), (k, logs_b[k], logs_a[k])
+        from conftest import rel_err
+        for (k, pa), (_, pb) in zip(list(sdf_a.named_parameters()) + list(rad_a.named_parameters()),
+                                    list(sdf_b.named_parameters()) + list(rad_b.named_parameters())):
+            if not k.endswith("embedder_obj.params"):
+                assert rel_err(pb, pa) < 5e-2, (k, rel_err(pb, pa))
+        if which == "ba":
+            a, b = loop_a.poses_se3().cpu(), loop_b.poses_se3().cpu()
+            assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()), "poses"
+        with open(os.path.join(out_dir, f"loop_ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["ba", "refine"])
+def test_two_ranks_view_sharded_loops_match_the_single_process_trajectory(which, tmp_path):
+    mp.spawn(_loop_worker, args=(2, _free_port(), str(tmp_path), "gloo", which, False), nprocs=2, join=True)
+    assert (tmp_path / "loop_ok0").exists() and (tmp_path / "loop_ok1").exists()
+
+
+@pytest.mark.parametrize("which", ["ba", "refine"])
+def test_one_rank_rccl_captured_loops(which, tmp_path):
+    """the CAPTURED iteration under a real RCCL communicator (world size 1: what this box allows): the loss-count, trip-count and
+    gradient all-reduces are recorded into the iteration's hipGraph (tracings on the capturing stream: no side-stream branch forks
+    again into RCCL's stream) -- same trajectory as the captured single-process loop"""
+    mp.spawn(_loop_worker, args=(1, _free_port(), str(tmp_path), "nccl", which, True), nprocs=1, join=True)
+    assert (tmp_path / "loop_ok0").exists()
