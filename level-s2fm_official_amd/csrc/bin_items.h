@@ -51,6 +51,19 @@ struct __attribute__((aligned(4))) ItemS {      // 20 bytes
 template <bool DUAL> struct ItemOf { typedef ItemS type; };
 template <> struct ItemOf<true> { typedef Item type; };
 
+// Round 5 -- EXPLICIT dual items on the coarse levels.  On a level whose cells are at least two sample spacings wide (ETH3D at 128
+// samples: levels 0 .. 3, 7 .. 2 consecutive samples of a ray per cell) the dual field uses the single field's recipe: the x-corners'
+// values of BOTH grids travel explicitly and consecutive samples in one cell are merged into one item per corner pair (run_sums).
+// An explicit dual pair is nine words: the 32-byte Item re-read as {ij, v00 v01 v10 v11 (SDF grid), w00 w01 w10 (second grid)} plus
+// w11 in a parallel float array indexed like the items (BinMeta::extra) -- one item size, one index arithmetic for every level.
+// The explicit levels are a PREFIX of the levels (resolutions grow), decided on the host from the grid and the samples per ray:
+constexpr int kMaxExplicitLevels = 6;
+__host__ __device__ __forceinline__ Item explicit_item(uint32_t ij, const float* v) {        // v[0..6] -> the item, v[7] -> extra
+    Item it;
+    it.ij = ij; it.wx = v[0]; it.a0 = v[1]; it.a1 = v[2]; it.b0 = v[3]; it.b1 = v[4]; it.c0 = v[5]; it.c1 = v[6];
+    return it;
+}
+
 struct BinMeta {           // device arrays inside the workspace
     int* count;            // [L][kBins]  items per (level, slab)
     int* start;            // [L][kBins]  absolute offsets into items
@@ -58,6 +71,8 @@ struct BinMeta {           // device arrays inside the workspace
                            //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
                            //                      order is deterministic
     Item* items;           // (single field: ItemS records in the same storage)
+    float* extra;          // ninth word of the explicit dual items (levels < n_explicit): extra[absolute item index]; those levels
+                           // come first in the item order, so the array covers kMaxExplicitLevels levels only
     u64* part_acc;         // kAccSlots u64 per (split slab, part): fixed-point partials, summed by slab_combine_kernel
     int part_blocks;       // capacity of part_acc in blocks of kAccSlots
     float* level_bound;    // [32] max over rays of the per-ray contribution bounds (rows 0..15 SDF grid, 16..31 second grid)
@@ -176,8 +191,9 @@ __device__ __forceinline__ void run_sums(float (&v)[NV], unsigned long long cont
 
 // The items of one (point, level) with run merging: nothing for a lane that continues a run; for a run's first lane the
 // classification of for_each_item, except that a merged run of a DUAL pair is always two half items.
-template <bool DUAL, typename F>
-__device__ __forceinline__ void for_each_item_merged(const LevelC& L, const uint32_t g[3], const RunFlags& rf, F&& f) {
+// halves: the factored dual item (a merged run is two half items per pair); false: explicit items (single field, explicit dual levels)
+template <typename F>
+__device__ __forceinline__ void for_each_item_merged(const LevelC& L, const uint32_t g[3], const RunFlags& rf, const bool halves, F&& f) {
     if (!rf.head) return;
     const uint32_t lmask = (1u << L.sshift) - 1u;
 #pragma unroll
@@ -185,7 +201,7 @@ __device__ __forceinline__ void for_each_item_merged(const LevelC& L, const uint
         const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
         const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
         const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
-        if (s0 == s1 && !(DUAL && rf.merged)) {
+        if (s0 == s1 && !(halves && rf.merged)) {
             f((int)s0, c, i0 & lmask, i1 & lmask);
         } else {
             f((int)s0, c, i0 & lmask, 0xFFFFu);
@@ -210,6 +226,7 @@ inline int part_blocks_capacity(int64_t n_points) {
     return (int)(want < 2048 ? want : 2048);
 }
 inline int64_t part_acc_floats(int64_t n_points) { return (int64_t)part_blocks_capacity(n_points) * kAccSlots * 2; }
+inline int64_t extra_floats(int64_t n_points) { return (8 * (int64_t)kMaxExplicitLevels * n_points + 63) / 64 * 64; }
 
 inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     BinMeta bm;
@@ -221,7 +238,8 @@ inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
     bm.part_acc = reinterpret_cast<u64*>(meta + meta_ints(n_points));   // 256-byte aligned
     bm.part_blocks = part_blocks_capacity(n_points);
-    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points) + part_acc_floats(n_points));
+    bm.extra = reinterpret_cast<float*>(meta + meta_ints(n_points) + part_acc_floats(n_points));
+    bm.items = reinterpret_cast<Item*>(meta + meta_ints(n_points) + part_acc_floats(n_points) + extra_floats(n_points));
     return bm;
 }
 

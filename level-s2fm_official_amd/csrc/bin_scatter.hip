@@ -48,14 +48,18 @@ namespace {
 #define LS2FM_FILL_PROBE 0
 #endif
 #ifndef LS2FM_FILL_MINW
-#define LS2FM_FILL_MINW 1
+#define LS2FM_FILL_MINW 5
 #endif
+// Dual field, the coarse levels (l < n_explicit; bin_items.h): EXPLICIT items -- the x-corners' values of both grids, consecutive
+// samples in one cell merged -- formed pair by pair: eight live values and one segmented reduction at a time (all 32 at once cost
+// 124 registers against 88, i.e. one workgroup per CU less -- as a second launch for those levels it took back what the merge
+// saved: fill 86 -> 97 us).
 template <bool DUAL>
 __global__ void __launch_bounds__(kFillThreads, LS2FM_FILL_MINW)
 scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
                     int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
                     const float* __restrict__ rec2, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad,
-                    BinMeta bm, int level_base, int reverse) {
+                    BinMeta bm, int level_base, int reverse, int n_explicit) {
     typedef typename ItemOf<DUAL>::type ItemT;
     __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
     __shared__ int lds_off[kBins];       // first slot (in the workgroup's sorted order) of the slab's run
@@ -64,6 +68,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     constexpr int kWin = DUAL ? kFillWin : kFillCap;      // (single field, 20-byte items: one pass -- two measured 52 -> 57 us)
     __shared__ ItemT s_items[kWin];
     __shared__ uint32_t s_gidx[kWin];
+    __shared__ float s_extra[DUAL ? kWin : 1];            // ninth word of an explicit dual item
     __shared__ int s_total;
     ItemT* __restrict__ g_items = reinterpret_cast<ItemT*>(bm.items);
     // levels are walked last to first: the accumulate launch reads the lists first to last, i.e. most recently written first
@@ -99,8 +104,10 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         }
     }
     // runs of consecutive points in one cell (bin_items.h): the same flags the counting pass derived
-    const RunFlags rf = wave_runs(g, live, lane, DUAL ? kMergeMinDual : kMergeMinSingle);
-    for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
+    const bool expl = DUAL && l < n_explicit;               // (workgroup-uniform) explicit, run-merged dual items on this level
+    const bool halves = DUAL && !expl;                      // factored items: a merged run would be two half items per pair
+    const RunFlags rf = wave_runs(g, live, lane, halves ? kMergeMinDual : kMergeMinSingle);
+    for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
     __syncthreads();
     // runs: offsets in the sorted order (exclusive prefix over the slabs, wave 0)
     if (tid < 64) {
@@ -122,39 +129,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         hist[tid] = 0;
     }
     __syncthreads();
-    // per corner pair c = by + 2 bz: the factored payload (A, B[, C]) and the two x-corners' explicit values
-    //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
-    constexpr int NV = DUAL ? 32 : 16;
-    float fa[4][2], fb[4][2], fcc[4][2], val[NV];
-    {
-        const float px0 = 1.0f - w[0];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int by = c & 1, bz = c >> 1;
-            const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
-            const float pyz = py * pz;
-            const float qyz = (by ? qd[1] : -qd[1]) * pz + py * (bz ? qd[2] : -qd[2]);
-            fa[c][0] = fmaf(qyz, r0, pyz * d0);
-            fa[c][1] = fmaf(qyz, r1, pyz * d1);
-            fb[c][0] = qd[0] * pyz * r0;
-            fb[c][1] = qd[0] * pyz * r1;
-            fcc[c][0] = pyz * e0;
-            fcc[c][1] = pyz * e1;
-            constexpr int S = DUAL ? 8 : 4;
-            val[S * c + 0] = fmaf(px0, fa[c][0], -fb[c][0]);
-            val[S * c + 1] = fmaf(px0, fa[c][1], -fb[c][1]);
-            val[S * c + 2] = fmaf(w[0], fa[c][0], fb[c][0]);
-            val[S * c + 3] = fmaf(w[0], fa[c][1], fb[c][1]);
-            if (DUAL) {
-                val[S * c + 4] = px0 * fcc[c][0];
-                val[S * c + 5] = px0 * fcc[c][1];
-                val[S * c + 6] = w[0] * fcc[c][0];
-                val[S * c + 7] = w[0] * fcc[c][1];
-            }
-        }
-    }
-    if (rf.cont != 0ull) run_sums<NV>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
-    // every item's slot in the workgroup's sorted order: slot_a[c] = the pair's item (or its first half), slot_b[c] = its second half
+    // every item's slot in the workgroup's sorted order
     // (named scalars, 16 bits per slot: as arrays indexed by the lambda's pair number they went to scratch memory)
     uint32_t sl0 = 0u, sl1 = 0u, sl2 = 0u, sl3 = 0u;
     auto put_slot = [&](unsigned c, bool second, int slot) {
@@ -166,7 +141,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         return (int)(second ? v >> 16 : v & 0xFFFFu);
     };
     static_assert(kFillThreads * 8 <= 0xFFFF, "slots fit 16 bits");
-    for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned c, uint32_t i0, uint32_t) {
+    for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned c, uint32_t i0, uint32_t) {
         int rank = atomicAdd(&hist[slab], 1);
         // long runs (coarse levels: consecutive samples of a ray fall into the same cell) are stored permuted, so that
         // the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same entry (same-address
@@ -177,44 +152,108 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         put_slot(c, i0 == 0xFFFFu, slot);
     });
     const int total = s_total;
-    for (int win = 0; win < total; win += kWin) {
-        if (win > 0) __syncthreads();                     // the previous window has been written out
-        for_each_item_merged<DUAL>(L, g, rf, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
-            constexpr int S = DUAL ? 8 : 4;
-            const int rel = get_slot(c, i0 == 0xFFFFu) - win;
-            if (rel < 0 || rel >= kWin) return;
-            ItemT it;
-            it.ij = i0 | (i1 << 16);
-            if constexpr (DUAL) {
-                if (rf.merged) {               // half item of a merged run: the summed values of ONE x-corner, wx = 0 / 1, B = 0
-                    const bool second = i0 == 0xFFFFu;
-                    it.wx = second ? 1.0f : 0.0f;
-                    it.a0 = val[S * c + (second ? 2 : 0)];
-                    it.a1 = val[S * c + (second ? 3 : 1)];
-                    it.b0 = 0.f;
-                    it.b1 = 0.f;
-                    it.c0 = val[S * c + (second ? 6 : 4)];
-                    it.c1 = val[S * c + (second ? 7 : 5)];
-                } else {
-                    it.wx = w[0];
-                    it.a0 = fa[c][0]; it.a1 = fa[c][1];
-                    it.b0 = fb[c][0]; it.b1 = fb[c][1];
-                    it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
-                }
-            } else {
-                it.v00 = val[S * c + 0]; it.v01 = val[S * c + 1];
-                it.v10 = val[S * c + 2]; it.v11 = val[S * c + 3];
-            }
-            s_items[rel] = it;
-            s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
-        });
-        __syncthreads();
+    // the two x-corners' values of corner pair c = by + 2 bz, both grids:
+    //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
+    auto pair_factors = [&](unsigned c, float (&a)[2], float (&b)[2], float (&cc)[2]) {
+        const int by = c & 1, bz = c >> 1;
+        const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
+        const float pyz = py * pz;
+        const float qyz = (by ? qd[1] : -qd[1]) * pz + py * (bz ? qd[2] : -qd[2]);
+        a[0] = fmaf(qyz, r0, pyz * d0);
+        a[1] = fmaf(qyz, r1, pyz * d1);
+        b[0] = qd[0] * pyz * r0;
+        b[1] = qd[0] * pyz * r1;
+        cc[0] = pyz * e0;
+        cc[1] = pyz * e1;
+    };
+    auto write_out = [&](int win) {
         // runs of one slab are contiguous in the sorted order and in memory: consecutive threads write consecutive items
         const int staged = total - win < kWin ? total - win : kWin;
 #if (LS2FM_FILL_PROBE & 1)
         if (staged < 0)                    // timing probe: no item stores
 #endif
-        for (int q = tid; q < staged; q += kFillThreads) g_items[s_gidx[q]] = s_items[q];
+        for (int q = tid; q < staged; q += kFillThreads) {
+            const uint32_t gi = s_gidx[q];
+            g_items[gi] = s_items[q];
+            if (DUAL && expl) bm.extra[gi] = s_extra[q];
+        }
+    };
+    if (!expl) {
+        // ---- factored dual items / the single field's explicit items
+        constexpr int NV = DUAL ? 1 : 16;
+        float fa[4][2], fb[4][2], fcc[4][2], val[NV];
+        {
+            const float px0 = 1.0f - w[0];
+#pragma unroll
+            for (unsigned c = 0; c < 4; ++c) {
+                pair_factors(c, fa[c], fb[c], fcc[c]);
+                if (!DUAL) {
+                    val[4 * c + 0] = fmaf(px0, fa[c][0], -fb[c][0]);
+                    val[4 * c + 1] = fmaf(px0, fa[c][1], -fb[c][1]);
+                    val[4 * c + 2] = fmaf(w[0], fa[c][0], fb[c][0]);
+                    val[4 * c + 3] = fmaf(w[0], fa[c][1], fb[c][1]);
+                }
+            }
+        }
+        if (!DUAL && rf.cont != 0ull) run_sums<NV>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
+        for (int win = 0; win < total; win += kWin) {
+            if (win > 0) __syncthreads();                     // the previous window has been written out
+            for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
+                const int rel = get_slot(c, i0 == 0xFFFFu) - win;
+                if (rel < 0 || rel >= kWin) return;
+                ItemT it;
+                it.ij = i0 | (i1 << 16);
+                if constexpr (DUAL) {
+                    it.wx = w[0];
+                    it.a0 = fa[c][0]; it.a1 = fa[c][1];
+                    it.b0 = fb[c][0]; it.b1 = fb[c][1];
+                    it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
+                } else {
+                    it.v00 = val[4 * c + 0]; it.v01 = val[4 * c + 1];
+                    it.v10 = val[4 * c + 2]; it.v11 = val[4 * c + 3];
+                }
+                s_items[rel] = it;
+                s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
+            });
+            __syncthreads();
+            write_out(win);
+        }
+    } else if constexpr (DUAL) {
+        // ---- explicit dual items, pair by pair: the pair's eight corner values, their sums over the run, its item(s)
+        const uint32_t lmask = (1u << L.sshift) - 1u;
+        const float px0 = 1.0f - w[0];
+        for (int win = 0; win < total; win += kWin) {         // (one window unless nothing merged)
+            if (win > 0) __syncthreads();
+#pragma unroll 1                                          // (unrolled, the scheduler interleaves the four pairs: 32 live values again)
+            for (unsigned c = 0; c < 4; ++c) {
+                float a[2], b[2], cc[2], v8[8];
+                pair_factors(c, a, b, cc);
+                v8[0] = fmaf(px0, a[0], -b[0]); v8[1] = fmaf(px0, a[1], -b[1]);
+                v8[2] = fmaf(w[0], a[0], b[0]); v8[3] = fmaf(w[0], a[1], b[1]);
+                v8[4] = px0 * cc[0]; v8[5] = px0 * cc[1];
+                v8[6] = w[0] * cc[0]; v8[7] = w[0] * cc[1];
+                if (rf.cont != 0ull) run_sums<8>(v8, rf.cont, lane);              // wave-uniform
+                if (rf.head) {
+                    const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
+                    const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
+                    const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
+                    auto stage = [&](int slab, bool second, uint32_t ij) {
+                        const int rel = get_slot(c, second) - win;
+                        if (rel < 0 || rel >= kWin) return;
+                        s_items[rel] = explicit_item(ij, v8);
+                        s_extra[rel] = v8[7];
+                        s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
+                    };
+                    if (s0 == s1) stage((int)s0, false, (i0 & lmask) | ((i1 & lmask) << 16));
+                    else {
+                        stage((int)s0, false, (i0 & lmask) | (0xFFFFu << 16));
+                        stage((int)s1, true, 0xFFFFu | ((i1 & lmask) << 16));
+                    }
+                }
+            }
+            __syncthreads();
+            write_out(win);
+        }
     }
     // the level's first workgroup also reduces the per-ray bounds of a single contribution (written by shade_bwd) to the
     // level's bound: the accumulate workgroups read two floats instead of n_rays each
@@ -244,6 +283,7 @@ struct SlabPlan {
     int parts[LS2FM_MAX_LEVELS];         // item-range parts per slab of the level
     int scratch[LS2FM_MAX_LEVELS];       // first block of the level's (slab, part) partials in BinMeta::part_acc (parts > 1)
     int headroom_bits;                   // log2 of the worst-case number of contributions to one entry
+    int n_explicit;                      // dual field: leading levels with explicit, run-merged items (bin_items.h)
 };
 
 __device__ __forceinline__ void add_fixed(u64* slot, float v, float to_fixed) {
@@ -261,166 +301,23 @@ __device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float
     to_float = ldexp(1.0, -shift);
 }
 
-// -DLS2FM_STAMPS: per-workgroup phase time stamps (100 MHz), read back by tools/acc_stamps.py
+// -DLS2FM_STAMPS: per-unit phase time stamps (100 MHz), read back by tools/acc_stamps_p.py
 #ifdef LS2FM_STAMPS
 __device__ long long g_acc_stamps[8 * 4096];
-#define ACC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
-#else
-#define ACC_STAMP(k) do {} while (0)
 #endif
 
-// (A variant that packed each feature pair into one 64-bit accumulator -- half the LDS atomics, slab_accumulate alone 117.5 ->
-// 95.7 us at C2 -- left the step unchanged and dropped contributions below 2^-17 of a level's bound, which Adam does not
-// forgive; measured and removed in round 3 / 4, `git log -S LS2FM_PACKED_ACC`.)
-
+// (Rounds 1-4 ran one workgroup per (level, slab[, part]); round 5's persistent form below replaced it -- `git log -S slab_accumulate_kernel`.
+// A variant that packed each feature pair into one 64-bit accumulator -- half the LDS atomics -- dropped contributions below 2^-17
+// of a level's bound, which Adam does not forgive; measured and removed in round 3 / 4, `git log -S LS2FM_PACKED_ACC`.)
+//
 // Point-split slabs (dense / tiny levels: every point's items fall into a handful of slabs, whose lists are cut into `parts`
-// workgroups) have two flush forms, chosen per launch (ls2fm_set_scatter_mode):
+// units) have two flush forms, chosen per launch (ls2fm_set_scatter_mode):
 //   combine = 1  every part leaves its 64-bit fixed-point partials in scratch; slab_combine_kernel, the next launch on the stream,
 //                sums them -- integer sums: exact and order-independent -- and writes every entry once with a plain store.  The
 //                table gradient is then the exactly rounded sum of its contributions on EVERY level, the backward repeats itself
 //                bit for bit, nothing is zeroed beforehand and no floating-point atomic is left in the path.
 //   combine = 0  float atomics into a table range zeroed by the backward's zero job (rounds 1-3): one launch fewer, sums of
 //                rounded partials in arrival order.
-template <bool DUAL, bool ADD_INTO>
-__global__ void __launch_bounds__(kAccThreads)
-slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
-                       float* __restrict__ dtable2, int block_base, int combine) {
-    typedef typename ItemOf<DUAL>::type ItemT;
-    constexpr bool add_into = ADD_INTO;
-    constexpr int F = DUAL ? 4 : 2;
-    __shared__ __attribute__((aligned(16))) u64 acc[kAccSlots];
-    const int tid = threadIdx.x;
-    ACC_STAMP(0);
-    const int bid = block_base + (int)blockIdx.x;        // a launch may cover a range of levels only (ls2fm_render_opts level groups)
-    int l = 0;
-    while (bid >= plan.first[l + 1]) ++l;
-    const int parts = plan.parts[l];
-    const uint32_t wg = bid - plan.first[l];
-    const uint32_t slab = wg / parts;
-    const int part = (int)(wg % parts);
-    const uint32_t size = lv.size[l];
-    const uint32_t lo = slab << sshift;
-    const uint32_t hi = lo + (1u << sshift) < size ? lo + (1u << sshift) : size;
-
-    // this workgroup's share of the slab's payload list.  Items are taken kAccBatch per lane at a time, the NEXT batch's loads
-    // in flight while the current one is added (a hashed slab of the benchmark is one batch: its loads are issued before the LDS
-    // is zeroed and the streaming phase is LDS atomics only -- per-workgroup stamps: 6.2 -> ... us)
-    const int n_items = bm.count[l * kBins + slab];
-    const ItemT* __restrict__ list = reinterpret_cast<const ItemT*>(bm.items) + bm.start[l * kBins + slab];
-    const int j_lo = (int)((int64_t)n_items * part / parts), j_hi = (int)((int64_t)n_items * (part + 1) / parts);
-    // nothing to add to the tables' current values (decided per SLAB: slab_combine_kernel skips such a slab's partials)
-    if (add_into && n_items == 0) return;
-    // (the loads are UNCONDITIONAL -- out-of-range lanes re-read the list's last item and are masked when it is used: a load
-    // under a branch makes the compiler wait for it right there, one ~2 us round trip per item instead of one per batch)
-    const int j_last = j_hi > j_lo ? j_hi - 1 : j_lo;
-    ItemT buf[kAccBatch];
-#pragma unroll
-    for (int u = 0; u < kAccBatch; ++u) {
-        const int j = j_lo + tid + u * kAccThreads;
-        buf[u] = list[j < j_hi ? j : j_last];
-    }
-    // LDS layout: FEATURE-MAJOR, acc[f * E + entry] with E = the slab size.  (Entry-major -- 32 bytes per entry -- put the 64
-    // lanes of one ds_add_u64 on only FOUR bank pairs, (8 entry + 2 f) mod 32: every atomic instruction of the streaming phase
-    // was a 16-way bank conflict; feature-major spreads them over all 16 pairs.  Per-workgroup stamps, hashed slab of 4096
-    // items: streaming 6.0 -> ... us.)
-    const int E = 1 << sshift;
-    {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        for (int e = tid; e < kAccSlots / 2; e += kAccThreads) reinterpret_cast<uint4*>(acc)[e] = z;
-    }
-#ifdef LS2FM_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[8 * blockIdx.x + 7] = wall_clock64();
-#endif
-    // bound of a single contribution on this level (reduced over the rays by scatter_fill); second grid: rows 16..31
-    float to_fixed1, to_fixed2;
-    double to_float1, to_float2;
-    quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed1, to_float1);
-    quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
-    __syncthreads();
-    ACC_STAMP(1);
-
-    auto add_item = [&](const ItemT& it) {
-        const uint32_t i0 = it.ij & 0xFFFFu, i1 = it.ij >> 16;
-        if constexpr (DUAL) {
-            const float px0 = 1.0f - it.wx;
-            if (i0 != 0xFFFFu) {                             // x-corner 0: px = 1 - wx, derivative sign -
-                u64* slot = acc + i0;
-                add_fixed(slot, fmaf(px0, it.a0, -it.b0), to_fixed1);
-                add_fixed(slot + E, fmaf(px0, it.a1, -it.b1), to_fixed1);
-                add_fixed(slot + 2 * E, px0 * it.c0, to_fixed2);
-                add_fixed(slot + 3 * E, px0 * it.c1, to_fixed2);
-            }
-            if (i1 != 0xFFFFu) {                             // x-corner 1: px = wx, derivative sign +
-                u64* slot = acc + i1;
-                add_fixed(slot, fmaf(it.wx, it.a0, it.b0), to_fixed1);
-                add_fixed(slot + E, fmaf(it.wx, it.a1, it.b1), to_fixed1);
-                add_fixed(slot + 2 * E, it.wx * it.c0, to_fixed2);
-                add_fixed(slot + 3 * E, it.wx * it.c1, to_fixed2);
-            }
-        } else {                                             // explicit corner values (formed by scatter_fill)
-            if (i0 != 0xFFFFu) {
-                add_fixed(acc + i0, it.v00, to_fixed1);
-                add_fixed(acc + E + i0, it.v01, to_fixed1);
-            }
-            if (i1 != 0xFFFFu) {
-                add_fixed(acc + i1, it.v10, to_fixed1);
-                add_fixed(acc + E + i1, it.v11, to_fixed1);
-            }
-        }
-    };
-    for (int base = j_lo + tid; base < j_hi; base += kAccBatch * kAccThreads) {
-        ItemT cur[kAccBatch];
-#pragma unroll
-        for (int u = 0; u < kAccBatch; ++u) cur[u] = buf[u];
-#pragma unroll
-        for (int u = 0; u < kAccBatch; ++u) {                // the next batch: in flight during this batch's atomics (unconditional,
-            const int j = base + (kAccBatch + u) * kAccThreads;      // see above; past the end it re-reads the last item)
-            buf[u] = list[j < j_hi ? j : j_last];
-        }
-#pragma unroll
-        for (int u = 0; u < kAccBatch; ++u)
-            if (base + u * kAccThreads < j_hi) add_item(cur[u]);
-    }
-    __syncthreads();
-    ACC_STAMP(2);
-    // ---- flush: fixed point -> fp32 (one rounding of the exact sum); slot e = F * entry + feature
-    float* dst1 = dtable1 + 2ull * (lv.offset[l] + lo);
-    float* dst2 = DUAL ? dtable2 + 2ull * (lv.offset[l] + lo) : nullptr;
-    if (parts > 1 && combine) {          // partials for slab_combine_kernel: plain coalesced stores, one block per (slab, part)
-        uint4* mine = reinterpret_cast<uint4*>(bm.part_acc + (size_t)(plan.scratch[l] + (int)wg) * kAccSlots);
-        for (int e = tid; e < kAccSlots / 2; e += kAccThreads) mine[e] = reinterpret_cast<const uint4*>(acc)[e];
-        return;
-    }
-    // one thread per ENTRY: its F accumulators (one or two 16-byte LDS reads), one float2 per grid
-    for (int entry = tid; entry < (int)(hi - lo); entry += kAccThreads) {
-        u64 tot[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) tot[f] = acc[f * E + entry];
-        float2 v1 = make_float2((float)((double)(long long)tot[0] * to_float1), (float)((double)(long long)tot[1] * to_float1));
-        float* d1 = dst1 + 2 * entry;
-        if (parts > 1) {                                          // float-atomic form (range zeroed by the backward's zero job
-            if (tot[0] != 0ull) atomicAdd(d1, v1.x);              // -- or holding the first producer's sums: add_into)
-            if (tot[1] != 0ull) atomicAdd(d1 + 1, v1.y);
-        } else if (add_into) {                                    // a second producer of the same table: += (ordered behind the first)
-            if ((tot[0] | tot[1]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d1); v1.x += o.x; v1.y += o.y; *reinterpret_cast<float2*>(d1) = v1; }
-        } else *reinterpret_cast<float2*>(d1) = v1;               // sole writer of the entry
-        if constexpr (DUAL) {
-            float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
-            float* d2 = dst2 + 2 * entry;
-            if (parts > 1) {
-                if (tot[2] != 0ull) atomicAdd(d2, v2.x);
-                if (tot[3] != 0ull) atomicAdd(d2 + 1, v2.y);
-            } else if (add_into) {
-                if ((tot[2] | tot[3]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d2); v2.x += o.x; v2.y += o.y; *reinterpret_cast<float2*>(d2) = v2; }
-            } else *reinterpret_cast<float2*>(d2) = v2;
-        }
-    }
-#ifdef LS2FM_STAMPS
-    __syncthreads();
-    ACC_STAMP(3);
-    if (tid == 0 && blockIdx.x < 4096) { g_acc_stamps[8 * blockIdx.x + 4] = l; g_acc_stamps[8 * blockIdx.x + 5] = j_hi - j_lo; }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------ accumulate, persistent
 // Round 5.  Per-slab stamps of the kernel above (profiles/r04_acc_stamps.txt): 4.8 us prologue (dispatch of a 1024-thread /
@@ -435,6 +332,8 @@ slab_accumulate_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float
 // The sums are the same exactly rounded integers in any order: results are bit-identical to the kernel above.
 struct AccUnit {
     int l, part, parts, wg, n_items, j_lo, j_hi, uid;  // l < 0: no unit
+    int start;                                         // the list's first item (absolute index: the explicit items' ninth word)
+    bool expl;                                         // explicit dual items on this level
     uint32_t slab;
     float bound1, bound2;                              // the level's bounds of a single contribution (read a unit ahead)
     const void* list;
@@ -516,10 +415,12 @@ __device__ __forceinline__ AccUnitRaw acc_unit_fetch(const SlabPlan& plan, const
 }
 
 template <typename ItemT>
-__device__ __forceinline__ AccUnit acc_unit_finish(const AccUnitRaw& r, const BinMeta& bm) {
+__device__ __forceinline__ AccUnit acc_unit_finish(const AccUnitRaw& r, const BinMeta& bm, int n_explicit) {
     AccUnit u;
     u.l = r.l; u.parts = r.parts; u.wg = r.wg; u.slab = (uint32_t)r.slab; u.part = r.wg % r.parts; u.uid = r.uid;
     u.n_items = r.count; u.bound1 = r.bound1; u.bound2 = r.bound2;
+    u.start = r.start;
+    u.expl = r.l >= 0 && r.l < n_explicit;
     u.list = reinterpret_cast<const ItemT*>(bm.items) + r.start;
     if (u.parts == 1) { u.j_lo = 0; u.j_hi = u.n_items; }
     else {            // floor(n part / parts) without a 64-bit division: n = q parts + r
@@ -551,10 +452,12 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
     const int tid = threadIdx.x;
     const int G = (int)gridDim.x;
     const int E = 1 << sshift;
+    const int n_exp = DUAL ? plan.n_explicit : 0;
     // units 0 .. 2G-1 are handed out statically (b, G + b), the rest through the counter (zeroed by scatter_fill's first workgroup)
-    AccUnit cur = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, (int)blockIdx.x, n_units), bm);
-    AccUnit nxt = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, G + (int)blockIdx.x, n_units), bm);
+    AccUnit cur = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, (int)blockIdx.x, n_units), bm, n_exp);
+    AccUnit nxt = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, G + (int)blockIdx.x, n_units), bm, n_exp);
     ItemT buf[kAccBatch];
+    float bufx[DUAL ? kAccBatch : 1];         // ninth word of explicit dual items
     {
         const ItemT* __restrict__ list = reinterpret_cast<const ItemT*>(cur.list);
         const int j_last = cur.j_hi > cur.j_lo ? cur.j_hi - 1 : cur.j_lo;
@@ -562,6 +465,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         for (int u = 0; u < kAccBatch; ++u) {
             const int j = cur.j_lo + tid + u * kAccThreads;
             buf[u] = load_item(list + (j < cur.j_hi ? j : j_last));
+            if (DUAL) bufx[u] = cur.expl ? bm.extra[cur.start + (j < cur.j_hi ? j : j_last)] : 0.f;
         }
     }
     {
@@ -578,9 +482,26 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         double to_float1, to_float2;
         quantum_of(cur.bound1, plan.headroom_bits, to_fixed1, to_float1);
         quantum_of(cur.bound2, plan.headroom_bits, to_fixed2, to_float2);
-        auto add_item = [&](const ItemT& it) {
+        auto add_item = [&](const ItemT& it, float x9) {
             const uint32_t i0 = it.ij & 0xFFFFu, i1 = it.ij >> 16;
             if constexpr (DUAL) {
+                if (cur.expl) {                // explicit item (bin_items.h: explicit_item): the corners' values as they are
+                    if (i0 != 0xFFFFu) {
+                        u64* slot = acc + i0;
+                        add_fixed(slot, it.wx, to_fixed1);
+                        add_fixed(slot + E, it.a0, to_fixed1);
+                        add_fixed(slot + 2 * E, it.b1, to_fixed2);
+                        add_fixed(slot + 3 * E, it.c0, to_fixed2);
+                    }
+                    if (i1 != 0xFFFFu) {
+                        u64* slot = acc + i1;
+                        add_fixed(slot, it.a1, to_fixed1);
+                        add_fixed(slot + E, it.b0, to_fixed1);
+                        add_fixed(slot + 2 * E, it.c1, to_fixed2);
+                        add_fixed(slot + 3 * E, x9, to_fixed2);
+                    }
+                    return;
+                }
                 const float px0 = 1.0f - it.wx;
                 if (i0 != 0xFFFFu) {
                     u64* slot = acc + i0;
@@ -611,16 +532,20 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         int b0 = cur.j_lo;
         do {
             ItemT now[kAccBatch];
+            float nowx[DUAL ? kAccBatch : 1];
 #pragma unroll
-            for (int u = 0; u < kAccBatch; ++u) now[u] = buf[u];
+            for (int u = 0; u < kAccBatch; ++u) { now[u] = buf[u]; if (DUAL) nowx[u] = bufx[u]; }
             const bool more = b0 + BT < cur.j_hi;                       // (uniform)
             const ItemT* __restrict__ list_n = reinterpret_cast<const ItemT*>(more ? cur.list : nxt.list);
             const int lo_n = more ? b0 + BT : nxt.j_lo, hi_n = more ? cur.j_hi : nxt.j_hi;
             const int last_n = hi_n > lo_n ? hi_n - 1 : lo_n;
+            const bool expl_n = DUAL && (more ? cur.expl : nxt.expl);    // (uniform)
+            const float* __restrict__ extra_n = bm.extra + (more ? cur.start : nxt.start);
 #pragma unroll
             for (int u = 0; u < kAccBatch; ++u) {                        // unconditional loads, masked where they are used
                 const int j = lo_n + tid + u * kAccThreads;
                 buf[u] = load_item(list_n + (j < hi_n ? j : last_n));
+                if (DUAL) bufx[u] = expl_n ? extra_n[j < hi_n ? j : last_n] : 0.f;
             }
             // The claim: lane 0 of wave 0, issued WITHOUT waiting for the returned value (as a builtin under `if (tid == 0)` the
             // compiler waits for it at the end of the branch: one memory round trip per unit in front of wave 0's adds), BEHIND
@@ -639,7 +564,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
 #endif
 #pragma unroll
             for (int u = 0; u < kAccBatch; ++u)
-                if (b0 + tid + u * kAccThreads < cur.j_hi) add_item(now[u]);
+                if (b0 + tid + u * kAccThreads < cur.j_hi) add_item(now[u], DUAL ? nowx[u] : 0.f);
             b0 += BT;
         } while (b0 < cur.j_hi);
         PACC_STAMP(cur.uid, 1);
@@ -697,7 +622,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         acc_unit_arrive(nraw.count, nraw.start, nraw.bound1, nraw.bound2);
         PACC_STAMP(cur.uid, 6);
         cur = nxt;
-        nxt = acc_unit_finish<ItemT>(nraw, bm);
+        nxt = acc_unit_finish<ItemT>(nraw, bm, n_exp);
     }
 }
 
@@ -770,10 +695,27 @@ bool levels_fit(const ls2fm_grid_desc* grid, int sshift) {
 
 }  // namespace
 
-// floats of workspace the scatter needs: meta + worst case 8 items (4 pairs, each split) of 32 bytes per (point, level)
+// floats of workspace the scatter needs: meta + worst case 8 items (4 pairs, each split) of 32 bytes per (point, level) + the
+// explicit dual items' ninth word
 int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points) {
     static_assert(sizeof(Item) == 32 && sizeof(ItemS) == 20, "item layouts");
-    return meta_ints(n_points) + part_acc_floats(n_points) + 8 * 8 * (int64_t)n_levels * n_points + 64;
+    return meta_ints(n_points) + part_acc_floats(n_points) + extra_floats(n_points) + 8 * 8 * (int64_t)n_levels * n_points + 64;
+}
+
+// Which leading levels of a dual-field render use explicit, run-merged items (bin_items.h): cells at least one sample spacing
+// wide for a ray that crosses the box along an axis -- resolution <= samples per ray (ETH3D at 128 samples: levels 0 .. 4, 7 ..
+// 1.4 samples per cell; measured at C2: 0 / 3 / 4 / 5 explicit levels -> step 0.519 / 0.506 / 0.504 / 0.502 ms); a prefix of the
+// levels; LS2FM_EXPLICIT_LEVELS overrides (0: the factored item everywhere, rounds 1-4).
+int ls2fm_explicit_levels(const ls2fm_grid_desc* grid, int dual, int n_samples) {
+    static const int forced = [] { const char* e = getenv("LS2FM_EXPLICIT_LEVELS"); return e ? atoi(e) : -1; }();
+    if (!dual || !grid) return 0;
+    int n = 0;
+    if (forced >= 0) n = forced;
+    else
+        while (n < grid->n_levels && n < kMaxExplicitLevels && (long long)grid->resolution[n] <= n_samples) ++n;
+    if (n > kMaxExplicitLevels) n = kMaxExplicitLevels;
+    if (n > grid->n_levels) n = grid->n_levels;
+    return n;
 }
 
 size_t ls2fm_bin_counts_bytes() { return 0; }      // nothing to zero: every count is written, not accumulated
@@ -783,18 +725,19 @@ bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual) { return level
 // payloads from shade_bwd's records, sorted by slab
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
-                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo, int level_hi) {
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo, int level_hi,
+                              int n_explicit) {
     const int64_t r_pad = (n_rays + 63) / 64 * 64;
     const int sshift = ls2fm_slab_shift(dual);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
     if (level_hi < 0) level_hi = grid->n_levels;
     if (level_hi <= level_lo) return LS2FM_OK;
-    const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo));
     // (most recently written lists are read first: slab_accumulate 101 -> 98 us at C2; LS2FM_FILL_REVERSE=0 for the A/B)
     static const int reverse = [] { const char* e = getenv("LS2FM_FILL_REVERSE"); return e ? atoi(e) : 1; }();
-    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo, reverse);
-    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo, reverse);
+    const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo));
+    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo, reverse, n_explicit);
+    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo, reverse, 0);
     return ls2fm_launch_status();
 }
 
@@ -871,24 +814,24 @@ extern "C" int ls2fm_debug_acc_stamps(long long* host) {
 // ls2fm_scatter_zero_range must have run on them before).  add_into: the sums are ADDED to the tables' current values instead
 // (entries without items untouched, nothing zeroed beforehand): a second gradient producer, ordered behind the first one by the caller.
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo, int level_hi, int add_into) {
+                                 hipStream_t stream, int level_lo, int level_hi, int add_into, int n_explicit) {
     const bool dual = dtable2 != nullptr;
     const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
-    const HostPlan h = make_plan(grid, n_points, sshift);
+    HostPlan h = make_plan(grid, n_points, sshift);
+    h.plan.n_explicit = dual ? n_explicit : 0;
     const int combine = g_scatter_mode.load() != 0 ? 1 : 0;
     if (level_hi < 0) level_hi = grid->n_levels;
     const int base = h.plan.first[level_lo], blocks = h.plan.first[level_hi] - base;
     if (blocks <= 0) return LS2FM_OK;
-    // persistent form (default): one resident workgroup per CU walks the units; LS2FM_ACC_PERSISTENT=0: a workgroup per unit
-    static const int persistent = [] { const char* e = getenv("LS2FM_ACC_PERSISTENT"); return e ? atoi(e) : 1; }();
+    // one resident workgroup per CU walks the units (claimed from a counter the scatter_fill launch in front has zeroed)
     static const int n_cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
-    if (persistent) {
+    {
         const int g = blocks < n_cus ? blocks : n_cus;
         int* claim = acc_claim(bm);
         if (dual)
@@ -897,12 +840,7 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
         else
             (add_into ? slab_accumulate_persistent_kernel<false, true> : slab_accumulate_persistent_kernel<false, false>)<<<g, kAccThreads, 0, stream>>>(
                 lv, h.plan, bm, sshift, dtable1, nullptr, base, blocks, combine, claim);
-    } else if (dual)
-        (add_into ? slab_accumulate_kernel<true, true> : slab_accumulate_kernel<true, false>)<<<blocks, kAccThreads, 0, stream>>>(
-            lv, h.plan, bm, sshift, dtable1, dtable2, base, combine);
-    else
-        (add_into ? slab_accumulate_kernel<false, true> : slab_accumulate_kernel<false, false>)<<<blocks, kAccThreads, 0, stream>>>(
-            lv, h.plan, bm, sshift, dtable1, nullptr, base, combine);
+    }
     const int cbase = h.cp.first[level_lo], cblocks = h.cp.first[level_hi] - cbase;
     if (combine && cblocks > 0) {
         if (dual)

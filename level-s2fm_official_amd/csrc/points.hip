@@ -28,9 +28,10 @@ int ls2fm_launch_post_shade(const ls2fm_loss_spec* loss, const float* ray_part, 
                             const ls2fm_grid_desc* scan_grid, int64_t n_points, float* bins_ws, hipStream_t stream);
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
-                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1);
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1,
+                              int n_explicit = 0);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0);
+                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0, int n_explicit = 0);
 int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grads* grads, int in_dim, const Packed* pk,
                               const float* wg, hipStream_t stream, int add = 0);
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);

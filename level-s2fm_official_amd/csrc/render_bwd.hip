@@ -71,9 +71,10 @@ int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grad
 // ------------------------------------------------------------------------------------------- C ABI
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
-                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1);
+                              const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1,
+                              int n_explicit = 0);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0);
+                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0, int n_explicit = 0);
 
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
 
@@ -200,6 +201,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // recorded after each group's accumulate, so that the caller can start all-reducing a group's slices of the gradient
     // tables while the later groups are still being scattered.
     {
+        const int n_explicit = ls2fm_explicit_levels(sdf_grid, dual, field->n_samples);      // as the forward's counting pass
         int groups = opts ? opts->n_level_groups : 1;
         static const int groups_env = [] { const char* e = getenv("LS2FM_LEVEL_GROUPS"); return e ? atoi(e) : 0; }();
         if (groups <= 1 && groups_env > 1 && !db) groups = groups_env;       // (measurement switch: no events, same results)
@@ -209,11 +211,12 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
             const int lo = L1 * gi / groups, hi = L1 * (gi + 1) / groups;
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
             int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
-                                               ws + w.rpt, ws + w.smax, n_rays, dual, s, lo, hi);
+                                               ws + w.rpt, ws + w.smax, n_rays, dual, s, lo, hi, n_explicit);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
             if (st != LS2FM_OK) return fail(forked, sc, st);
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
-            st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s, lo, hi);
+            st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s, lo, hi,
+                                              0, n_explicit);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
             if (st != LS2FM_OK) return fail(forked, sc, st);
             if (opts && opts->n_level_groups > 1 && opts->group_events[gi] &&

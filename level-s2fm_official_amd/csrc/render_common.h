@@ -207,6 +207,8 @@ static inline bool same_grid_geometry(const ls2fm_grid_desc* a, const ls2fm_grid
 }
 
 int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points);
+// leading levels of a dual-field render whose table-gradient items are explicit and run-merged (bin_items.h); 0: none
+int ls2fm_explicit_levels(const ls2fm_grid_desc* grid, int dual, int n_samples);
 
 // Workspace carve-up (offsets in floats).  Channels are SoA with stride p_pad.
 struct WsLayout {

@@ -282,6 +282,7 @@ struct EncodeExtras {
     int* tile_counts;         // [L][n_tiles][kBins] or null: no counting
     int* scan_ticket;
     int n_tiles, sshift;
+    int n_explicit;           // dual field: leading levels whose scatter items are explicit and run-merged (bin_items.h)
     int n_prep_tasks;         // 3: both MLPs + the radiance chain (render); 1: the SDF MLP only (point queries)
     const float* pts;         // [n,3] free points instead of ray samples (point queries), or null
 };
@@ -427,9 +428,10 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                                // already at hand: pair c = (by, bz) -> x-corners k = 2 by + 4 bz and k + 1.  Every lane in
                                // here is live and so is its predecessor (live lanes are a prefix of the wave): the run flags
                                // are those the fill pass derives from the same cells
-            const RunFlags rf = wave_runs(g, true, tid & 63, ex.dual != 0 ? kMergeMinDual : kMergeMinSingle);
+            const bool factored = ex.dual != 0 && l >= ex.n_explicit;        // the factored 32-byte dual item (fine levels)
+            const RunFlags rf = wave_runs(g, true, tid & 63, factored ? kMergeMinDual : kMergeMinSingle);
             if (rf.head) {
-                const bool halves = ex.dual != 0 && rf.merged;                // a merged run of a dual pair: two half items
+                const bool halves = factored && rf.merged;                    // a merged run of a factored pair: two half items
 #pragma unroll
                 for (int cp = 0; cp < 4; ++cp) {
                     const uint32_t i0 = c.idx[2 * cp] - lv.offset, i1 = c.idx[2 * cp + 1] - lv.offset;
@@ -600,6 +602,7 @@ int ls2fm_launch_points_encode(const ls2fm_field_desc* field, const ls2fm_grid_d
     ex.scan_ticket = scan_ticket(bm);
     ex.n_tiles = bm.n_tiles;
     ex.sshift = ls2fm_slab_shift(0);
+    ex.n_explicit = 0;
     ex.n_prep_tasks = 1;
     ex.pts = pts;
     ray_encode_kernel<false><<<(unsigned)(kEncReserved + 8 * most), kEncThreads, 0, s>>>(
@@ -647,6 +650,7 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ex.in_dim = 3 + 2 * L1; ex.in_dim2 = 3 + 2 * L2; ex.rad_in = 3 + 3 + kView + LS2FM_FEAT * (dual ? 2 : 1); ex.dual = dual;
     ex.packed = pk;
     ex.tile_counts = nullptr; ex.scan_ticket = nullptr; ex.n_tiles = 0; ex.sshift = ls2fm_slab_shift(dual);
+    ex.n_explicit = ls2fm_explicit_levels(sdf_grid, dual, field->n_samples);
     ex.n_prep_tasks = 3; ex.pts = nullptr;
     if (prepare_bwd) {
         const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
