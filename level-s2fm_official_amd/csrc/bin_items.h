@@ -67,6 +67,8 @@ __host__ __device__ __forceinline__ Item explicit_item(uint32_t ij, const float*
 struct BinMeta {           // device arrays inside the workspace
     int* count;            // [L][kBins]  items per (level, slab)
     int* start;            // [L][kBins]  absolute offsets into items
+    int* part_ticket;      // [L][kBins]  parts of a point-split slab that have left their partials (zeroed by scatter_fill): the
+                           //             last one to arrive combines the slab (bin_scatter.hip)
     int* tile;             // [L][n_tiles][kBins]  per fill-workgroup counts, turned into absolute offsets by the scan: no
                            //                      global atomics anywhere (1 M of them cost ~50 us per pass), and the item
                            //                      order is deterministic
@@ -215,7 +217,7 @@ static_assert(kCountThreads == kFillThreads, "count and fill classify the same t
 
 inline int64_t meta_ints(int64_t n_points) {
     const int64_t n_tiles = (n_points + kFillTile - 1) / kFillTile;
-    return (2 * LS2FM_MAX_LEVELS * kBins + 64 + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
+    return (3 * LS2FM_MAX_LEVELS * kBins + 64 + LS2FM_MAX_LEVELS * n_tiles * kBins + 63) / 64 * 64;
 }
 
 // Scratch of the point-split slabs (dense / tiny levels whose few slabs receive every point's items: a slab's list is cut into
@@ -235,7 +237,8 @@ inline BinMeta make_bin_meta(float* bins_ws, int64_t n_points) {
     bm.count = meta;
     bm.start = meta + LS2FM_MAX_LEVELS * kBins;
     bm.level_bound = reinterpret_cast<float*>(meta + 2 * LS2FM_MAX_LEVELS * kBins);
-    bm.tile = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
+    bm.part_ticket = meta + 2 * LS2FM_MAX_LEVELS * kBins + 64;
+    bm.tile = meta + 3 * LS2FM_MAX_LEVELS * kBins + 64;
     bm.part_acc = reinterpret_cast<u64*>(meta + meta_ints(n_points));   // 256-byte aligned
     bm.part_blocks = part_blocks_capacity(n_points);
     bm.extra = reinterpret_cast<float*>(meta + meta_ints(n_points) + part_acc_floats(n_points));

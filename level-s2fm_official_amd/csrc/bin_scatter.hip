@@ -73,7 +73,10 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     ItemT* __restrict__ g_items = reinterpret_cast<ItemT*>(bm.items);
     // levels are walked last to first: the accumulate launch reads the lists first to last, i.e. most recently written first
     const int tid = threadIdx.x, lane = tid & 63, l = level_base + (reverse ? (int)(gridDim.y - 1u - blockIdx.y) : (int)blockIdx.y);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *acc_claim(bm) = 0;      // unit counter of the accumulate launch behind this one
+    if (blockIdx.x == 0 && blockIdx.y == 0) {        // armed for the accumulate launch behind this one: unit counter, slab tickets
+        if (tid == 0) *acc_claim(bm) = 0;
+        for (int q = tid; q < LS2FM_MAX_LEVELS * kBins; q += kFillThreads) bm.part_ticket[q] = 0;
+    }
     static_assert(kBins <= kFillThreads, "one thread per slab for the run offsets");
     int pre_base = 0;
     if (tid < kBins) pre_base = bm.start[l * kBins + tid] + bm.tile[((int64_t)l * bm.n_tiles + blockIdx.x) * kBins + tid];
@@ -129,6 +132,54 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         hist[tid] = 0;
     }
     __syncthreads();
+    // the two x-corners' values of corner pair c = by + 2 bz, both grids:
+    //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
+    auto pair_factors = [&](unsigned c, float (&a)[2], float (&b)[2], float (&cc)[2]) {
+        const int by = c & 1, bz = c >> 1;
+        const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
+        const float pyz = py * pz;
+        const float qyz = (by ? qd[1] : -qd[1]) * pz + py * (bz ? qd[2] : -qd[2]);
+        a[0] = fmaf(qyz, r0, pyz * d0);
+        a[1] = fmaf(qyz, r1, pyz * d1);
+        b[0] = qd[0] * pyz * r0;
+        b[1] = qd[0] * pyz * r1;
+        cc[0] = pyz * e0;
+        cc[1] = pyz * e1;
+    };
+    if constexpr (!DUAL) {
+        // ---- single field: 20-byte explicit items, ONE staging area for all of them (26 KB): ranked and staged in one pass
+        // over the pairs (the windowed form below enumerates them once more: 52 -> 57 us)
+        float val[16];
+        {
+            const float px0 = 1.0f - w[0];
+#pragma unroll
+            for (unsigned c = 0; c < 4; ++c) {
+                float a[2], b[2], cc[2];
+                pair_factors(c, a, b, cc);
+                val[4 * c + 0] = fmaf(px0, a[0], -b[0]);
+                val[4 * c + 1] = fmaf(px0, a[1], -b[1]);
+                val[4 * c + 2] = fmaf(w[0], a[0], b[0]);
+                val[4 * c + 3] = fmaf(w[0], a[1], b[1]);
+            }
+        }
+        if (rf.cont != 0ull) run_sums<16>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
+        for_each_item_merged(L, g, rf, false, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
+            ItemT it;
+            it.ij = i0 | (i1 << 16);
+            it.v00 = val[4 * c + 0]; it.v01 = val[4 * c + 1];
+            it.v10 = val[4 * c + 2]; it.v11 = val[4 * c + 3];
+            int rank = atomicAdd(&hist[slab], 1);
+            const int n_run = run_len[slab];                 // (long runs are stored permuted: see below)
+            if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
+            const int slot = lds_off[slab] + rank;
+            const uint32_t gi = (uint32_t)(base[slab] + rank);
+            if (slot < kWin) { s_items[slot] = it; s_gidx[slot] = gi; }
+            else g_items[gi] = it;                           // more split pairs than the staging area holds: direct write
+        });
+        __syncthreads();
+        const int staged = s_total < kWin ? s_total : kWin;
+        for (int q = tid; q < staged; q += kFillThreads) g_items[s_gidx[q]] = s_items[q];
+    } else {
     // every item's slot in the workgroup's sorted order
     // (named scalars, 16 bits per slot: as arrays indexed by the lambda's pair number they went to scratch memory)
     uint32_t sl0 = 0u, sl1 = 0u, sl2 = 0u, sl3 = 0u;
@@ -152,20 +203,6 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         put_slot(c, i0 == 0xFFFFu, slot);
     });
     const int total = s_total;
-    // the two x-corners' values of corner pair c = by + 2 bz, both grids:
-    //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
-    auto pair_factors = [&](unsigned c, float (&a)[2], float (&b)[2], float (&cc)[2]) {
-        const int by = c & 1, bz = c >> 1;
-        const float py = by ? w[1] : 1.0f - w[1], pz = bz ? w[2] : 1.0f - w[2];
-        const float pyz = py * pz;
-        const float qyz = (by ? qd[1] : -qd[1]) * pz + py * (bz ? qd[2] : -qd[2]);
-        a[0] = fmaf(qyz, r0, pyz * d0);
-        a[1] = fmaf(qyz, r1, pyz * d1);
-        b[0] = qd[0] * pyz * r0;
-        b[1] = qd[0] * pyz * r1;
-        cc[0] = pyz * e0;
-        cc[1] = pyz * e1;
-    };
     auto write_out = [&](int win) {
         // runs of one slab are contiguous in the sorted order and in memory: consecutive threads write consecutive items
         const int staged = total - win < kWin ? total - win : kWin;
@@ -179,23 +216,10 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         }
     };
     if (!expl) {
-        // ---- factored dual items / the single field's explicit items
-        constexpr int NV = DUAL ? 1 : 16;
-        float fa[4][2], fb[4][2], fcc[4][2], val[NV];
-        {
-            const float px0 = 1.0f - w[0];
+        // ---- factored dual items
+        float fa[4][2], fb[4][2], fcc[4][2];
 #pragma unroll
-            for (unsigned c = 0; c < 4; ++c) {
-                pair_factors(c, fa[c], fb[c], fcc[c]);
-                if (!DUAL) {
-                    val[4 * c + 0] = fmaf(px0, fa[c][0], -fb[c][0]);
-                    val[4 * c + 1] = fmaf(px0, fa[c][1], -fb[c][1]);
-                    val[4 * c + 2] = fmaf(w[0], fa[c][0], fb[c][0]);
-                    val[4 * c + 3] = fmaf(w[0], fa[c][1], fb[c][1]);
-                }
-            }
-        }
-        if (!DUAL && rf.cont != 0ull) run_sums<NV>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
+        for (unsigned c = 0; c < 4; ++c) pair_factors(c, fa[c], fb[c], fcc[c]);
         for (int win = 0; win < total; win += kWin) {
             if (win > 0) __syncthreads();                     // the previous window has been written out
             for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
@@ -203,22 +227,17 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
                 if (rel < 0 || rel >= kWin) return;
                 ItemT it;
                 it.ij = i0 | (i1 << 16);
-                if constexpr (DUAL) {
-                    it.wx = w[0];
-                    it.a0 = fa[c][0]; it.a1 = fa[c][1];
-                    it.b0 = fb[c][0]; it.b1 = fb[c][1];
-                    it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
-                } else {
-                    it.v00 = val[4 * c + 0]; it.v01 = val[4 * c + 1];
-                    it.v10 = val[4 * c + 2]; it.v11 = val[4 * c + 3];
-                }
+                it.wx = w[0];
+                it.a0 = fa[c][0]; it.a1 = fa[c][1];
+                it.b0 = fb[c][0]; it.b1 = fb[c][1];
+                it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
                 s_items[rel] = it;
                 s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
             });
             __syncthreads();
             write_out(win);
         }
-    } else if constexpr (DUAL) {
+    } else {
         // ---- explicit dual items, pair by pair: the pair's eight corner values, their sums over the run, its item(s)
         const uint32_t lmask = (1u << L.sshift) - 1u;
         const float px0 = 1.0f - w[0];
@@ -255,6 +274,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
             write_out(win);
         }
     }
+    }       // (dual field)
     // the level's first workgroup also reduces the per-ray bounds of a single contribution (written by shade_bwd) to the
     // level's bound: the accumulate workgroups read two floats instead of n_rays each
     if (blockIdx.x == 0) {
@@ -318,6 +338,57 @@ __device__ long long g_acc_stamps[8 * 4096];
 //                bit for bit, nothing is zeroed beforehand and no floating-point atomic is left in the path.
 //   combine = 0  float atomics into a table range zeroed by the backward's zero job (rounds 1-3): one launch fewer, sums of
 //                rounded partials in arrival order.
+
+// ---- the point-split slabs' partials -> table entries (combine form): entry `entry` of slab `slab` on level l.  Integer sums:
+// exact, order-independent.
+template <bool DUAL, bool ADD_INTO>
+__device__ __forceinline__ void combine_entry(const LevelSet& lv, const SlabPlan& plan, const BinMeta& bm, int sshift, float* __restrict__ dtable1,
+                                              float* __restrict__ dtable2, int l, uint32_t slab, int entry, float bound1, float bound2) {
+    constexpr int F = DUAL ? 4 : 2;
+    const uint32_t lo = slab << sshift;
+    const uint32_t hi = lo + (1u << sshift) < lv.size[l] ? lo + (1u << sshift) : lv.size[l];
+    if (lo + (uint32_t)entry >= hi) return;
+    const int parts = plan.parts[l];
+    float to_fixed, to_fixed2;
+    double to_float1, to_float2;
+    quantum_of(bound1, plan.headroom_bits, to_fixed, to_float1);
+    quantum_of(bound2, plan.headroom_bits, to_fixed2, to_float2);
+    // partials are feature-major like the accumulators: [part][f * E + entry].  Loads of kCombineBatch parts are issued together
+    // (a part beyond the last re-reads the last one and is masked): one memory round trip per batch, not per part
+    const int E = 1 << sshift;
+    const u64* __restrict__ src = bm.part_acc + (size_t)(plan.scratch[l] + (int)slab * parts) * kAccSlots + entry;
+    u64 tot[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) tot[f] = 0ull;
+    constexpr int kCombineBatch = 4;
+    for (int q0 = 0; q0 < parts; q0 += kCombineBatch) {
+        u64 v[kCombineBatch][F];
+#pragma unroll
+        for (int u = 0; u < kCombineBatch; ++u) {
+            const int q = q0 + u < parts ? q0 + u : parts - 1;
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[u][f] = src[(size_t)q * kAccSlots + f * E];
+        }
+#pragma unroll
+        for (int u = 0; u < kCombineBatch; ++u)
+            if (q0 + u < parts) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) tot[f] += v[u][f];
+            }
+    }
+    float2 v1 = make_float2((float)((double)(long long)tot[0] * to_float1), (float)((double)(long long)tot[1] * to_float1));
+    float2* d1 = reinterpret_cast<float2*>(dtable1 + 2ull * (lv.offset[l] + lo + entry));
+    if (ADD_INTO) {
+        if ((tot[0] | tot[1]) != 0ull) { const float2 o = *d1; v1.x += o.x; v1.y += o.y; *d1 = v1; }
+    } else *d1 = v1;
+    if constexpr (DUAL) {
+        float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
+        float2* d2 = reinterpret_cast<float2*>(dtable2 + 2ull * (lv.offset[l] + lo + entry));
+        if (ADD_INTO) {
+            if ((tot[2] | tot[3]) != 0ull) { const float2 o = *d2; v2.x += o.x; v2.y += o.y; *d2 = v2; }
+        } else *d2 = v2;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ accumulate, persistent
 // Round 5.  Per-slab stamps of the kernel above (profiles/r04_acc_stamps.txt): 4.8 us prologue (dispatch of a 1024-thread /
@@ -448,7 +519,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
     constexpr int F = DUAL ? 4 : 2;
     constexpr int BT = kAccBatch * kAccThreads;
     __shared__ __attribute__((aligned(16))) u64 acc[kAccSlots];
-    __shared__ int s_claim;
+    __shared__ int s_claim, s_claim2;
     const int tid = threadIdx.x;
     const int G = (int)gridDim.x;
     const int E = 1 << sshift;
@@ -579,13 +650,33 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         const uint32_t size = lv.size[l];
         const uint32_t lo = cur.slab << sshift;
         const uint32_t hi = lo + (1u << sshift) < size ? lo + (1u << sshift) : size;
-        if (cur.parts > 1 && combine) {          // partials for slab_combine_kernel (ADD_INTO: an empty slab's are never read)
+        if (cur.parts > 1 && combine) {
+            // A part of a point-split slab: its fixed-point partials go to scratch; the LAST part of the slab to get here (a ticket
+            // per slab, zeroed by scatter_fill) sums all of them -- integers: exact, order-independent -- and writes the entries.
+            // No combine launch behind this kernel (11 us at the end of the backward's chain), and no workgroup ever waits for
+            // another: nothing to deadlock on.  Hand-off: plain stores, a full barrier (every wave's stores have left), one lane's
+            // agent-scope release + drained counter, then the ticket; the last arriver acquires at agent scope before it reads.
+            // (ADD_INTO: an empty slab has nothing to add -- its parts skip all of this.)
             if (!(ADD_INTO && cur.n_items == 0)) {
                 uint4* mine = reinterpret_cast<uint4*>(bm.part_acc + (size_t)(plan.scratch[l] + cur.wg) * kAccSlots);
                 const uint4 z = make_uint4(0u, 0u, 0u, 0u);
                 for (int e = tid; e < kAccSlots / 2; e += kAccThreads) {
                     mine[e] = reinterpret_cast<const uint4*>(acc)[e];
                     reinterpret_cast<uint4*>(acc)[e] = z;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int arrived = __hip_atomic_fetch_add(&bm.part_ticket[l * kBins + (int)cur.slab], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = arrived == cur.parts - 1;
+                    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    s_claim2 = last;
+                }
+                __syncthreads();
+                if (s_claim2) {
+                    for (int entry = tid; entry < E; entry += kAccThreads)
+                        combine_entry<DUAL, ADD_INTO>(lv, plan, bm, sshift, dtable1, dtable2, l, cur.slab, entry, cur.bound1, cur.bound2);
                 }
             }
         } else if (!(ADD_INTO && cur.n_items == 0)) {
@@ -623,67 +714,6 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         PACC_STAMP(cur.uid, 6);
         cur = nxt;
         nxt = acc_unit_finish<ItemT>(nraw, bm, n_exp);
-    }
-}
-
-// ---- the point-split slabs' partials -> table entries (combine form).  Block = 1024 entries of one split slab.
-struct CombinePlan { int first[LS2FM_MAX_LEVELS + 1]; };      // first block of every level (levels with parts == 1: none)
-
-template <bool DUAL, bool ADD_INTO>
-__global__ void __launch_bounds__(kAccThreads)
-slab_combine_kernel(LevelSet lv, SlabPlan plan, CombinePlan cp, BinMeta bm, int sshift, float* __restrict__ dtable1,
-                    float* __restrict__ dtable2, int block_base) {
-    constexpr int F = DUAL ? 4 : 2;
-    const int bid = block_base + (int)blockIdx.x;
-    int l = 0;
-    while (bid >= cp.first[l + 1]) ++l;
-    const int chunks = (1 << sshift) / kAccThreads;           // blocks per slab
-    const int rel = bid - cp.first[l];
-    const uint32_t slab = (uint32_t)(rel / chunks);
-    const int entry = (rel % chunks) * kAccThreads + (int)threadIdx.x;
-    const uint32_t lo = slab << sshift;
-    const uint32_t hi = lo + (1u << sshift) < lv.size[l] ? lo + (1u << sshift) : lv.size[l];
-    if (lo + (uint32_t)entry >= hi) return;
-    if (ADD_INTO && bm.count[l * kBins + (int)slab] == 0) return;         // its parts returned without writing partials
-    const int parts = plan.parts[l];
-    float to_fixed, to_fixed2;
-    double to_float1, to_float2;
-    quantum_of(bm.level_bound[l], plan.headroom_bits, to_fixed, to_float1);
-    quantum_of(DUAL ? bm.level_bound[16 + l] : 0.f, plan.headroom_bits, to_fixed2, to_float2);
-    // partials are feature-major like the accumulators: [part][f * E + entry].  Loads of kCombineBatch parts are issued together
-    // (a part beyond the last re-reads the last one and is masked): one memory round trip per batch, not per part
-    const int E = 1 << sshift;
-    const u64* __restrict__ src = bm.part_acc + (size_t)(plan.scratch[l] + (int)slab * parts) * kAccSlots + entry;
-    u64 tot[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) tot[f] = 0ull;
-    constexpr int kCombineBatch = 8;
-    for (int q0 = 0; q0 < parts; q0 += kCombineBatch) {
-        u64 v[kCombineBatch][F];
-#pragma unroll
-        for (int u = 0; u < kCombineBatch; ++u) {
-            const int q = q0 + u < parts ? q0 + u : parts - 1;
-#pragma unroll
-            for (int f = 0; f < F; ++f) v[u][f] = src[(size_t)q * kAccSlots + f * E];
-        }
-#pragma unroll
-        for (int u = 0; u < kCombineBatch; ++u)
-            if (q0 + u < parts) {
-#pragma unroll
-                for (int f = 0; f < F; ++f) tot[f] += v[u][f];
-            }
-    }
-    float2 v1 = make_float2((float)((double)(long long)tot[0] * to_float1), (float)((double)(long long)tot[1] * to_float1));
-    float2* d1 = reinterpret_cast<float2*>(dtable1 + 2ull * (lv.offset[l] + lo + entry));
-    if (ADD_INTO) {
-        if ((tot[0] | tot[1]) != 0ull) { const float2 o = *d1; v1.x += o.x; v1.y += o.y; *d1 = v1; }
-    } else *d1 = v1;
-    if constexpr (DUAL) {
-        float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
-        float2* d2 = reinterpret_cast<float2*>(dtable2 + 2ull * (lv.offset[l] + lo + entry));
-        if (ADD_INTO) {
-            if ((tot[2] | tot[3]) != 0ull) { const float2 o = *d2; v2.x += o.x; v2.y += o.y; *d2 = v2; }
-        } else *d2 = v2;
     }
 }
 
@@ -742,32 +772,38 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
 }
 
 namespace {
-struct HostPlan { SlabPlan plan; CombinePlan cp; int total, zero_lo, zero_hi; };
+struct HostPlan { SlabPlan plan; int total, zero_lo, zero_hi; };
 
-// 1: the point-split levels are combined in fixed point by slab_combine_kernel (deterministic, exactly rounded; default)
+// 1: the point-split levels are combined in fixed point by the last part of a slab to finish (deterministic, exactly rounded; default)
 // 0: float atomics into a zeroed range (rounds 1-3)
 std::atomic<int> g_scatter_mode{[] { const char* e = getenv("LS2FM_SCATTER_MODE"); return e ? atoi(e) : 1; }()};
 
-HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift) {
+// n_explicit / n_samples: on the dual field's explicit levels consecutive samples of a ray in one cell travel as one item
+// (bin_items.h) -- ~0.9 n_samples / resolution of them (measured at C2: 7.0 / 4.4 / 3.0 / 2.0 on levels 0 .. 3): fewer items
+// per slab, fewer parts to cut its list into
+HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift, int n_explicit = 0, int n_samples = 1) {
     const int capacity = part_blocks_capacity(n_points);
-    const int chunks = (1 << sshift) / kAccThreads;
     for (int max_parts = kMaxParts;; --max_parts) {
         HostPlan h{};
         for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) h.plan.parts[l] = 1;
         h.plan.headroom_bits = 4;                // 8 corners per point (+1)
         while ((1ll << (h.plan.headroom_bits - 4)) < n_points) ++h.plan.headroom_bits;
+        h.plan.n_explicit = n_explicit < LS2FM_MAX_LEVELS ? n_explicit : 0;        // (the kernels' flag is a dual-field one)
         h.zero_lo = h.zero_hi = -1;
         const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
-        int scratch = 0, comb = 0;
+        int scratch = 0;
         for (int l = 0; l < LS2FM_MAX_LEVELS + 1; ++l) {
             h.plan.first[l] = h.total;
-            h.cp.first[l] = comb;
             if (l >= grid->n_levels) continue;
             const int slabs = level_slabs(grid->size[l], sshift);
             int parts = 1;
             if (!grid->hashed[l] || slabs < 16) {
                 // dense / tiny level: 4 pair items per point spread over few slabs -> split the slabs' lists
-                const int64_t per_block = 4 * n_points / slabs;
+                int64_t per_block = 4 * n_points / slabs;
+                if (l < n_explicit) {
+                    const double run = 0.9 * (double)n_samples / (double)grid->resolution[l];
+                    if (run > 1.0) per_block = (int64_t)((double)per_block / run);
+                }
                 parts = (int)((per_block + target - 1) / target);
                 if (parts > max_parts) parts = max_parts;
                 if (parts < 1) parts = 1;
@@ -776,7 +812,6 @@ HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift) {
             h.plan.scratch[l] = scratch;
             if (parts > 1) {
                 scratch += slabs * parts;        // one block of partials per (slab, part)
-                comb += slabs * chunks;
                 if (h.zero_lo < 0) h.zero_lo = l;
                 h.zero_hi = l;
             }
@@ -814,13 +849,13 @@ extern "C" int ls2fm_debug_acc_stamps(long long* host) {
 // ls2fm_scatter_zero_range must have run on them before).  add_into: the sums are ADDED to the tables' current values instead
 // (entries without items untouched, nothing zeroed beforehand): a second gradient producer, ordered behind the first one by the caller.
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo, int level_hi, int add_into, int n_explicit) {
+                                 hipStream_t stream, int level_lo, int level_hi, int add_into, int n_explicit, int n_samples) {
     const bool dual = dtable2 != nullptr;
     const int sshift = ls2fm_slab_shift(dual ? 1 : 0);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
     const LevelSet lv = make_level_set(grid);
-    HostPlan h = make_plan(grid, n_points, sshift);
-    h.plan.n_explicit = dual ? n_explicit : 0;
+    // (single field: explicit, run-merged items on every level)
+    const HostPlan h = make_plan(grid, n_points, sshift, dual ? n_explicit : LS2FM_MAX_LEVELS, n_samples);
     const int combine = g_scatter_mode.load() != 0 ? 1 : 0;
     if (level_hi < 0) level_hi = grid->n_levels;
     const int base = h.plan.first[level_lo], blocks = h.plan.first[level_hi] - base;
@@ -840,15 +875,6 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
         else
             (add_into ? slab_accumulate_persistent_kernel<false, true> : slab_accumulate_persistent_kernel<false, false>)<<<g, kAccThreads, 0, stream>>>(
                 lv, h.plan, bm, sshift, dtable1, nullptr, base, blocks, combine, claim);
-    }
-    const int cbase = h.cp.first[level_lo], cblocks = h.cp.first[level_hi] - cbase;
-    if (combine && cblocks > 0) {
-        if (dual)
-            (add_into ? slab_combine_kernel<true, true> : slab_combine_kernel<true, false>)<<<cblocks, kAccThreads, 0, stream>>>(
-                lv, h.plan, h.cp, bm, sshift, dtable1, dtable2, cbase);
-        else
-            (add_into ? slab_combine_kernel<false, true> : slab_combine_kernel<false, false>)<<<cblocks, kAccThreads, 0, stream>>>(
-                lv, h.plan, h.cp, bm, sshift, dtable1, nullptr, cbase);
     }
     return ls2fm_launch_status();
 }

@@ -74,7 +74,8 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1,
                               int n_explicit = 0);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
-                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0, int n_explicit = 0);
+                                 hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0, int n_explicit = 0,
+                                 int n_samples = 1);
 
 bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual);
 
@@ -216,7 +217,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
             if (st != LS2FM_OK) return fail(forked, sc, st);
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
             st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s, lo, hi,
-                                              0, n_explicit);
+                                              0, n_explicit, field->n_samples);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_SDF, s);
             if (st != LS2FM_OK) return fail(forked, sc, st);
             if (opts && opts->n_level_groups > 1 && opts->group_events[gi] &&
