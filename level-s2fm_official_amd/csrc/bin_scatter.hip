@@ -44,6 +44,16 @@ namespace {
 // and no overflow path (any item count is served).  Every item's slot is fixed once (rank = LDS atomic) and kept in registers;
 // a window pass re-derives the item's indices (eight hashes) and stages the items whose slot falls into the window.  The
 // run offsets (two dependent global loads per slab) are requested at the very top, ahead of the records.
+#ifndef LS2FM_FILL_NT
+#define LS2FM_FILL_NT 0
+#endif
+// how the accumulate pass stores the gradient tables: 1 = non-temporal (default: 100 MB that nothing reads before the optimizer --
+// kept out of the L2s they leave the table slices and item lists in place: slab_accumulate 84 -> 76 us and the NEXT step's gather
+// pass 104 -> 98 us at C2), 0 = plain, 2 = write-through (sc1: no gain).  The fill's item stores stay plain: as nt / sc1 stores of
+// 16-byte halves they cost 190 instead of 86 us.
+#ifndef LS2FM_ACC_NT_STORE
+#define LS2FM_ACC_NT_STORE 1
+#endif
 #ifndef LS2FM_FILL_PROBE
 #define LS2FM_FILL_PROBE 0
 #endif
@@ -211,6 +221,23 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
 #endif
         for (int q = tid; q < staged; q += kFillThreads) {
             const uint32_t gi = s_gidx[q];
+#if LS2FM_FILL_NT
+            if constexpr (DUAL) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4* src = reinterpret_cast<const u32x4*>(&s_items[q]);
+                u32x4* dst = reinterpret_cast<u32x4*>(&g_items[gi]);
+#if LS2FM_FILL_NT == 2
+                const u32x4 h0 = src[0], h1 = src[1];
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(dst), "v"(h0), "v"(h1) : "memory");
+#elif LS2FM_FILL_NT == 3
+                const u32x4 h0 = src[0], h1 = src[1];
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" :: "v"(dst), "v"(h0), "v"(h1) : "memory");
+#else
+                __builtin_nontemporal_store(src[0], dst);
+                __builtin_nontemporal_store(src[1], dst + 1);
+#endif
+            } else
+#endif
             g_items[gi] = s_items[q];
             if (DUAL && expl) bm.extra[gi] = s_extra[q];
         }
@@ -433,6 +460,22 @@ __device__ __forceinline__ ItemS load_item(const ItemS* p) {
     return u.it;
 #else
     return *p;
+#endif
+}
+
+// one entry of a gradient table, written once by its sole owner and not read again in this launch: plain, non-temporal (1) or
+// write-through (2) stores -- the table is the optimizer's input much later, keeping its lines in this XCD's L2 only evicts others
+__device__ __forceinline__ void store_entry(float* d, const float2 v) {
+#if LS2FM_ACC_NT_STORE == 2
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 r = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(d), "v"(r) : "memory");
+#elif LS2FM_ACC_NT_STORE == 1
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 r = {v.x, v.y};
+    __builtin_nontemporal_store(r, reinterpret_cast<f32x2*>(d));
+#else
+    *reinterpret_cast<float2*>(d) = v;
 #endif
 }
 
@@ -693,7 +736,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
                     if (tot[1] != 0ull) atomicAdd(d1 + 1, v1.y);
                 } else if (ADD_INTO) {
                     if ((tot[0] | tot[1]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d1); v1.x += o.x; v1.y += o.y; *reinterpret_cast<float2*>(d1) = v1; }
-                } else *reinterpret_cast<float2*>(d1) = v1;
+                } else store_entry(d1, v1);
                 if constexpr (DUAL) {
                     float2 v2 = make_float2((float)((double)(long long)tot[2] * to_float2), (float)((double)(long long)tot[3] * to_float2));
                     float* d2 = dst2 + 2 * entry;
@@ -702,7 +745,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
                         if (tot[3] != 0ull) atomicAdd(d2 + 1, v2.y);
                     } else if (ADD_INTO) {
                         if ((tot[2] | tot[3]) != 0ull) { const float2 o = *reinterpret_cast<float2*>(d2); v2.x += o.x; v2.y += o.y; *reinterpret_cast<float2*>(d2) = v2; }
-                    } else *reinterpret_cast<float2*>(d2) = v2;
+                    } else store_entry(d2, v2);
                 }
             }
         }
