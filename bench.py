@@ -451,7 +451,7 @@ def main():
         # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter summary of
         # this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is QUOTED when the workload
         # is the default one -- with the commit it was measured at, so a stale figure is recognisable
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(q)), "")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(q)), "")
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
             doc = json.load(open(pmc))
             if roofline["kernel"].startswith("scatter_pair") and "scatter_fill" in doc and "slab_accumulate" in doc:

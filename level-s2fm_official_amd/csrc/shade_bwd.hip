@@ -42,6 +42,27 @@ constexpr int kTRows = 48;     // da | gj | h of one hidden block (U / V: 36 row
 constexpr int kSwWg = kMfmaBwdSdfFloats - 4 * 4 * 64 + 64;       // WG: W1[0] as 64 floats instead of its operand-ordered 4 KB
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// the scatter's records: written once here, read once by scatter_fill (any XCD) -- optionally non-temporal (LS2FM_REC_NT)
+#ifndef LS2FM_REC_NT
+#define LS2FM_REC_NT 1
+#endif
+__device__ __forceinline__ void st4(float* p, const float4 v) {
+#if LS2FM_REC_NT
+    const f32x4 r = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st2(float* p, const float2 v) {
+#if LS2FM_REC_NT
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 r = {v.x, v.y};
+    __builtin_nontemporal_store(r, reinterpret_cast<f32x2*>(p));
+#else
+    *reinterpret_cast<float2*>(p) = v;
+#endif
+}
 // lane J of this lane's 16-lane row (DPP row_share: folds into the consuming VALU instruction)
 template <int J> __device__ __forceinline__ float row_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, false));
@@ -551,9 +572,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc)
             if (live_c[cc] && g == 0) {
-                float4* dst = reinterpret_cast<float4*>(out + w.rpt + (int64_t)is[cc] * 8);
-                dst[0] = make_float4(xg[cc][0], xg[cc][1], xg[cc][2], gns[cc][0]);
-                dst[1] = make_float4(gns[cc][1], gns[cc][2], 0.f, 0.f);
+                float* dst = out + w.rpt + (int64_t)is[cc] * 8;
+                st4(dst, make_float4(xg[cc][0], xg[cc][1], xg[cc][2], gns[cc][0]));
+                st4(dst + 4, make_float4(gns[cc][1], gns[cc][2], 0.f, 0.f));
             }
 
         // (WG) U, V, GF of this tile as operands of the contraction over the samples: row jl (+ 16 mk), samples 4g .. 4g + 3.
@@ -696,7 +717,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     if (2 * l < ch1 && live_c[cc]) {
                         const float d0 = de[mk][cc][2 * hv], d1 = de[mk][cc][2 * hv + 1];
                         const float r0 = rr[mk][cc][2 * hv], r1 = rr[mk][cc][2 * hv + 1];
-                        *reinterpret_cast<float4*>(out + w.rec1 + ((int64_t)l * P + is[cc]) * 4) = make_float4(d0, d1, r0, r1);
+                        st4(out + w.rec1 + ((int64_t)l * P + is[cc]) * 4, make_float4(d0, d1, r0, r1));
                         const float b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[l] * g1[cc] * fmaxf(fabsf(r0), fabsf(r1));
                         bnd[mk][hv] = fmaxf(bnd[mk][hv], b);
                     }
@@ -830,7 +851,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         const int l = 8 * mk + 2 * g + hv;
                         if (2 * l < ch2 && live_c[cc]) {
                             const float d0 = de2[mk][cc][2 * hv], d1 = de2[mk][cc][2 * hv + 1];
-                            *reinterpret_cast<float2*>(out + w.rec2 + ((int64_t)l * P + is[cc]) * 2) = make_float2(d0, d1);
+                            st2(out + w.rec2 + ((int64_t)l * P + is[cc]) * 2, make_float2(d0, d1));
                             bnd[mk][hv] = fmaxf(bnd[mk][hv], fmaxf(fabsf(d0), fabsf(d1)));
                         }
                     }

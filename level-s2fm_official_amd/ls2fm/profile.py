@@ -48,7 +48,17 @@ def algorithmic_work(n_points: int, dual: bool, n_levels: int = 16):
         "shade_fwd": ("mfma", 2 * fwd_macs * n_points), "shade_bwd": ("mfma", 2 * bwd_macs * n_points),
         "wgrad_mlp_sdf": ("mfma", 2 * (64 * 36 + 64 * 35 + 17 * 65 + 64) * n_points),
         "wgrad_mlp_geo": ("mfma", 2 * (64 * 36 + 17 * 65) * n_points),
+        "_dual": dual,
     }
+
+
+def _fused_wgrad(times, work):
+    """round 5: shade_bwd contracts the MLPs' weight gradients itself (no wgrad_mlp launch in the render's backward) -- their
+    GEMMs are then part of ITS algorithmic work"""
+    if "shade_bwd" in times and "wgrad_mlp_sdf" not in times and "wgrad_mlp_geo" not in times:
+        work = dict(work)
+        work["shade_bwd"] = ("mfma", work["shade_bwd"][1] + work["wgrad_mlp_sdf"][1] + work["wgrad_mlp_geo"][1] * (1 if work.get("_dual") else 0))
+    return work
 
 
 def _fractions(times, work, hbm_peak_gbs, f32_peak_tflops):
@@ -59,7 +69,7 @@ def _fractions(times, work, hbm_peak_gbs, f32_peak_tflops):
         pair_us = times["scatter_fill"][0] + times["slab_accumulate"][0]
         times["scatter_pair"] = (pair_us, times["scatter_fill"][1], times["scatter_fill"][2] + times["slab_accumulate"][2])
     for name, (avg_us, _, _) in times.items():
-        if name not in work:
+        if name not in work or name.startswith("_"):
             continue
         bound, amount = work[name]
         rate = amount / (avg_us * 1e-6)
@@ -72,7 +82,7 @@ def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float
     times = kernel_times(lib)
     if not times:
         return None
-    work = algorithmic_work(n_points, dual)
+    work = _fused_wgrad(times, algorithmic_work(n_points, dual))
     name = max(times, key=lambda k: times[k][2])          # a single kernel (the scatter's two passes are separate launches)
     avg_us, launches, total_ms = times[name]
     grand = sum(t[2] for t in times.values())
