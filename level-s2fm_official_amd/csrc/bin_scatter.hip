@@ -33,6 +33,7 @@
 #include <cstdlib>
 
 #include "bin_items.h"
+#include "side_jobs.h"
 
 namespace {
 
@@ -69,21 +70,34 @@ __global__ void __launch_bounds__(kFillThreads, LS2FM_FILL_MINW)
 scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray, int64_t n_points,
                     int64_t p_pad, int sshift, const float* __restrict__ rpt, const float* __restrict__ rec1,
                     const float* __restrict__ rec2, const float* __restrict__ ray_bound, int64_t n_rays, int64_t r_pad,
-                    BinMeta bm, int level_base, int reverse, int n_explicit) {
+                    BinMeta bm, int level_base, int reverse, int n_explicit, SideJobs sj) {
     typedef typename ItemOf<DUAL>::type ItemT;
     __shared__ int hist[kBins];          // items of this workgroup per slab, then running rank
     __shared__ int lds_off[kBins];       // first slot (in the workgroup's sorted order) of the slab's run
     __shared__ int base[kBins];          // first global item index of the slab's run
     __shared__ int run_len[kBins];       // items of this workgroup in the slab's run
     constexpr int kWin = DUAL ? kFillWin : kFillCap;      // (single field, 20-byte items: one pass -- two measured 52 -> 57 us)
-    __shared__ ItemT s_items[kWin];
-    __shared__ uint32_t s_gidx[kWin];
-    __shared__ float s_extra[DUAL ? kWin : 1];            // ninth word of an explicit dual item
+    // staging area: items | their global indices | (dual) the explicit items' ninth word -- one raw block, which the side jobs of
+    // this launch (side_jobs.h) use as their arena
+    constexpr int kItemBytes = kWin * (int)sizeof(ItemT);
+    constexpr int kStageBytes = kItemBytes + 4 * kWin + (DUAL ? 4 * kWin : 0);
+    constexpr int kRawBytes = kStageBytes > 4 * kTailArenaFloats ? kStageBytes : 4 * kTailArenaFloats;
+    static_assert(kItemBytes % 16 == 0, "the index array behind the items is aligned");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRawBytes];
+    ItemT* const s_items = reinterpret_cast<ItemT*>(s_raw);
+    uint32_t* const s_gidx = reinterpret_cast<uint32_t*>(s_raw + kItemBytes);
+    float* const s_extra = reinterpret_cast<float*>(s_raw + kItemBytes + 4 * kWin);           // ninth word of an explicit dual item
     __shared__ int s_total;
+    if ((int)blockIdx.y < sj.rows) {     // leading rows: the weight-gradient tail's jobs (no side stream in the backward)
+        const int job = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        if (job < sj.dec_blocks + sj.l1_jobs + sj.n_red + kFinalizeTasks) side_job_run(sj, job, reinterpret_cast<float*>(s_raw), &s_total);
+        return;
+    }
     ItemT* __restrict__ g_items = reinterpret_cast<ItemT*>(bm.items);
     // levels are walked last to first: the accumulate launch reads the lists first to last, i.e. most recently written first
-    const int tid = threadIdx.x, lane = tid & 63, l = level_base + (reverse ? (int)(gridDim.y - 1u - blockIdx.y) : (int)blockIdx.y);
-    if (blockIdx.x == 0 && blockIdx.y == 0) {        // armed for the accumulate launch behind this one: unit counter, slab tickets
+    const int y_lv = (int)blockIdx.y - sj.rows, n_lv = (int)gridDim.y - sj.rows;
+    const int tid = threadIdx.x, lane = tid & 63, l = level_base + (reverse ? n_lv - 1 - y_lv : y_lv);
+    if (blockIdx.x == 0 && y_lv == 0) {              // armed for the accumulate launch behind this one: unit counter, slab tickets
         if (tid == 0) *acc_claim(bm) = 0;
         for (int q = tid; q < LS2FM_MAX_LEVELS * kBins; q += kFillThreads) bm.part_ticket[q] = 0;
     }
@@ -799,7 +813,7 @@ bool ls2fm_bins_levels_fit(const ls2fm_grid_desc* grid, int dual) { return level
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo, int level_hi,
-                              int n_explicit) {
+                              int n_explicit, const void* side_jobs) {
     const int64_t r_pad = (n_rays + 63) / 64 * 64;
     const int sshift = ls2fm_slab_shift(dual);
     const BinMeta bm = make_bin_meta(bins_ws, n_points);
@@ -808,9 +822,16 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
     if (level_hi <= level_lo) return LS2FM_OK;
     // (most recently written lists are read first: slab_accumulate 101 -> 98 us at C2; LS2FM_FILL_REVERSE=0 for the A/B)
     static const int reverse = [] { const char* e = getenv("LS2FM_FILL_REVERSE"); return e ? atoi(e) : 1; }();
-    const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo));
-    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo, reverse, n_explicit);
-    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo, reverse, 0);
+    SideJobs sj{};
+    if (side_jobs) {
+        sj = *static_cast<const SideJobs*>(side_jobs);
+        const int n_jobs = sj.dec_blocks + sj.l1_jobs + sj.n_red + kFinalizeTasks;
+        sj.rows = (n_jobs + bm.n_tiles - 1) / bm.n_tiles;
+    }
+    static_assert(kFillThreads == kWmThreads, "the side jobs are written for 256-thread workgroups");
+    const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo + sj.rows));
+    if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo, reverse, n_explicit, sj);
+    else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo, reverse, 0, sj);
     return ls2fm_launch_status();
 }
 

@@ -29,7 +29,7 @@ int ls2fm_launch_post_shade(const ls2fm_loss_spec* loss, const float* ray_part, 
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1,
-                              int n_explicit = 0);
+                              int n_explicit = 0, const void* side_jobs = nullptr);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
                                  hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0, int n_explicit = 0,
                                  int n_samples = 1);

@@ -12,7 +12,7 @@
 //   finalize      un-collapse the radiance chain, weight-norm backward, d beta
 #include <cstdlib>
 
-#include "wgrad_tail.h"
+#include "side_jobs.h"
 
 namespace {
 
@@ -72,7 +72,7 @@ int ls2fm_launch_finalize_sdf(const ls2fm_params* params, const ls2fm_param_grad
 int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, const float* center, const float* ray, float* bins_ws,
                               int64_t n_points, int64_t p_pad, const float* rec1, const float* rec2, const float* rpt,
                               const float* ray_bound, int64_t n_rays, int dual, hipStream_t stream, int level_lo = 0, int level_hi = -1,
-                              int n_explicit = 0);
+                              int n_explicit = 0, const void* side_jobs = nullptr);
 int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, int64_t n_points, float* dtable1, float* dtable2,
                                  hipStream_t stream, int level_lo = 0, int level_hi = -1, int add_into = 0, int n_explicit = 0,
                                  int n_samples = 1);
@@ -111,7 +111,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) lsc.s[l] = l < L1 ? sdf_grid->scale[l] : 0.f;
 
     SideCtx sc;
-    bool forked = false;
+    bool forked = false, joined = false;
     LS2FM_CHECK_ARG(((reinterpret_cast<uintptr_t>(grads->sdf_table) | (dual ? reinterpret_cast<uintptr_t>(grads->rad_table) : 0)) & 15u) == 0);
 
     Upstream up{d_rgb, d_sdfs_volume, d_normals, d_depth_mlp, d_normal_mlp, LossUp{}};
@@ -124,7 +124,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // for A/B measurements)
     // (one-sample rays share the workspace layout of free points, which has no per-ray partials: wgrad_mlp.hip serves them)
     static const int fused_env = [] { const char* e = getenv("LS2FM_FUSED_WGRAD"); return e ? atoi(e) : 1; }();
-    const int fused_wgrad = fused_env && field->n_samples > 1;
+    // (rays of fewer than 64 samples -- BASELINE configs[0]: 256 rays x 32 -- leave half of a wave's lanes empty in the fused form:
+    // C1 0.171 fused against 0.154 ms with the separate launches)
+    const int fused_wgrad = fused_env && field->n_samples >= 64;
     ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,
                            dual ? grads->rad_table : nullptr, s, fused_wgrad);
     ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
@@ -172,12 +174,41 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     }
 
     // the one fork of the backward: weight-gradient GEMMs -> reduce -> finalize run on the side stream, beside the table scatters
-    forked = ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
+    static const int probe_no_side = [] { const char* e = getenv("LS2FM_PROBE_NO_SIDE"); return e ? atoi(e) : 0; }();     // timing probe: wrong MLP gradients
+    // Round 5: NO side stream in the render's backward when the MLPs' weight gradients were contracted by shade_bwd and no traced
+    // depth rides along: what is left of the chain (decoder columns, level-1 sums, reduction rows, finalize tasks) runs as leading
+    // workgroups of the scatter_fill launch (side_jobs.h) -- one chain on one queue.  LS2FM_SIDE_IN_FILL=0: the side stream of
+    // rounds 2-4 (A/B).
+    static const int side_in_fill_env = [] { const char* e = getenv("LS2FM_SIDE_IN_FILL"); return e ? atoi(e) : 1; }();
+    // (only where the fill is long enough to hide the jobs' ~45 us chain of hand-offs: >= 32 k sample points; and while the level-1
+    // sums -- 39 KB of per-ray partials per ray -- stay small beside the fill's own traffic: C5, 4096 rays x 256: 2.002 -> 1.984 ms;
+    // C3, 8192 rays x 128: 3.074 -> 3.100)
+    const bool side_in_fill = side_in_fill_env && fused_wgrad && !db && !probe_no_side && w.p >= 32768 && n_rays <= 4096;
+    SideJobs sj{};
+    if (side_in_fill) {
+        const WgPartLayout pl = make_wg_part_layout(dual, n_rays, field->n_samples);
+        float* l1_sdf = ws + w.mpart + pl.l1_sdf;
+        float* l1_geo = ws + w.mpart + pl.l1_geo;
+        sj.dec_blocks = kSideDecBlocks;
+        sj.l1_jobs = kL1Seg * (kRegsSdf + (dual ? kRegsGeo : 0));
+        sj.n_red = kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec;
+        sj.w = w; sj.dual = dual; sj.n_rays = n_rays; sj.ws = ws;
+        sj.part_dec = ws + w.mpart + pl.dec;
+        sj.l1 = L1Job{ws + w.mpart + pl.slot_sdf, ws + w.mpart + pl.slot_geo, l1_sdf, l1_geo, pl.n_slots, dual};
+        sj.parts = WgradParts{l1_sdf, l1_geo, sj.part_dec, kL1Seg, kL1Seg, sj.dec_blocks, dual};
+        sj.fa = FinalizeArgs{*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg, ws + w.dbeta, n_rays, 0};
+        static_assert(kSideDecBlocks + kL1Seg * (kRegsSdf + kRegsGeo) + kRegsSdf + kRegsGeo + kRegsDec <= kSideFlagInts, "one flag per side job");
+        sj.flags = reinterpret_cast<int*>(ws + w.wg + kWgFlagsAt);                  // (zeroed by shade_bwd's leading workgroups)
+        static const int side_probe = [] { const char* e = getenv("LS2FM_SIDE_PROBE"); return e ? atoi(e) : 0; }();
+        sj.probe = side_probe;
+    }
+    forked = !probe_no_side && !side_in_fill && ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
     // The side chain is enqueued IN FRONT of the scatter.  (Behind it -- LS2FM_SIDE_FIRST=0, tried in round 5 now that the chain is
     // short: the scatter then keeps shade_bwd's hardware queue in a hipGraph replay -- measured 0.526 against 0.509 ms per step.)
     static const int side_first = [] { const char* e = getenv("LS2FM_SIDE_FIRST"); return e ? atoi(e) : 1; }();
     auto launch_side = [&]() -> int {
+    if (probe_no_side || side_in_fill) return LS2FM_OK;
     Ls2fmWgradParts parts{};
     if (ls2fm_launch_wgrad_mlp(fc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, gs, false, &parts, db ? &extra : nullptr,
                                fused_wgrad) != LS2FM_OK)
@@ -212,9 +243,17 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
             const int lo = L1 * gi / groups, hi = L1 * (gi + 1) / groups;
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_RAD, s);
             int st = ls2fm_launch_scatter_fill(sdf_grid, fc, center, ray, ws + w.bins, w.p, P, ws + w.rec1, dual ? ws + w.rec2 : nullptr,
-                                               ws + w.rpt, ws + w.smax, n_rays, dual, s, lo, hi, n_explicit);
+                                               ws + w.rpt, ws + w.smax, n_rays, dual, s, lo, hi, n_explicit,
+                                               (side_in_fill && gi == 0) ? &sj : nullptr);
             ls2fm_prof_end(LS2FM_PROF_SCATTER_RAD, s);
             if (st != LS2FM_OK) return fail(forked, sc, st);
+            // LS2FM_JOIN_EARLY=1: the side chain is joined in FRONT of the (last) accumulate launch instead of at the end of the
+            // call: the call then ends on one queue
+            static const int join_early = [] { const char* e = getenv("LS2FM_JOIN_EARLY"); return e ? atoi(e) : 0; }();
+            if (join_early && side_first && forked && !joined && gi == groups - 1) {
+                if (hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return fail(forked, sc, LS2FM_ERR_LAUNCH);
+                joined = true;
+            }
             ls2fm_prof_begin(LS2FM_PROF_SCATTER_SDF, s);
             st = ls2fm_launch_slab_accumulate(sdf_grid, ws + w.bins, w.p, grads->sdf_table, dual ? grads->rad_table : nullptr, s, lo, hi,
                                               0, n_explicit, field->n_samples);
@@ -236,6 +275,6 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         if (forked2 && (hipEventRecord(sc2.join, sc2.side) != hipSuccess || hipStreamWaitEvent(s, sc2.join, 0) != hipSuccess))
             return ls2fm_join_on_error(forked, sc, s, LS2FM_ERR_LAUNCH);
     }
-    if (forked && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
+    if (forked && !joined && hipStreamWaitEvent(s, sc.join, 0) != hipSuccess) return LS2FM_ERR_LAUNCH;       // join
     return ls2fm_launch_status();
 }

@@ -273,6 +273,12 @@ struct WgLayout {
     static constexpr int total = dWv + 3 * 27;
 };
 
+// behind the reduced block (rounded up to 64 floats, its slack holds wgrad_tail's ticket): one flag word per job of the in-fill
+// side chain (side_jobs.h) -- zeroed with the block by shade_bwd's leading workgroups
+constexpr int kSideFlagInts = 4096;
+constexpr int kWgFlagsAt = (WgLayout::total + 63) / 64 * 64;
+constexpr int kWgBlockFloats = kWgFlagsAt + kSideFlagInts;
+
 static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int l2, int dual) {
     WsLayout w;
     w.p = n_rays * n_samples;
@@ -309,7 +315,7 @@ static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int
     w.dzr = take(3 * w.r_pad);
     w.renc = take(27 * w.r_pad);
     w.mpart = take(make_wg_part_layout(dual, n_rays, n_samples).total);
-    w.wg = take(WgLayout::total);
+    w.wg = take(kWgBlockFloats);     // reduced gradients + ticket words + the side jobs' flags (side_jobs.h): zeroed as one range
     w.dbeta = take(2 * w.r_pad);     // one double per ray: d L / d beta partials (summed in fixed order by finalize)
     // bin meta (counts first) directly after wg / dbeta: one memset zeroes all three (render_bwd.hip)
     w.bins = take(ls2fm_bins_workspace_floats(l1, w.p));   // per-slab item lists of the scatter (bin_scatter.hip)

@@ -13,7 +13,7 @@
 // layout, read back as one ds_read_b128 per lane (4 consecutive samples = the 4 k-slots of 4 MFMAs).
 // Persistent waves keep all 85 accumulator registers for the whole kernel; workgroups reduce through LDS and write one
 // partial each, summed by wgrad_mlp_reduce in a fixed order (deterministic).
-#include "wgrad_tail.h"
+#include "side_jobs.h"
 
 namespace {
 
@@ -238,133 +238,14 @@ wgrad_mlp_kernel(FieldC fc, int ch, WsLayout w, const Packed* __restrict__ pk, c
     for (int q = tid; q < R * 64; q += kWmThreads) dst[q] = red[q];
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Radiance-decoder columns: dWc (3 x 39) = sum over samples of dz [p, n, f, f2, 1]^T and dWv (3 x 27) = sum over rays of
-// (per-ray sums of dz) renc^T.  Every operand already lies in HBM as [row][sample]: the MFMA operands (row jl, 4
-// consecutive samples) are plain 16-byte loads, no LDS.
-
-// four consecutive samples s .. s + 3 of one row: the load is UNCONDITIONAL (the address clamped into the row's padded extent) and
-// the masking is a separate step applied where the values are USED, one iteration later -- a load under a branch, or one whose
-// lanes are patched right behind it, makes the compiler wait for it on the spot (this kernel was four exposed memory round
-// trips per tile: 21 us for 21 MB)
-__device__ __forceinline__ float4 load4_raw(const float* __restrict__ row, int64_t s, int64_t s_last) {
-    return *reinterpret_cast<const float4*>(row + (s < s_last ? s : s_last));
-}
-__device__ __forceinline__ float4 mask4(const float4 v, int64_t s, int64_t n, bool on) {
-    return make_float4((on && s < n) ? v.x : 0.f, (on && s + 1 < n) ? v.y : 0.f, (on && s + 2 < n) ? v.z : 0.f, (on && s + 3 < n) ? v.w : 0.f);
-}
-
-// Level 1 of the fixed-order sum of shade_bwd's per-ray weight-gradient partials (shade_bwd.hip, 3.): job (row k, segment sg)
-// adds row k of the rays [sg * per, (sg + 1) * per) -- wave v takes the rays v, v + 4, ... of the segment, eight loads in
-// flight, then the four waves' sums are added in order -- and leaves row k of segment sum sg.  The order of the additions is a
-// function of (n_rays, kL1Seg) alone: deterministic.
-struct L1Job { const float* slot_sdf; const float* slot_geo; float* l1_sdf; float* l1_geo; int n_slots, dual; };
-
-__device__ void wgrad_l1_job(const L1Job& jb, int job) {
-    __shared__ float s_l1[kWmWaves][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rows = kRegsSdf + (jb.dual ? kRegsGeo : 0);
-    int k = job % rows;
-    const int sg = job / rows;
-    const bool geo = k >= kRegsSdf;
-    if (geo) k -= kRegsSdf;
-    const int R = geo ? kRegsGeo : kRegsSdf;
-    const float* __restrict__ src = (geo ? jb.slot_geo : jb.slot_sdf) + (int64_t)k * 64 + lane;
-    const int per = (jb.n_slots + kL1Seg - 1) / kL1Seg;
-    const int lo = sg * per, hi = min(lo + per, jb.n_slots);
-    float acc = 0.f;
-    int b = lo + wave;
-    for (; b + 7 * kWmWaves < hi; b += 8 * kWmWaves) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + u * kWmWaves) * (R * 64)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; b < hi; b += kWmWaves) acc += src[(int64_t)b * (R * 64)];
-    s_l1[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0)
-        (geo ? jb.l1_geo : jb.l1_sdf)[((int64_t)sg * R + k) * 64 + lane] = (s_l1[0][lane] + s_l1[1][lane]) + (s_l1[2][lane] + s_l1[3][lane]);
-}
-
 __global__ void __launch_bounds__(kWmThreads)
 wgrad_dec_kernel(WsLayout w, int dual, int64_t n_rays, const float* __restrict__ ws, float* __restrict__ part, int dec_blocks, L1Job l1) {
+    __shared__ __attribute__((aligned(16))) float s_arena[kRegsDec * 64];
     if ((int)blockIdx.x >= dec_blocks) {          // trailing workgroups: level-1 sums of shade_bwd's partials
-        wgrad_l1_job(l1, (int)blockIdx.x - dec_blocks);
+        wgrad_l1_job_a<false>(l1, (int)blockIdx.x - dec_blocks, s_arena);
         return;
     }
-    __shared__ float red[kRegsDec * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int jl = lane & 15, g = lane >> 4;
-    const int64_t P = w.p_pad;
-    f32x4 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int n_tiles_p = (int)((w.p + 15) / 16), n_tiles_r = (int)((n_rays + 15) / 16);
-    // software-pipelined: the NEXT tile's four operand loads are in flight during this tile's twelve MFMAs (a wave has ~8
-    // tiles: with the loads issued and awaited tile by tile the kernel was eight exposed memory round trips, 21 us for 21 MB)
-    const int step = dec_blocks * kWmWaves;
-    const int64_t s_last = P - 4;                  // rows are p_pad long (a multiple of 64)
-    const float* __restrict__ row_a = ws + w.dz + (jl < 3 ? jl : 0) * P;
-    const float* __restrict__ row_b0 = ws + w.fe + jl * P;
-    const float* __restrict__ row_b1 = ws + (dual ? w.fe2 : w.fe) + jl * P;
-    const float* __restrict__ row_b2 = jl < 3 ? ws + w.p3 + jl * P : ws + w.nrm + (jl < 6 ? jl - 3 : 0) * P;
-    {
-        // kDecBatch tiles per trip, all their loads issued before the first MFMA (a wave has ~8 tiles at the benchmark: two memory
-        // round trips instead of thirty-two).  (A rotating "next tile" prefetch does not survive the compiler here: it merges the
-        // loop-carried loads back into the iteration that uses them, or waits for vmcnt(0) at the loop head.)
-        constexpr int kDecBatch = 4;
-#pragma unroll 1
-        for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_p; tile += kDecBatch * step) {
-            float4 ra[kDecBatch], rb0[kDecBatch], rb1[kDecBatch], rb2[kDecBatch];
-#pragma unroll
-            for (int u = 0; u < kDecBatch; ++u) {
-                const int64_t s = (int64_t)(tile + u * step) * 16 + 4 * g;
-                ra[u] = load4_raw(row_a, s, s_last); rb0[u] = load4_raw(row_b0, s, s_last);
-                rb1[u] = load4_raw(row_b1, s, s_last); rb2[u] = load4_raw(row_b2, s, s_last);
-            }
-            __builtin_amdgcn_sched_barrier(0);       // (the machine scheduler otherwise sinks each tile's loads to its MFMAs)
-#pragma unroll
-            for (int u = 0; u < kDecBatch; ++u) {
-                const int64_t s = (int64_t)(tile + u * step) * 16 + 4 * g;
-                const bool on = tile + u * step < n_tiles_p;
-                const float4 a = mask4(ra[u], s, w.p, on && jl < 3), b0 = mask4(rb0[u], s, w.p, on), b1 = mask4(rb1[u], s, w.p, on && dual != 0);
-                float4 b2 = mask4(rb2[u], s, w.p, on && jl < 6);
-                if (on && jl == 6) b2 = make_float4(1.f, 1.f, 1.f, 1.f);       // bias column (a is zero beyond the last sample)
-                acc[0] = mfma4(a.x, b0.x, acc[0]); acc[1] = mfma4(a.x, b1.x, acc[1]); acc[2] = mfma4(a.x, b2.x, acc[2]);
-                acc[0] = mfma4(a.y, b0.y, acc[0]); acc[1] = mfma4(a.y, b1.y, acc[1]); acc[2] = mfma4(a.y, b2.y, acc[2]);
-                acc[0] = mfma4(a.z, b0.z, acc[0]); acc[1] = mfma4(a.z, b1.z, acc[1]); acc[2] = mfma4(a.z, b2.z, acc[2]);
-                acc[0] = mfma4(a.w, b0.w, acc[0]); acc[1] = mfma4(a.w, b1.w, acc[1]); acc[2] = mfma4(a.w, b2.w, acc[2]);
-            }
-        }
-    }
-    {
-        const int64_t r_last = w.r_pad - 4;
-#pragma unroll 1
-        for (int tile = blockIdx.x * kWmWaves + wave; tile < n_tiles_r; tile += dec_blocks * kWmWaves) {
-            const int64_t s = (int64_t)tile * 16 + 4 * g;
-            const float4 ra = load4_raw(ws + w.dzr + (jl < 3 ? jl : 0) * w.r_pad, s, r_last), rb0 = load4_raw(ws + w.renc + jl * w.r_pad, s, r_last),
-                         rb1 = load4_raw(ws + w.renc + (16 + jl < kView ? 16 + jl : 0) * w.r_pad, s, r_last);
-            const float4 a = mask4(ra, s, n_rays, jl < 3), b0 = mask4(rb0, s, n_rays, true), b1 = mask4(rb1, s, n_rays, 16 + jl < kView);
-            acc[3] = mfma4(a.x, b0.x, acc[3]); acc[4] = mfma4(a.x, b1.x, acc[4]); acc[3] = mfma4(a.y, b0.y, acc[3]); acc[4] = mfma4(a.y, b1.y, acc[4]);
-            acc[3] = mfma4(a.z, b0.z, acc[3]); acc[4] = mfma4(a.z, b1.z, acc[4]); acc[3] = mfma4(a.w, b0.w, acc[3]); acc[4] = mfma4(a.w, b1.w, acc[4]);
-        }
-    }
-    for (int wv = 0; wv < kWmWaves; ++wv) {
-        if (wave == wv) {
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (wv == 0) red[(t * 4 + q) * 64 + lane] = acc[t][q];
-                    else red[(t * 4 + q) * 64 + lane] += acc[t][q];
-                }
-        }
-        __syncthreads();
-    }
-    float* dst = part + (int64_t)blockIdx.x * (kRegsDec * 64);
-    for (int q = tid; q < kRegsDec * 64; q += kWmThreads) dst[q] = red[q];
+    wgrad_dec_block_a<false>(w, dual, n_rays, ws, part, dec_blocks, (int)blockIdx.x, s_arena);
 }
 
 __global__ void __launch_bounds__(kWmThreads)

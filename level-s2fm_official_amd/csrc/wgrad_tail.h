@@ -16,6 +16,13 @@ constexpr int kFinalizeTasks = 7;
 // the hand-off of the scan jobs (bin_items.h).  An agent-scope release / acquire pair instead writes back and invalidates a
 // whole L2 per workgroup: measured 35.6 us for the launch and +12 us on the step (it runs beside slab_accumulate).
 __device__ __forceinline__ void wg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes write-through (a dword write-through store is one fabric write per LANE, ~6x the time per byte: fine for the 7 k
+// floats of the reduced block, not for the 330 k floats of the in-launch partials of side_jobs.h)
+__device__ __forceinline__ void wg_store4(float* p, const float4 v) {
+    typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+    const wg_f32x4 r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(r) : "memory");
+}
 __device__ __forceinline__ float wg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // several of them IN FLIGHT together: the compiler keeps atomic loads in program order and waits for each on the spot (a
 // finalize task's nine loads per thread were nine exposed round trips to memory, ~13 us of the tail kernel's 35): the same
@@ -26,17 +33,29 @@ __device__ __forceinline__ void wg_load3(const float* p0, const float* p1, const
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
+__device__ __forceinline__ void wg_load4(const float* p0, const float* p1, const float* p2, const float* p3, float& v0, float& v1, float& v2, float& v3) {
+    asm volatile("global_load_dword %0, %4, off sc1\n\tglobal_load_dword %1, %5, off sc1\n\tglobal_load_dword %2, %6, off sc1\n\t"
+                 "global_load_dword %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+
+// LDS of the tail's jobs, carved from an arena the calling kernel lends (floats): the standalone kernels declare one of their own
+// (wrappers below); scatter_fill lends its staging area to the jobs that ride in its launch (side_jobs.h)
+constexpr int kTailArenaFloats = 3 * 68 + 4 + 3 * 64 + 64 * 68 + 2 * 256;      // finalize_task: s_dwc, s_dbc, s_dt1, s_row, s_db (double[256])
+
 // sum of the per-workgroup partials (fixed order -> deterministic), scattered into the reduced-gradient buffer
 // (WgLayout).  One launch for all three producers: block ranges [0,85) SDF MLP, [85,153) second MLP, then 20 decoder.
 typedef Ls2fmWgradParts WgradParts;
 
-// one workgroup (256 threads) per output row `k` (block ranges above)
-__device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg, int k) {
+// one workgroup (256 threads) per output row `k` (block ranges above).  WT: the partials were written IN THIS LAUNCH by other
+// workgroups (write-through stores, drained, then a ticket the caller has waited for): read with L2-bypassing loads, four in flight
+template <bool WT>
+__device__ __forceinline__ void reduce_partials_row_a(const WgradParts& wp, float* __restrict__ wg, int k, float* __restrict__ arena) {
     const float* __restrict__ part_sdf = wp.sdf;
     const float* __restrict__ part_geo = wp.geo;
     const float* __restrict__ part_dec = wp.dec;
     const int nb_dec = wp.nb_dec, dual = wp.dual;
-    __shared__ float s_sum[kWmWaves][64];
+    float (*s_sum)[64] = reinterpret_cast<float (*)[64]>(arena);          // [kWmWaves][64]
     int kind = 0;
     if (k >= kRegsSdf) { k -= kRegsSdf; kind = 1; if (!dual || k >= kRegsGeo) { k -= dual ? kRegsGeo : 0; kind = 2; } }
     const float* part = kind == 0 ? part_sdf : (kind == 1 ? part_geo : part_dec);
@@ -45,11 +64,24 @@ __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, jl = lane & 15, g = lane >> 4;
     float s0 = 0.f, s1 = 0.f;
     int b = grp;
-    for (; b + kWmWaves < nb; b += 2 * kWmWaves) {
-        s0 += part[((int64_t)b * R + k) * 64 + lane];
-        s1 += part[((int64_t)(b + kWmWaves) * R + k) * 64 + lane];
+    if constexpr (WT) {
+        // (same operand order as the plain form: s0 takes b, b + 2 W, ..., s1 takes b + W, b + 3 W, ...)
+        for (; b < nb; b += 4 * kWmWaves) {
+            const int b1 = b + kWmWaves, b2 = b + 2 * kWmWaves, b3 = b + 3 * kWmWaves;
+            const float* q = part + (int64_t)k * 64 + lane;
+            float v0, v1, v2, v3;
+            wg_load4(q + (int64_t)b * R * 64, q + (int64_t)(b1 < nb ? b1 : b) * R * 64, q + (int64_t)(b2 < nb ? b2 : b) * R * 64,
+                     q + (int64_t)(b3 < nb ? b3 : b) * R * 64, v0, v1, v2, v3);
+            if (b1 < nb) { s0 += v0; s1 += v1; } else { s0 += v0; }
+            if (b3 < nb) { s0 += v2; s1 += v3; } else if (b2 < nb) { s0 += v2; }
+        }
+    } else {
+        for (; b + kWmWaves < nb; b += 2 * kWmWaves) {
+            s0 += part[((int64_t)b * R + k) * 64 + lane];
+            s1 += part[((int64_t)(b + kWmWaves) * R + k) * 64 + lane];
+        }
+        if (b < nb) s0 += part[((int64_t)b * R + k) * 64 + lane];
     }
-    if (b < nb) s0 += part[((int64_t)b * R + k) * 64 + lane];
     s_sum[grp][lane] = s0 + s1;
     __syncthreads();
     if (grp != 0) return;
@@ -84,6 +116,10 @@ __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg
         const int o = GEO ? 1 + 4 * t + g : 4 * t + g;
         if (jl == 0 && o < kOut) wg_store(&dW1[o * 65 + 64], v);
     }
+}
+[[maybe_unused]] __device__ void reduce_partials_row(const WgradParts& wp, float* __restrict__ wg, int k) {
+    __shared__ float s_arena[kWmWaves * 64];
+    reduce_partials_row_a<false>(wp, wg, k, s_arena);
 }
 
 
@@ -125,7 +161,7 @@ struct FinalizeArgs {
 };
 
 // one workgroup (256 threads) per task
-[[maybe_unused]] __device__ void finalize_task(const FinalizeArgs& fa, const int task) {
+__device__ __forceinline__ void finalize_task_a(const FinalizeArgs& fa, const int task, float* __restrict__ arena) {
     const ls2fm_params& P = fa.P;
     const ls2fm_param_grads& G = fa.G;
     const int in_dim = fa.in_dim, in_dim2 = fa.in_dim2, rad_in = fa.rad_in, dual = fa.dual;
@@ -133,10 +169,12 @@ struct FinalizeArgs {
     const float* __restrict__ wg = fa.wg;
     const float* __restrict__ dbeta = fa.dbeta;
     const int64_t n_rays = fa.n_rays;
-    __shared__ float s_dwc[3][68];
-    __shared__ float s_dbc[4];
-    __shared__ float s_dt1[3][64];
-    __shared__ float s_row[64][68];       // effective-weight gradients of the layer being processed
+    float (*s_dwc)[68] = reinterpret_cast<float (*)[68]>(arena);                          // [3][68]
+    float* s_dbc = arena + 3 * 68;                                                        // [4]
+    float (*s_dt1)[64] = reinterpret_cast<float (*)[64]>(arena + 3 * 68 + 4);             // [3][64]
+    float (*s_row)[68] = reinterpret_cast<float (*)[68]>(arena + 3 * 68 + 4 + 3 * 64);    // [64][68]: effective-weight gradients of the layer being processed
+    double* s_db = reinterpret_cast<double*>(arena + 3 * 68 + 4 + 3 * 64 + 64 * 68);      // [256]  (offset 4752 floats: 8-byte aligned)
+    static_assert((3 * 68 + 4 + 3 * 64 + 64 * 68) % 2 == 0, "s_db is 8-byte aligned inside a 16-byte aligned arena");
     const int tid = threadIdx.x;
 
     // one workgroup per layer (7 independent tasks; a single workgroup doing all of them was a 58 us latency chain):
@@ -221,7 +259,6 @@ struct FinalizeArgs {
         // beta = exp(beta_param * speed):  d/d beta_param = dL/dbeta * beta * speed ; dL/dbeta = fixed-order sum of the
         // per-ray partials of shade_bwd (fp64)
         {
-            __shared__ double s_db[256];
             double acc = 0.0;
             for (int64_t r = tid; r < n_rays; r += 256) acc += reinterpret_cast<const double*>(dbeta)[r];
             s_db[tid] = acc;
@@ -262,6 +299,10 @@ struct FinalizeArgs {
     weight_norm_bwd_rows(P.rad_mlp[2].weight_v, P.rad_mlp[2].weight_g, &s_row[0][0], 68, 3, 64,
                          G.rad_mlp[2].weight_v, G.rad_mlp[2].weight_g, tid);
     if (tid < 3) G.rad_mlp[2].bias[tid] = s_dbc[tid];
+}
+[[maybe_unused]] __device__ void finalize_task(const FinalizeArgs& fa, const int task) {
+    __shared__ __attribute__((aligned(16))) float s_arena[kTailArenaFloats];
+    finalize_task_a(fa, task, s_arena);
 }
 
 
