@@ -365,12 +365,29 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
         t_eager = probe(False)
-        captured = CapturedStep(whole_step, params, stream=s_main)
-        t_graph = probe(True)
-        use_graph = not (t_eager < 0.98 * t_graph)      # a tie goes to the replay: its step time does not depend on the host
-        launch_probe = {"eager_ms_per_step": t_eager * 1e3, "graph_ms_per_step": t_graph * 1e3}
+        # N > 1: the capture records RCCL's collectives into the graph -- exercised on a one-rank RCCL group only so far; if it
+        # fails on a real multi-GPU node the line falls back to eager launches (every rank takes the same decision) and says so
+        capture_error = None
+        try:
+            captured = CapturedStep(whole_step, params, stream=s_main)
+        except Exception as e:                                   # noqa: BLE001
+            if not multi:
+                raise
+            capture_error = f"{type(e).__name__}: {e}"[:300]
+        if multi:
+            ok = torch.tensor([0.0 if capture_error else 1.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1.0:
+                captured = None
+                capture_error = capture_error or "capture failed on another rank"
+        t_graph = probe(True) if captured is not None else float("inf")
+        use_graph = captured is not None and not (t_eager < 0.98 * t_graph)      # a tie goes to the replay: its step time does not depend on the host
+        launch_probe = {"eager_ms_per_step": t_eager * 1e3, "graph_ms_per_step": None if captured is None else t_graph * 1e3}
+        if capture_error:
+            launch_probe["capture_error"] = capture_error
         if rank == 0:
-            print(f"[bench] launch probe: eager {t_eager * 1e3:.3f} ms/step, hipGraph {t_graph * 1e3:.3f} ms/step", file=sys.stderr)
+            print(f"[bench] launch probe: eager {t_eager * 1e3:.3f} ms/step, hipGraph {t_graph * 1e3:.3f} ms/step"
+                  + (f" (capture failed: {capture_error})" if capture_error else ""), file=sys.stderr)
         if world > 1:                       # every rank must take the same path
             flag = torch.tensor([1.0 if use_graph else 0.0], device=dev)
             dist.all_reduce(flag)
