@@ -59,6 +59,26 @@ wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_
     }
 }
 
+// The upstream of the traced depth (loss head inside the render: the depth-consistency term) per ray -- exactly the lines of
+// shade_bwd's first part that form `d_depth_ref`, as a kernel of its own, so that the tracing's own backward (ls2fm_depth_backward: a
+// chain of five small launches over the track points) can start BESIDE shade_bwd instead of behind it.
+__global__ void __launch_bounds__(256)
+depth_upstream_kernel(LossUp lo, const float* __restrict__ rout_depth, int64_t n_rays) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    float gt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lo.d_terms) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) gt[k] = lo.d_terms[k];
+    }
+    const float g_all = gt[4] + (lo.d_total ? lo.d_total[0] : 0.f);
+    const float gl_dc = lo.sums[5] > 0.0 ? fmaf(lo.weights[2], g_all, gt[2]) / (float)lo.sums[5] : 0.f;
+    float gd = 0.f;
+    if (lo.depth_ref != nullptr && (lo.mask_dc == nullptr || lo.mask_dc[r] != 0))
+        gd = gl_dc * ls2fm_smooth_l1_grad(lo.depth_ref[r] - rout_depth[r]);
+    lo.d_depth_ref[r] = gd;
+}
+
 }  // namespace
 
 // weight-norm backward of the SDF MLP alone (point queries, points.hip): tasks 0 and 1 of finalize_kernel
@@ -118,31 +138,29 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (loss)
         up.loss = LossUp{loss->rgb_gt, loss->depth_ref, loss->mask_eik, loss->mask_dc, loss->mask_mse, loss->weights, loss->sums,
                          loss->d_terms, loss->d_total, loss->d_depth_ref, loss->flags};
-    ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
-    // (leading workgroups of this launch zero the weight-gradient accumulators and the atomically flushed table ranges)
-    // the MLPs' weight gradients are contracted inside shade_bwd (LS2FM_FUSED_WGRAD=0: round 4's separate wgrad_mlp launches,
-    // for A/B measurements)
-    // (one-sample rays share the workspace layout of free points, which has no per-ray partials: wgrad_mlp.hip serves them)
     static const int fused_env = [] { const char* e = getenv("LS2FM_FUSED_WGRAD"); return e ? atoi(e) : 1; }();
     // (rays of fewer than 64 samples -- BASELINE configs[0]: 256 rays x 32 -- leave half of a wave's lanes empty in the fused form:
     // C1 0.171 fused against 0.154 ms with the separate launches)
     const int fused_wgrad = fused_env && field->n_samples >= 64;
-    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,
-                           dual ? grads->rad_table : nullptr, s, fused_wgrad);
-    ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
-    if (opts && opts->depth_grad_ready && hipEventRecord((hipEvent_t)opts->depth_grad_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
-    // the tracing's own backward (ls2fm_depth_backward): a second internal branch, forked here -- d_depth_ref is final.  Its
-    // stages are those of ls2fm_sdf_points_bwd over the track points, MERGED into this call's own chains: the per-point rows it
-    // leaves (front: gather pass, points_bwd, scans) are contracted by this call's SDF weight-gradient kernel as extra tiles
-    // (no second wgrad_mlp / reduction / weight-norm backward -- whose 63 KB workgroups waited for a CU beside this call's), and
-    // its table gradient is ADDED into this call's table behind the main accumulate (no second table, no final sum kernel).
+    // the tracing's own backward (ls2fm_depth_backward): a second internal branch.  Its stages are those of ls2fm_sdf_points_bwd
+    // over the track points, MERGED into this call's own chains: the per-point rows it leaves (front: gather pass, points_bwd,
+    // scans) are contracted by this call's SDF weight-gradient kernel as extra tiles (no second wgrad_mlp / reduction / weight-norm
+    // backward -- whose 63 KB workgroups waited for a CU beside this call's), and its table gradient is ADDED into this call's table
+    // behind the main accumulate (no second table, no final sum kernel).
+    // Round 5, measured and NOT taken (LS2FM_DEPTH_EARLY=1 enables it; results identical): the branch forked IN FRONT of shade_bwd --
+    // the depth's upstream from depth_upstream_kernel (the same arithmetic as shade_bwd's first part, which then leaves d_depth_ref
+    // alone) -- so that its five small launches run beside shade_bwd instead of beside the scatter, where they are stretched 3-5x and
+    // end the stage's backward 90 us behind the main accumulate.  shade_bwd is ONE round of workgroups that fills every slot of the
+    // chip: whatever runs beside it starts a second round -- stage step 0.808 - 0.820 -> 0.856 - 0.864 ms, loops +0.06 - 0.1 ms.
     const ls2fm_depth_backward* db = (opts && loss && loss->d_depth_ref) ? opts->depth_bwd : nullptr;
+    static const int depth_early_env = [] { const char* e = getenv("LS2FM_DEPTH_EARLY"); return e ? atoi(e) : 0; }();
+    const bool depth_early = db != nullptr && depth_early_env != 0;
     SideCtx sc1, sc2;
     bool forked2 = false;
     Ls2fmWgradExtra extra{};
     int64_t n_track = 0;
     hipStream_t ds = s;
-    if (db) {
+    auto launch_depth_branch = [&]() -> int {
         LS2FM_CHECK_ARG(db->points && db->trips && db->gate && db->d_sdf && db->workspace && db->k_max >= 1);
         if (opts->n_level_groups > 1) return LS2FM_ERR_UNSUPPORTED;      // a group's slices would not be final at its event
         n_track = n_rays * (int64_t)db->k_max;
@@ -162,6 +180,26 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
             if (forked2) { (void)hipEventRecord(sc2.join, sc2.side); (void)hipStreamWaitEvent(s, sc2.join, 0); }
             return st;
         }
+        return LS2FM_OK;
+    };
+    if (depth_early) {
+        depth_upstream_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, s>>>(up.loss, ws + w.rout + 3 * w.r_pad, n_rays);
+        if (opts->depth_grad_ready && hipEventRecord((hipEvent_t)opts->depth_grad_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+        const int st = launch_depth_branch();
+        if (st != LS2FM_OK) return st;
+        up.loss.d_depth_ref = nullptr;                   // (shade_bwd leaves it alone: the branch is reading it)
+    }
+    ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
+    // (leading workgroups of this launch zero the weight-gradient accumulators and the atomically flushed table ranges)
+    // the MLPs' weight gradients are contracted inside shade_bwd (LS2FM_FUSED_WGRAD=0: round 4's separate wgrad_mlp launches,
+    // for A/B measurements)
+    // (one-sample rays share the workspace layout of free points, which has no per-ray partials: wgrad_mlp.hip serves them)
+    ls2fm_launch_shade_bwd(fc, lsc, dual, 2 * L1, 2 * L2, w, pk, center, ray, n_rays, ws, up, want_pose, sdf_grid, grads->sdf_table,
+                           dual ? grads->rad_table : nullptr, s, fused_wgrad);
+    ls2fm_prof_end(LS2FM_PROF_SHADE_BWD, s);
+    if (!depth_early) {
+        if (opts && opts->depth_grad_ready && hipEventRecord((hipEvent_t)opts->depth_grad_ready, s) != hipSuccess) return LS2FM_ERR_LAUNCH;
+        if (db) { const int st = launch_depth_branch(); if (st != LS2FM_OK) return st; }
     }
     auto fail = [&](bool f1, const SideCtx& c1, int st) {       // error after the forks: every branch is joined back into `s`
         if (forked2) { (void)hipEventRecord(sc2.join, sc2.side); (void)hipStreamWaitEvent(s, sc2.join, 0); }
