@@ -397,3 +397,48 @@ def test_fused_adam_keeps_the_interleaved_copy_current_without_rebuilds():
         before = calls["n"]
         ren.forward(opt, center, ray, sdf, rad)
         assert calls["n"] == before + 1 and torch.equal(t1._ls2fm_mirror[0].table, interleaved())
+
+
+def test_weight_gradient_tail_inside_the_fill_launch_matches_the_side_stream_form(tmp_path):
+    """Round 5: with the MLPs' weight gradients contracted inside shade_bwd, the rest of the chain (decoder columns, level-1 sums,
+    reduction rows, finalize tasks) runs as leading workgroups of the scatter_fill launch (csrc/side_jobs.h; hand-offs by flags inside
+    one launch) when the batch is large enough -- against the side stream of rounds 2-4 (LS2FM_SIDE_IN_FILL=0) and against the
+    separate wgrad_mlp launches (LS2FM_FUSED_WGRAD=0): every MLP / decoder / beta gradient of the benchmark's step within 1e-5 of each
+    other (the forms differ in summation order only).  The switches are read once per process: three child processes."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, numpy as np, torch
+root = sys.argv[1]
+for p in (root, os.path.join(root, "level-s2fm_official_amd")):
+    sys.path.insert(0, p)
+import bench
+from ls2fm.options import make_options
+from ls2fm.models.SDF import SDF
+from ls2fm.models.RadF import RadF
+from ls2fm.models.Renderer import Renderer
+opt = make_options("ETH3D", device="cuda", dual_field=True, sample_intvs=128)
+torch.manual_seed(0)
+sdf, rad, ren = SDF(opt).cuda(), RadF(opt).cuda(), Renderer(opt)
+bench.randomize([sdf, rad], seed=0)
+c, r = bench.synthetic_rays(512, float(opt.data.bound_max[0]), "cuda", seed=0)
+bench.loss_head(ren.forward(opt, c, r, sdf, rad)).backward()
+out = {}
+for pre, mod in (("s.", sdf), ("r.", rad)):
+    for k, p in mod.named_parameters():
+        if not k.endswith("embedder_obj.params"):
+            out[pre + k] = p.grad.detach().cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    got = {}
+    for tag, env in (("fill", {}), ("side", {"LS2FM_SIDE_IN_FILL": "0"}), ("separate", {"LS2FM_FUSED_WGRAD": "0"})):
+        path = str(tmp_path / f"{tag}.npz")
+        res = subprocess.run([sys.executable, "-c", code, root, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        got[tag] = dict(np.load(path))
+    assert len(got["fill"]) >= 20
+    for k, ref in got["separate"].items():
+        scale = float(np.abs(ref).max()) + 1e-30
+        for tag in ("fill", "side"):
+            err = float(np.abs(got[tag][k] - ref).max()) / scale
+            assert np.isfinite(got[tag][k]).all() and err < 1e-5, (tag, k, err)
