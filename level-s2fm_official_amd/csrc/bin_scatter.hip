@@ -828,7 +828,7 @@ int ls2fm_launch_scatter_fill(const ls2fm_grid_desc* grid, const FieldC& fc, con
         const int n_jobs = sj.dec_blocks + sj.l1_jobs + sj.n_red + kFinalizeTasks;
         sj.rows = (n_jobs + bm.n_tiles - 1) / bm.n_tiles;
     }
-    static_assert(kFillThreads == kWmThreads, "the side jobs are written for 256-thread workgroups");
+    if (kFillThreads != kWmThreads && sj.rows > 0) return LS2FM_ERR_UNSUPPORTED;      // the side jobs are written for 256-thread workgroups
     const dim3 g((unsigned)bm.n_tiles, (unsigned)(level_hi - level_lo + sj.rows));
     if (dual) scatter_fill_kernel<true><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, rec2, ray_bound, n_rays, r_pad, bm, level_lo, reverse, n_explicit, sj);
     else      scatter_fill_kernel<false><<<g, kFillThreads, 0, stream>>>(lv, fc, center, ray, n_points, p_pad, sshift, rpt, rec1, nullptr, ray_bound, n_rays, r_pad, bm, level_lo, reverse, 0, sj);
