@@ -562,6 +562,9 @@ __device__ __forceinline__ AccUnit acc_unit_finish(const AccUnitRaw& r, const Bi
 #ifndef LS2FM_ACC_PROBE
 #define LS2FM_ACC_PROBE 0
 #endif
+#ifndef LS2FM_ACC_HOLD
+#define LS2FM_ACC_HOLD 1          // 0: second units G + b for every workgroup, claims to the pool's end (A/B)
+#endif
 #ifdef LS2FM_STAMPS
 #define PACC_STAMP(uid, k) do { if (threadIdx.x == 0 && (uid) < 4096) g_acc_stamps[8 * (uid) + (k)] = wall_clock64(); } while (0)
 #else
@@ -571,7 +574,7 @@ __device__ __forceinline__ AccUnit acc_unit_finish(const AccUnitRaw& r, const Bi
 template <bool DUAL, bool ADD_INTO>
 __global__ void __launch_bounds__(kAccThreads)
 slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int sshift, float* __restrict__ dtable1,
-                                  float* __restrict__ dtable2, int block_base, int n_units, int combine, int* __restrict__ claim) {
+                                  float* __restrict__ dtable2, int block_base, int n_units, int combine, int* __restrict__ claim, int hold) {
     typedef typename ItemOf<DUAL>::type ItemT;
     constexpr int F = DUAL ? 4 : 2;
     constexpr int BT = kAccBatch * kAccThreads;
@@ -581,9 +584,24 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
     const int G = (int)gridDim.x;
     const int E = 1 << sshift;
     const int n_exp = DUAL ? plan.n_explicit : 0;
-    // units 0 .. 2G-1 are handed out statically (b, G + b), the rest through the counter (zeroed by scatter_fill's first workgroup)
-    AccUnit cur = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, (int)blockIdx.x, n_units), bm, n_exp);
-    AccUnit nxt = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, G + (int)blockIdx.x, n_units), bm, n_exp);
+    // Every workgroup starts with two units in hand (the second one's first batch is requested behind the first one's last) and
+    // claims a third from a counter (zeroed by scatter_fill's first workgroup) while it works on the first, and so on: up to
+    // three units per workgroup when the pool runs dry -- the kernel ended 12 us after its AVERAGE workgroup (per-unit stamps:
+    // end times 48.8 / 54.8 / 67.3 us min / mean / max; list scheduling of the same unit times: 57.8), and its last workgroup
+    // was always a part of the level-0 slab (50 us with the combine) + the two hashed units it had been sitting on.  So:
+    //   * unit ids run level by level, coarse first; the first `hold` are LONG (parts of point-split slabs).  Their workgroups
+    //     get the LAST ids as their second unit -- work that is due at the end anyway -- and never claim;
+    //   * the others take G + b - hold, then claim -- until the unit they hold as `next` is one of the pool's last G - hold
+    //     (the zone): every claiming workgroup takes at most one unit of the zone, as its last.  (Every id is still taken: if
+    //     one of the zone were not, the counter would have stopped below the pool's end, so every claiming workgroup would have
+    //     stopped claiming, so each would hold a zone id -- G - hold distinct ones: all of them.)
+    const int b = (int)blockIdx.x;
+    const int n_hold = hold > 0 ? hold : 0;
+    const int second = b < n_hold ? n_units - 1 - b : G + b - n_hold;
+    const int dyn_base = 2 * G - n_hold, dyn_end = n_units - n_hold;
+    const int zone_lo = hold >= 0 && n_units >= 3 * G ? dyn_end - (G - n_hold) : 0x7fffffff;
+    AccUnit cur = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, b, n_units), bm, n_exp);
+    AccUnit nxt = acc_unit_finish<ItemT>(acc_unit_fetch<DUAL, false>(plan, bm, block_base, second, n_units), bm, n_exp);
     ItemT buf[kAccBatch];
     float bufx[DUAL ? kAccBatch : 1];         // ninth word of explicit dual items
     {
@@ -602,8 +620,10 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
     }
     lds_barrier();
     while (cur.l >= 0) {
-        // the unit after the next: claimed now, read behind this unit's streaming phase
-        int claimed = 0;
+        // the unit after the next: claimed in this unit's first batch, read behind its streaming phase -- unless the NEXT unit is
+        // already one of the zone (a tail id, or one of the pool's last G - hold): no claim behind it
+        int claimed = n_units;               // (not claimed: an id beyond the last unit)
+        const bool claim_more = nxt.l >= 0 && nxt.uid - block_base < zone_lo;
         const int l = cur.l;
         PACC_STAMP(cur.uid, 0);
         float to_fixed1, to_fixed2;
@@ -679,7 +699,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
             // compiler waits for it at the end of the branch: one memory round trip per unit in front of wave 0's adds), BEHIND
             // the batch loads just issued: every vmcnt the compiler computes for loads older than the atomic is merely one too
             // strict, and loads younger than it complete after it (in-order return) -- its bookkeeping stays valid.
-            if (tid < 64 && b0 == cur.j_lo) {
+            if (tid < 64 && b0 == cur.j_lo && claim_more) {
                 unsigned long long saved;
                 asm volatile("s_mov_b64 %1, exec\n\t"
                              "s_mov_b64 exec, 1\n\t"
@@ -702,7 +722,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         }
         lds_barrier();
         PACC_STAMP(cur.uid, 2);
-        AccUnitRaw nraw = acc_unit_fetch<DUAL, true>(plan, bm, block_base, 2 * G + __builtin_amdgcn_readfirstlane(s_claim), n_units);
+        AccUnitRaw nraw = acc_unit_fetch<DUAL, true>(plan, bm, block_base, dyn_base + __builtin_amdgcn_readfirstlane(s_claim), dyn_end);
         // ---- flush + clear
         const uint32_t size = lv.size[l];
         const uint32_t lo = cur.slab << sshift;
@@ -933,12 +953,17 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
     {
         const int g = blocks < n_cus ? blocks : n_cus;
         int* claim = acc_claim(bm);
+        // leading units that are parts of point-split slabs (the kernel's `hold`; -1: no tail units, no zone)
+        int hold = 0;
+        for (int l = level_lo; l < level_hi && h.plan.parts[l] > 1; ++l) hold += h.plan.first[l + 1] - h.plan.first[l];
+        if (hold > g || blocks < 3 * g) hold = 0;
+        if (!LS2FM_ACC_HOLD) hold = -1;
         if (dual)
             (add_into ? slab_accumulate_persistent_kernel<true, true> : slab_accumulate_persistent_kernel<true, false>)<<<g, kAccThreads, 0, stream>>>(
-                lv, h.plan, bm, sshift, dtable1, dtable2, base, blocks, combine, claim);
+                lv, h.plan, bm, sshift, dtable1, dtable2, base, blocks, combine, claim, hold);
         else
             (add_into ? slab_accumulate_persistent_kernel<false, true> : slab_accumulate_persistent_kernel<false, false>)<<<g, kAccThreads, 0, stream>>>(
-                lv, h.plan, bm, sshift, dtable1, nullptr, base, blocks, combine, claim);
+                lv, h.plan, bm, sshift, dtable1, nullptr, base, blocks, combine, claim, hold);
     }
     return ls2fm_launch_status();
 }

@@ -48,3 +48,33 @@ for rows in wg.values():
     for p, q in zip(rows[:-1], rows[1:]):
         gaps.append((q[0] - p[6]) / 100.0)
 print("gap between a unit's end barrier and the next unit's start: mean", np.mean(gaps), "max", np.max(gaps))
+last = max(wg, key=lambda b: max(r[6] for r in wg[b]))
+print("last workgroup", last, "units (level, items, start us, total us):",
+      [(int(r[4]), int(r[5]), round((r[0] - t0) / 100.0, 1), round((r[6] - r[0]) / 100.0, 1)) for r in sorted(wg[last], key=lambda r: r[0])])
+if os.environ.get("ACC_STAMPS_LONG"):
+    for r in a[a[:, 4] <= 2]:
+        print("level", int(r[4]), "uid", int(np.where((a == r).all(1))[0][0]), "items", int(r[5]), "start", round((r[0] - t0) / 100.0, 1),
+              " ".join(f"{n} {(r[e] - r[b]) / 100.0:6.2f}" for n, (b, e) in zip(names, cols)), "wg", int(r[7]))
+if os.environ.get("ACC_STAMPS_SIM"):
+    import heapq
+    dur = np.zeros(len(a)); items = np.zeros(len(a), dtype=np.int64); lev = np.zeros(len(a), dtype=np.int64)
+    rows = np.nonzero(np.array(buf[:], dtype=np.int64).reshape(4096, 8)[:, 0] > 0)[0]
+    full = np.array(buf[:], dtype=np.int64).reshape(4096, 8)
+    n = rows.max() + 1
+    dur = (full[:n, 6] - full[:n, 0]) / 100.0
+    G = 256
+    def deal(order_of_wg):
+        tot = np.zeros(G)
+        for u in range(n): tot[order_of_wg(u)] += dur[u]
+        return tot
+    snake = deal(lambda u: (u % G) if (u // G) % 2 == 0 else G - 1 - (u % G))
+    rr = deal(lambda u: u % G)
+    print("sum of unit times / G", dur.sum() / G, " round robin max", rr.max(), " snake min/max", snake.min(), snake.max())
+    h = [(0.0, w) for w in range(G)]; heapq.heapify(h)
+    for u in range(n):                       # list scheduling in uid order (what a zero-latency claim would do)
+        t, w = heapq.heappop(h); heapq.heappush(h, (t + dur[u], w))
+    print("list scheduling in uid order: max", max(t for t, _ in h), "min", min(t for t, _ in h))
+    h = [(0.0, w) for w in range(G)]; heapq.heapify(h)
+    for u in np.argsort(-dur):
+        t, w = heapq.heappop(h); heapq.heappush(h, (t + dur[u], w))
+    print("LPT: max", max(t for t, _ in h))
