@@ -590,7 +590,8 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
     // end times 48.8 / 54.8 / 67.3 us min / mean / max; list scheduling of the same unit times: 57.8), and its last workgroup
     // was always a part of the level-0 slab (50 us with the combine) + the two hashed units it had been sitting on.  So:
     //   * unit ids run level by level, coarse first; the first `hold` are LONG (parts of point-split slabs).  Their workgroups
-    //     get the LAST ids as their second unit -- work that is due at the end anyway -- and never claim;
+    //     get the LAST ids as their second unit -- work that is due at the end anyway -- and claim nothing while they work on
+    //     the long one (behind it: once, if the pool is not yet down to its zone -- see the flush);
     //   * the others take G + b - hold, then claim -- until the unit they hold as `next` is one of the pool's last G - hold
     //     (the zone): every claiming workgroup takes at most one unit of the zone, as its last.  (Every id is still taken: if
     //     one of the zone were not, the counter would have stopped below the pool's end, so every claiming workgroup would have
@@ -619,6 +620,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         for (int e = tid; e < kAccSlots / 2; e += kAccThreads) reinterpret_cast<uint4*>(acc)[e] = z;
     }
     lds_barrier();
+    bool first = true;
     while (cur.l >= 0) {
         // the unit after the next: claimed in this unit's first batch, read behind its streaming phase -- unless the NEXT unit is
         // already one of the zone (a tail id, or one of the pool's last G - hold): no claim behind it
@@ -783,6 +785,19 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
                 }
             }
         }
+        if (LS2FM_ACC_HOLD && first && b < n_hold) {
+            // a long unit's workgroup joins the claiming ones behind it -- one exposed round trip, once -- unless the pool is
+            // already down to its zone (the level-0 slab's combining part at C2: it ends with the tail unit it holds).  Without
+            // this the `hold` workgroups idle once their two units are done: 4096 rays, 200 of 256 workgroups, accumulate 253 -> 510 us
+            lds_barrier();                   // (every thread has read s_claim for this unit's fetch)
+            if (tid == 0) {
+                const int seen = __hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_claim = dyn_base + seen < zone_lo ? atomicAdd(claim, 1) : n_units;
+            }
+            __syncthreads();
+            nraw = acc_unit_fetch<DUAL, true>(plan, bm, block_base, dyn_base + __builtin_amdgcn_readfirstlane(s_claim), dyn_end);
+        }
+        first = false;
         PACC_STAMP(cur.uid, 3);
 #ifdef LS2FM_STAMPS
         if (tid == 0 && cur.uid < 4096) { g_acc_stamps[8 * cur.uid + 4] = l; g_acc_stamps[8 * cur.uid + 5] = cur.j_hi - cur.j_lo; g_acc_stamps[8 * cur.uid + 7] = blockIdx.x; }
