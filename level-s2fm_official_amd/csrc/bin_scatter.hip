@@ -562,9 +562,6 @@ __device__ __forceinline__ AccUnit acc_unit_finish(const AccUnitRaw& r, const Bi
 #ifndef LS2FM_ACC_PROBE
 #define LS2FM_ACC_PROBE 0
 #endif
-#ifndef LS2FM_ACC_HOLD
-#define LS2FM_ACC_HOLD 1          // 0: second units G + b for every workgroup, claims to the pool's end (A/B)
-#endif
 #ifdef LS2FM_STAMPS
 #define PACC_STAMP(uid, k) do { if (threadIdx.x == 0 && (uid) < 4096) g_acc_stamps[8 * (uid) + (k)] = wall_clock64(); } while (0)
 #else
@@ -785,7 +782,7 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
                 }
             }
         }
-        if (LS2FM_ACC_HOLD && first && b < n_hold) {
+        if (first && b < n_hold) {
             // a long unit's workgroup joins the claiming ones behind it -- one exposed round trip, once -- unless the pool is
             // already down to its zone (the level-0 slab's combining part at C2: it ends with the tail unit it holds).  Without
             // this the `hold` workgroups idle once their two units are done: 4096 rays, 200 of 256 workgroups, accumulate 253 -> 510 us
@@ -972,7 +969,10 @@ int ls2fm_launch_slab_accumulate(const ls2fm_grid_desc* grid, float* bins_ws, in
         int hold = 0;
         for (int l = level_lo; l < level_hi && h.plan.parts[l] > 1; ++l) hold += h.plan.first[l + 1] - h.plan.first[l];
         if (hold > g || blocks < 3 * g) hold = 0;
-        if (!LS2FM_ACC_HOLD) hold = -1;
+        // LS2FM_ACC_HOLD=0 (read once per process): second units G + b for every workgroup, claims to the pool's end -- the schedule of
+        // the round's first half, for A/B runs; the table gradients are the same bits either way (exact sums)
+        static const int hold_env = [] { const char* e = getenv("LS2FM_ACC_HOLD"); return e ? atoi(e) : 1; }();
+        if (!hold_env) hold = -1;
         if (dual)
             (add_into ? slab_accumulate_persistent_kernel<true, true> : slab_accumulate_persistent_kernel<true, false>)<<<g, kAccThreads, 0, stream>>>(
                 lv, h.plan, bm, sshift, dtable1, dtable2, base, blocks, combine, claim, hold);

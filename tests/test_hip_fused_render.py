@@ -442,3 +442,46 @@ np.savez(sys.argv[2], **out)
         for tag in ("fill", "side"):
             err = float(np.abs(got[tag][k] - ref).max()) / scale
             assert np.isfinite(got[tag][k]).all() and err < 1e-5, (tag, k, err)
+
+
+@pytest.mark.gpu
+def test_table_gradients_do_not_depend_on_the_accumulate_kernels_unit_schedule(tmp_path):
+    """Round 5: which units a workgroup of the persistent slab_accumulate kernel takes (tail ids behind the long point-split units,
+    no claims behind a unit of the pool's last ids; LS2FM_ACC_HOLD=0: static pairs + claims to the end) only moves work between
+    workgroups -- every entry is an exact fixed-point sum, so both table gradients of the benchmark's step and of a 4096-ray step
+    (200 of 256 workgroups start on a long unit there) are the same BITS under either schedule.  Two child processes (the switch is
+    read once)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, numpy as np, torch
+root = sys.argv[1]
+for p in (root, os.path.join(root, "level-s2fm_official_amd")):
+    sys.path.insert(0, p)
+import bench
+from ls2fm.options import make_options
+from ls2fm.models.SDF import SDF
+from ls2fm.models.RadF import RadF
+from ls2fm.models.Renderer import Renderer
+opt = make_options("ETH3D", device="cuda", dual_field=True, sample_intvs=128)
+torch.manual_seed(0)
+sdf, rad, ren = SDF(opt).cuda(), RadF(opt).cuda(), Renderer(opt)
+bench.randomize([sdf, rad], seed=0)
+out = {}
+for rays in (1024, 4096):
+    c, r = bench.synthetic_rays(rays, float(opt.data.bound_max[0]), "cuda", seed=0)
+    sdf.zero_grad(); rad.zero_grad()
+    bench.loss_head(ren.forward(opt, c, r, sdf, rad)).backward()
+    out[f"sdf{rays}"] = sdf.embed_fn.embedder_obj.params.grad.detach().cpu().numpy().copy()
+    out[f"rad{rays}"] = rad.embed_fn.embedder_obj.params.grad.detach().cpu().numpy().copy()
+np.savez(sys.argv[2], **out)
+'''
+    got = {}
+    for tag, env in (("hold", {}), ("plain", {"LS2FM_ACC_HOLD": "0"})):
+        path = str(tmp_path / f"{tag}.npz")
+        res = subprocess.run([sys.executable, "-c", code, root, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        got[tag] = dict(np.load(path))
+    assert len(got["hold"]) == 4
+    for k, ref in got["plain"].items():
+        assert np.abs(ref).max() > 0 and np.array_equal(got["hold"][k], ref), k
