@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 7
+#define LS2FM_ABI_VERSION 8
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -507,6 +507,17 @@ int ls2fm_tracing_term_fwd(const float* center, const float* ray, const float* d
                            const float* sdf_last, int64_t n, float* out, void* stream);
 int ls2fm_tracing_term_bwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
                            const float* sdf_last, int64_t n, const float* out, const float* g, float* d_d, float* d_sdf, void* stream);
+
+/* The loss lines of a bundle-adjustment iteration outside the render (pipelines/BA.py:160-170: `sdf_surf`, the adaptive weight
+ * 10^1 of the re-projection error above 10 px, the weighted sum) as one launch each way:
+ *   out_surf = mean |sdfs| ;  out_w = reproj > thresh ? w_hi : w_lo  (from the error's VALUE: no gradient through the choice) ;
+ *   out_extra = out_w reproj + w_surf out_surf + w_add add        (add: one more device scalar, e.g. the tracing loss; may be NULL)
+ * reproj, add, the three outputs: one float each (device); sdfs [n].  bwd: g [1] upstream of out_extra ->
+ * d_reproj [1] = g out_w, d_sdfs [n] = g w_surf sign(sdfs) / n (sign(0) = 0, as torch), d_add [1] = g w_add (NULL with add NULL). */
+int ls2fm_ba_terms_fwd(const float* reproj, const float* sdfs, int64_t n, const float* add, float thresh, float w_lo, float w_hi,
+                       float w_surf, float w_add, float* out_surf, float* out_w, float* out_extra, void* stream);
+int ls2fm_ba_terms_bwd(const float* sdfs, int64_t n, const float* w_reproj, const float* g, float w_surf, float w_add,
+                       float* d_reproj, float* d_sdfs, float* d_add, void* stream);
 
 /* SDF.get_surface_pts' projection line (models/SDF.py:104-110):  out = p - normals / |normals|.detach() * sdf ,  length = |normals|
  * (p, normals, out [n,3]; sdf, length [n]) and its gradient w.r.t. normals and sdf (d p = g_out, the caller's); g_out / g_length

@@ -255,6 +255,63 @@ extern "C" int ls2fm_tracing_term_bwd(const float* center, const float* ray, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The loss lines of a bundle-adjustment iteration outside the render (pipelines/BA.py:160-170 of the reference):
+//   sdf_surf = mean |sdfs| ;  w_reproj = reproj > thresh ? w_hi : w_lo (the adaptive weight, from the DETACHED error) ;
+//   extra = w_reproj reproj + w_surf sdf_surf + w_add add
+// -- nine elementwise / reduction torch kernels and seven of autograd's, one launch each way (a captured iteration pays >= 4.6 us
+// per graph node, whatever its size).
+namespace {
+__global__ void __launch_bounds__(kTtThreads)
+ba_terms_fwd_kernel(const float* __restrict__ reproj, const float* __restrict__ sdfs, int64_t n, const float* __restrict__ add, float thresh,
+                    float w_lo, float w_hi, float w_surf, float w_add, float* __restrict__ out_surf, float* __restrict__ out_w,
+                    float* __restrict__ out_extra) {
+    __shared__ double red[kTtThreads / 64];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = tid; i < n; i += kTtThreads) s += (double)fabsf(sdfs[i]);
+    const double tot = block_sum(s, red, tid);
+    if (tid == 0) {
+        const float surf = (float)(tot / (double)n);
+        const float r = reproj[0];
+        const float w = r > thresh ? w_hi : w_lo;
+        float e = fmaf(w_surf, surf, w * r);
+        if (add) e = fmaf(w_add, add[0], e);
+        out_surf[0] = surf; out_w[0] = w; out_extra[0] = e;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ba_terms_bwd_kernel(const float* __restrict__ sdfs, int64_t n, const float* __restrict__ w_reproj, const float* __restrict__ g, float w_surf,
+                    float w_add, float* __restrict__ d_reproj, float* __restrict__ d_sdfs, float* __restrict__ d_add) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float gg = g[0];
+    if (i == 0) {
+        d_reproj[0] = gg * w_reproj[0];
+        if (d_add) d_add[0] = gg * w_add;
+    }
+    if (i < n) {
+        const float s = sdfs[i];
+        d_sdfs[i] = (gg * w_surf / (float)n) * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));       // sign(0) = 0, as torch's abs backward
+    }
+}
+}  // namespace
+
+extern "C" int ls2fm_ba_terms_fwd(const float* reproj, const float* sdfs, int64_t n, const float* add, float thresh, float w_lo, float w_hi,
+                                  float w_surf, float w_add, float* out_surf, float* out_w, float* out_extra, void* stream) {
+    LS2FM_CHECK_ARG(n >= 1 && reproj && sdfs && out_surf && out_w && out_extra);
+    ba_terms_fwd_kernel<<<1, kTtThreads, 0, (hipStream_t)stream>>>(reproj, sdfs, n, add, thresh, w_lo, w_hi, w_surf, w_add, out_surf, out_w,
+                                                                  out_extra);
+    return ls2fm_launch_status();
+}
+
+extern "C" int ls2fm_ba_terms_bwd(const float* sdfs, int64_t n, const float* w_reproj, const float* g, float w_surf, float w_add,
+                                  float* d_reproj, float* d_sdfs, float* d_add, void* stream) {
+    LS2FM_CHECK_ARG(n >= 1 && sdfs && w_reproj && g && d_reproj && d_sdfs);
+    ba_terms_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(sdfs, n, w_reproj, g, w_surf, w_add, d_reproj, d_sdfs, d_add);
+    return ls2fm_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // SDF.get_surface_pts' last line (models/SDF.py:104-110 of the reference):  out = p - n / |n|.detach() * sdf ,  length = |n|
 // -- four elementwise torch kernels and ~10 of autograd's, one launch each way.  The norm is DETACHED inside the quotient: the
 // gradient reaches n through the product only, and through `length`.

@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -150,6 +150,8 @@ _SIGNATURES = {
     "ls2fm_se3_exp_bwd": (c_int32, [_P, _P, c_int32, _P, _P]),
     "ls2fm_tracing_term_fwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "ls2fm_tracing_term_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "ls2fm_ba_terms_fwd": (c_int32, [_P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "ls2fm_ba_terms_bwd": (c_int32, [_P, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "ls2fm_surface_pts_fwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
     "ls2fm_surface_pts_bwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "ls2fm_match_term_fwd": (c_int32, [_P, _P, _P, _P, POINTER(c_float), c_int32, c_int64, _P, _P, _P, _P, _P]),

@@ -247,8 +247,9 @@ class RenderStage:
         if self.extra_loss is not None:
             ret["loss_extra"] = self.extra_loss(ret)
             # (replicated on every rank of a view-sharded step: 1 / world of it per rank in the backward, the whole in the log)
-            loss_bwd = ret["loss_all"] + (ret["loss_extra"] if world == 1 else ret["loss_extra"] * (1.0 / world))
-            ret["loss_all"] = ret["loss_all"] + ret["loss_extra"]
+            total = ret["loss_all"] + ret["loss_extra"]
+            loss_bwd = total if world == 1 else ret["loss_all"] + ret["loss_extra"] * (1.0 / world)
+            ret["loss_all"] = total
         from . import fused as _fused
         with _fused.pass_gradient_sharing(self.share_gradients and static_trips and self.extra_prepare is not None):
             loss_bwd.backward(gradient=self._one)
@@ -472,7 +473,8 @@ class TracingConsistency:
         self.target.copy_(self.views.xyzs[self.views.id_pad[view]])
         self.live.copy_(self.views.kp_live[view])
 
-    def __call__(self, ret):
+    def __call__(self, ret, raw=False):
+        """raw=True (fused CUDA path without sdf_surf only): the UNWEIGHTED tracing loss -- the caller multiplies by `w_tracing`"""
         early = self._early.take()
         d, sdf_last = early[:2] if early is not None else self.sdf.sphere_tracing(self.center, self.ray, self.sdf, static_trips=self.static)[:2]
         if d.is_cuda and d.dtype == torch.float32:
@@ -480,6 +482,8 @@ class TracingConsistency:
             # of their autograd mirror is a graph node of >= 4.6 us, whatever its size
             terms = _TracingTerm.apply(self.center, self.ray, d, self.target, self.live, sdf_last if self.use_sdfs else None)
             ret["tracing_loss"] = terms[0]
+            if raw and not self.use_sdfs:          # the caller weights it inside a fused node of its own (BALoop)
+                return ret["tracing_loss"]
             loss = self.w_tracing * ret["tracing_loss"]
             if self.use_sdfs:
                 ret["sdf_surf"] = terms[1]
@@ -529,6 +533,46 @@ class _TracingTerm(torch.autograd.Function):
                                               _lib.ptr(out), _lib.ptr(g), _lib.ptr(d_d), _lib.ptr(d_s), _lib.stream_ptr()),
                    "ls2fm_tracing_term_bwd")
         return None, None, d_d.view(ctx.shapes[0]), None, None, (None if d_s is None else d_s.view(ctx.shapes[1]))
+
+
+class _BATerms(torch.autograd.Function):
+    """BA.run_ba's loss lines outside the render (pipelines/BA.py:160-170) as one fused node each way (include/ls2fm.h:
+    ls2fm_ba_terms_fwd / _bwd): (sdf_surf, w_reproj, extra) with sdf_surf = mean |sdfs|, w_reproj = w_hi where the re-projection
+    error exceeds `thresh` else w_lo (from the detached error), extra = w_reproj reproj + w_surf sdf_surf + w_add add.  Only
+    `extra` carries a gradient (the other two are the log's)."""
+
+    @staticmethod
+    def forward(ctx, reproj, sdfs, add, thresh, w_lo, w_hi, w_surf, w_add):
+        from . import _lib
+        lib = _lib.load()
+        r = reproj.detach().reshape(1).float().contiguous()
+        s = sdfs.detach().reshape(-1).float().contiguous()
+        a = None if add is None else add.detach().reshape(1).float().contiguous()
+        surf, w, extra = (torch.empty((), device=s.device) for _ in range(3))
+        _lib.check(lib.ls2fm_ba_terms_fwd(_lib.ptr(r), _lib.ptr(s), s.numel(), _lib.ptr(a), float(thresh), float(w_lo), float(w_hi),
+                                          float(w_surf), float(w_add), _lib.ptr(surf), _lib.ptr(w), _lib.ptr(extra), _lib.stream_ptr()),
+                   "ls2fm_ba_terms_fwd")
+        ctx.save_for_backward(s, w)
+        ctx.consts = (float(w_surf), float(w_add), reproj.shape, sdfs.shape, None if add is None else add.shape)
+        ctx.mark_non_differentiable(surf, w)
+        ctx.set_materialize_grads(False)
+        return surf, w, extra
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_surf, g_w, g):
+        from . import _lib
+        lib = _lib.load()
+        s, w = ctx.saved_tensors
+        w_surf, w_add, shape_r, shape_s, shape_a = ctx.consts
+        if g is None:
+            return (None,) * 8
+        g = g.reshape(1).float().contiguous()
+        d_r, d_s = torch.empty(1, device=s.device), torch.empty_like(s)
+        d_a = None if shape_a is None else torch.empty(1, device=s.device)
+        _lib.check(lib.ls2fm_ba_terms_bwd(_lib.ptr(s), s.numel(), _lib.ptr(w), _lib.ptr(g), w_surf, w_add, _lib.ptr(d_r), _lib.ptr(d_s),
+                                          _lib.ptr(d_a), _lib.stream_ptr()), "ls2fm_ba_terms_bwd")
+        return d_r.view(shape_r), d_s.view(shape_s), (None if d_a is None else d_a.view(shape_a)), None, None, None, None, None
 
 
 class _MatchTerm(torch.autograd.Function):
@@ -1041,6 +1085,16 @@ class BALoop:
             reproj, _ = reprojection_term(xyzs_new, poses, self.view_start, self._k_host, self.obs_uv, sdfs, 2 * self.sdf_threshold)
         else:
             reproj = self._reproj_torch(xyzs_new, poses, sdfs)
+        if xyzs_new.is_cuda and sdfs.dtype == torch.float32:
+            # BA.py:160-170 as one node each way: sdf_surf, the adaptive weight, the weighted sum with the tracing loss
+            on = 1.0 if self.w_reproj_lo else 0.0
+            tl = self.tracing(ret, raw=True)           # unweighted on its fused path (then it IS ret["tracing_loss"]), else weighted
+            raw = tl is ret.get("tracing_loss")
+            surf, w_reproj, extra = _BATerms.apply(reproj, sdfs, tl if raw else None, 10.0, on, 10.0 * on, self.w_surf,
+                                                   self.tracing.w_tracing if raw else 0.0)
+            ret["reproj_error"], ret["w_reproj"], ret["sdf_surf"] = reproj, w_reproj, surf
+            self._new_points = xyzs_new.detach()
+            return extra if raw else extra + tl
         if getattr(self, "_w_hi", None) is None or self._w_hi.device != reproj.device:       # constants once, not two fill kernels per iteration
             on = 1.0 if self.w_reproj_lo else 0.0
             self._w_hi, self._w_lo = torch.full((), 10.0 * on, device=reproj.device), torch.full((), on, device=reproj.device)

@@ -153,6 +153,44 @@ def test_fused_tracing_term_matches_the_torch_lines(use_sdfs):
         assert torch.allclose(f[3], t[3], rtol=2e-5, atol=1e-9) and float(f[3][7]) == 0.0
 
 
+@pytest.mark.parametrize("error,with_add", [(3.5, True), (12.0, True), (12.0, False), (10.0, False)])
+def test_fused_ba_terms_match_the_torch_lines(error, with_add):
+    """ls2fm_ba_terms_fwd / _bwd against BALoop._extra's torch lines (pipelines/BA.py:160-170): sdf_surf = mean |sdfs|, the adaptive
+    weight from the DETACHED re-projection error (10^1 above 10 px, not AT 10), the weighted sum with the tracing loss -- values and
+    the gradients w.r.t. the error, the SDF values (a zero among them: sign(0) = 0) and the added term"""
+    from ls2fm import _lib
+    from ls2fm.stage import _BATerms
+    gen = torch.Generator().manual_seed(29)
+    n = 1337
+    s0 = torch.randn(n, 1, generator=gen).to(DEV) * 0.01
+    s0[11] = 0.0
+    w_surf, w_add = 10.0 ** 1.5, 10.0 ** 0.5
+    res = {}
+    for which in ("fused", "torch"):
+        r = torch.tensor(error, device=DEV, requires_grad=True)
+        sd = s0.clone().requires_grad_(True)
+        a = torch.tensor(0.37, device=DEV, requires_grad=True) if with_add else None
+        if which == "fused":
+            surf, w, extra = _BATerms.apply(r, sd, a, 10.0, 1.0, 10.0, w_surf, w_add if with_add else 0.0)
+            assert not surf.requires_grad and not w.requires_grad
+        else:
+            w = torch.where(r.detach() > 10, torch.full((), 10.0, device=DEV), torch.full((), 1.0, device=DEV))
+            surf = sd.abs().mean()
+            extra = w * r + w_surf * surf + (w_add * a if with_add else 0.0)
+        (2.0 * extra).backward()
+        res[which] = (surf.detach(), w.detach(), extra.detach(), r.grad.clone(), sd.grad.clone(), None if a is None else a.grad.clone())
+    f, t = res["fused"], res["torch"]
+    assert float(f[1]) == float(t[1]) == (10.0 if error > 10 else 1.0)
+    assert abs(float(f[0]) - float(t[0])) < 2e-6 * abs(float(t[0])) and abs(float(f[2]) - float(t[2])) < 2e-6 * abs(float(t[2]))
+    assert float(f[3]) == float(t[3])
+    assert torch.allclose(f[4], t[4], rtol=2e-6, atol=0.0) and float(f[4][11]) == 0.0 and f[4].shape == s0.shape
+    if with_add:
+        assert abs(float(f[5]) - float(t[5])) < 1e-6 * abs(float(t[5]))
+    lib = _lib.load()
+    assert lib.ls2fm_ba_terms_fwd(None, None, 4, None, 10.0, 1.0, 10.0, 1.0, 0.0, None, None, None, _lib.stream_ptr()) == -1
+    assert lib.ls2fm_ba_terms_bwd(None, 0, None, None, 1.0, 0.0, None, None, None, _lib.stream_ptr()) == -1
+
+
 def test_fused_match_term_matches_the_torch_lines():
     """ls2fm_match_term_fwd / _bwd against the torch lines of InitLoop._extra they replace (Camera.py:136, 168-178 +
     Initialization.py:154-160): surface points, cross-view projection, pixel error and |sdf| means over both views, and the
