@@ -616,6 +616,41 @@ class _MatchTerm(torch.autograd.Function):
         return (None, None, *grads)
 
 
+class _HostPicks:
+    """The per-iteration ray pick of the loops -- the first k entries of a random permutation of the H W pixels, as the reference's
+    `torch.randperm(H * W, device=...)[:k]` (pipelines/Camera.py:263, 431, 468) -- drawn on the HOST (numpy `Generator.choice`
+    without replacement: the same distribution; seeded from `torch.initial_seed()`) and handed to the device with ONE asynchronous
+    copy, together with the iteration's view index, from a ring of pinned buffers.  The device-side randperm is a radix sort of
+    H W keys: 12 launches / 56 us in front of every captured iteration, for 15 us of host time that overlaps the previous
+    iteration.  `dev[:k]` are the pixel indices, `dev[k:]` the tail values (the view); `device_picks=True` on a loop keeps the
+    device-side draw."""
+    RING = 8
+
+    def __init__(self, n_total, k, device, tail=1):
+        import numpy as np
+        self.n, self.k, self.tail = int(n_total), int(k), int(tail)
+        self.rng = np.random.default_rng(int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF)
+        self.dev = torch.zeros(self.k + self.tail, dtype=torch.long, device=device)
+        cuda = self.dev.is_cuda
+        self.host = [torch.zeros(self.k + self.tail, dtype=torch.long).pin_memory() if cuda else torch.zeros(self.k + self.tail, dtype=torch.long)
+                     for _ in range(self.RING if cuda else 1)]
+        self.events = [None] * len(self.host)
+        self.slot = 0
+
+    def draw(self, *tail_values):
+        h, ev = self.host[self.slot], self.events[self.slot]
+        if ev is not None:
+            ev.synchronize()                     # (the copy that last read this pinned buffer: RING iterations ago)
+        h[:self.k] = torch.from_numpy(self.rng.choice(self.n, self.k, replace=False))
+        for q, v in enumerate(tail_values):
+            h[self.k + q] = int(v)
+        self.dev.copy_(h, non_blocking=True)
+        if self.dev.is_cuda:
+            self.events[self.slot] = torch.cuda.Event()
+            self.events[self.slot].record()
+        self.slot = (self.slot + 1) % len(self.host)
+
+
 def _pick_rays(views, poses, rays_idx, se3=None, poses_out=None):
     """CameraSet.render's ray pick for given poses (Camera.py:457-463): the same pixels in every view.  se3 [V,6]: the poses are
     the exponentials of these parameters, formed in the same launch (and left in poses_out)"""
@@ -656,11 +691,12 @@ class RefineLoop:
                           lr_color=1e-3, max_iter=500, rand_rays=8192)
         logs = loop.run()                      # {"all": [max_iter], "PSNR": ..., ...} device tensors
 
-    picks: optional per-iteration (rays_idx, view) pairs (parity tests replay the reference's draws); default: a device-side
-    `torch.randperm(H * W)` head and a host-side random view per iteration (no device synchronisation either way)."""
+    picks: optional per-iteration (rays_idx, view) pairs (parity tests replay the reference's draws); default: the pixel indices and
+    the view drawn on the host and copied in one asynchronous transfer (`_HostPicks`; `device_picks=True`: the reference's
+    device-side `torch.randperm(H * W)` head) -- no device synchronisation either way."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, max_iter, rand_rays,
-                 capture=False, static_trips=None, distributed=False):
+                 capture=False, static_trips=None, distributed=False, device_picks=False):
         """distributed=True (a process group is up; every rank holds the same views, weights and per-iteration picks): the render
         rays are sharded by view, the gradients all-reduced (RenderStage(shard_views=True, reducer="auto"))"""
         get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
@@ -676,8 +712,10 @@ class RefineLoop:
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss")
         # an iteration's picks as device tensors, updated in place: the ray pick and the key-point rays are formed INSIDE the step
         dev = self.poses.device
-        self._idx = torch.zeros(self.rand_rays // self.poses.shape[0], dtype=torch.long, device=dev)
-        self._view = torch.zeros(1, dtype=torch.long, device=dev)
+        k = self.rand_rays // self.poses.shape[0]
+        self._picks = _HostPicks(views.H * views.W, k, dev, tail=1)          # pixel indices + the view, one buffer, one copy per iteration
+        self._idx, self._view = self._picks.dev[:k], self._picks.dev[k:]
+        self.device_picks = bool(device_picks)
         self._fixed = _FixedPoseRays(views, self.poses)
 
     def _inputs(self):
@@ -686,6 +724,9 @@ class RefineLoop:
 
     def step(self, rays_idx=None, view=None):
         V = self.poses.shape[0]
+        if rays_idx is None and view is None and not self.device_picks:
+            self._picks.draw(random.randint(0, V - 1))
+            return self.stage.step()
         if rays_idx is None:
             rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // V]
         self._idx.copy_(rays_idx)
@@ -714,7 +755,7 @@ class InitLoop:
     `kypts[mch_msks[..., 0]][inlier_msks]` and `cam_i.kypts[mch_msks[..., 1]][inlier_msks]` select); track_ids / xyzs unused."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, max_iter, rand_rays,
-                 capture=False, static_trips=None, sdf_filter=True):
+                 capture=False, static_trips=None, sdf_filter=True, device_picks=False):
         get = (lambda k: weights.get(k)) if isinstance(weights, dict) else (lambda k: getattr(weights, k, None))
         if len(views.keypoints) != 2 or views.keypoints[0].shape != views.keypoints[1].shape:
             raise ValueError("ls2fm.stage.InitLoop: two views with the same number of matched key points")
@@ -730,7 +771,9 @@ class InitLoop:
         self.stage = RenderStage(opt, renderer, sdf_field, rad_field, weights=weights, lr=lr_sdf, lr_end=lr_sdf_end, max_iter=max_iter,
                                  lr_color=lr_color, capture=capture, extra_loss=self._extra, eikonal_over="all", extra_prepare=self._prepare,
                                  input_fn=lambda: self._fixed.pick(self._idx), share_gradients=bool(self.static))
-        self._idx = torch.zeros(self.rand_rays // 2, dtype=torch.long, device=self.poses.device)
+        self._picks = _HostPicks(views.H * views.W, self.rand_rays // 2, self.poses.device, tail=0)
+        self._idx = self._picks.dev
+        self.device_picks = bool(device_picks)
         self._fixed = _FixedPoseRays(views, self.poses)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "reproj_error")
         self._surface = self._finish = None
@@ -785,9 +828,13 @@ class InitLoop:
         return self.w_reproj * ret["reproj_error"] + self.w_surf * ret["sdf_surf"]
 
     def step(self, rays_idx=None):
-        if rays_idx is None:
+        if rays_idx is None and not self.device_picks:
+            self._picks.draw()
+            rays_idx = self._idx
+        elif rays_idx is None:
             rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // 2]
-        self._idx.copy_(rays_idx)
+        if rays_idx is not self._idx:
+            self._idx.copy_(rays_idx)
         return self.stage.step()
 
     def run(self, n_iters=None, picks=None):
@@ -1017,7 +1064,7 @@ class BALoop:
     (BA.py:181)."""
 
     def __init__(self, opt, renderer, sdf_field, rad_field, views, weights, lr_sdf, lr_sdf_end, lr_color, lr_pose_r, lr_pose_t,
-                 max_iter, rand_rays, capture=False, static_trips=None, distributed=False):
+                 max_iter, rand_rays, capture=False, static_trips=None, distributed=False, device_picks=False):
         """distributed=True: BASELINE.json configs[3] -- the render rays of the registered views sharded by view over the ranks of
         the process group, one gradient all-reduce per iteration (fields' flat buffer + the pose groups); the point side,
         re-projection and tracing consistency are evaluated on every rank (same inputs) with weight 1 / world in the backward"""
@@ -1050,8 +1097,10 @@ class BALoop:
                                  extra_params=[dict(params=[self.rot], lr=lr_pose_r), dict(params=[self.trans], lr=lr_pose_t)],
                                  extra_prepare=self._prepare, input_fn=self._inputs, share_gradients=bool(static),
                                  shard_views=bool(distributed), reducer="auto" if distributed else None)
-        self._idx = torch.zeros(self.rand_rays // se3.shape[0], dtype=torch.long, device=se3.device)
-        self._view = torch.zeros(1, dtype=torch.long, device=se3.device)
+        k = self.rand_rays // se3.shape[0]
+        self._picks = _HostPicks(views.H * views.W, k, se3.device, tail=1)
+        self._idx, self._view = self._picks.dev[:k], self._picks.dev[k:]
+        self.device_picks = bool(device_picks)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")
         self._render_poses = torch.zeros(se3.shape[0], 3, 4, device=se3.device)
         # the key-point rays of the tracing consistency come from the CAMERAS' own poses (Camera.get_pts3D -> get_pose,
@@ -1117,10 +1166,13 @@ class BALoop:
 
     def step(self, rays_idx=None, view=None):
         V = self.rot.shape[0]
-        if rays_idx is None:
-            rays_idx = torch.randperm(self.views.H * self.views.W, device=self.rot.device)[: self.rand_rays // V]
-        self._idx.copy_(rays_idx)
-        self._view.fill_(random.randint(0, V - 1) if view is None else int(view))
+        if rays_idx is None and view is None and not self.device_picks:
+            self._picks.draw(random.randint(0, V - 1))
+        else:
+            if rays_idx is None:
+                rays_idx = torch.randperm(self.views.H * self.views.W, device=self.rot.device)[: self.rand_rays // V]
+            self._idx.copy_(rays_idx)
+            self._view.fill_(random.randint(0, V - 1) if view is None else int(view))
         ret = self.stage.step()
         with torch.no_grad():
             self.xyzs_all[self.obs_point] = self._new_points                                     # BA.py:181

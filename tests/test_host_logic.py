@@ -28,7 +28,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ls2fm.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared          # the python binding covers the whole header
-    assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == 7
+    abi = int(re.search(r"#define\s+LS2FM_ABI_VERSION\s+(\d+)", header).group(1))          # library, binding and header agree
+    assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == abi
     assert lib.ls2fm_status_string(-2) == b"unsupported configuration"
 
 

@@ -1,3 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_hip_camera_rays.py tests/test_hip_stage_loops.py tests/test_hip_stage.py tests/test_hip_dist_two_rank.py -m gpu -x -q 2>&1 | tail -15
+timeout 1200 python -m pytest tests/test_hip_camera_rays.py tests/test_hip_stage_loops.py tests/test_hip_stage.py tests/test_hip_dist_two_rank.py tests/test_hip_checkpoint.py tests/test_hip_training_trajectory.py -m gpu -x -q 2>&1 | tail -3
+python tools/time_loops.py 2>&1 | grep -v amdgpu
+rocprofv3 --kernel-trace -d gpurun_out/ltl -- python tools/loop_timeline.py run BA >/dev/null 2>&1
+python tools/loop_timeline.py show gpurun_out/ltl | cut -c1-120 > gpurun_out/tl_BA.txt; grep "iteration span" gpurun_out/tl_BA.txt; rm -rf gpurun_out/ltl
