@@ -501,12 +501,14 @@ int ls2fm_camera_rays(const float* poses, const float* se3, const float* kinv_ho
  * points (pipelines/Camera.py:108-143 get_pts3D and the callers' loss lines, e.g. BA.py:155-161) -- as one launch each way:
  *   surface_i = center_i + ray_i d_i ;  w_i = live_i / sum(live) ;  out[0] = sum_i |target_i - surface_i| w_i ;
  *   out[1] = sum_i |sdf_last_i| w_i (0 when sdf_last is NULL) ;  out[2] = sum(live)            (fp64 fixed-order sums)
- * center, ray, target [n,3], d, live, sdf_last [n] (device); out [3].  bwd: g [2] upstream of out[0], out[1] (device) ->
- * d_d [n], d_sdf [n] (NULL with sdf_last NULL); d |e| / d d at e = 0 is 0, sign(0) = 0, as torch. */
+ * center, ray, target [n,3], d, live, sdf_last [n] (device); out [3].  bwd: g_tl, g_sd: one float each, the upstreams of out[0]
+ * and out[1] (device; NULL = that term has no upstream: zero) -> d_d [n], d_sdf [n] (NULL with sdf_last NULL); d |e| / d d at
+ * e = 0 is 0, sign(0) = 0, as torch. */
 int ls2fm_tracing_term_fwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
                            const float* sdf_last, int64_t n, float* out, void* stream);
 int ls2fm_tracing_term_bwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
-                           const float* sdf_last, int64_t n, const float* out, const float* g, float* d_d, float* d_sdf, void* stream);
+                           const float* sdf_last, int64_t n, const float* out, const float* g_tl, const float* g_sd, float* d_d,
+                           float* d_sdf, void* stream);
 
 /* The loss lines of a bundle-adjustment iteration outside the render (pipelines/BA.py:160-170: `sdf_surf`, the adaptive weight
  * 10^1 of the re-projection error above 10 px, the weighted sum) as one launch each way:

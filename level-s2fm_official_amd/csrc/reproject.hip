@@ -216,9 +216,11 @@ tracing_term_fwd_kernel(const float* __restrict__ center, const float* __restric
 __global__ void __launch_bounds__(256)
 tracing_term_bwd_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ d,
                         const float* __restrict__ target, const float* __restrict__ live, const float* __restrict__ sdf_last, int64_t n,
-                        const float* __restrict__ out, const float* __restrict__ g, float* __restrict__ d_d, float* __restrict__ d_sdf) {
+                        const float* __restrict__ out, const float* __restrict__ g_tl, const float* __restrict__ g_sd, float* __restrict__ d_d,
+                        float* __restrict__ d_sdf) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const float g0 = g_tl ? g_tl[0] : 0.f, g1 = g_sd ? g_sd[0] : 0.f;          // (a term nobody differentiates: no upstream)
     const float w = live[i] / out[2];
     float e[3], q = 0.f;
 #pragma unroll
@@ -229,10 +231,10 @@ tracing_term_bwd_kernel(const float* __restrict__ center, const float* __restric
     const float len = sqrtf(q);
     // d |e| / d d = -(e . ray) / |e|   (0 at e = 0, as torch's norm backward)
     const float dot = fmaf(e[2], ray[3 * i + 2], fmaf(e[1], ray[3 * i + 1], e[0] * ray[3 * i]));
-    d_d[i] = len > 0.f ? -(g[0] * w) * dot / len : 0.f;
+    d_d[i] = len > 0.f ? -(g0 * w) * dot / len : 0.f;
     if (d_sdf) {
         const float s = sdf_last[i];
-        d_sdf[i] = g[1] * w * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));
+        d_sdf[i] = g1 * w * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));
     }
 }
 
@@ -246,11 +248,11 @@ extern "C" int ls2fm_tracing_term_fwd(const float* center, const float* ray, con
 }
 
 extern "C" int ls2fm_tracing_term_bwd(const float* center, const float* ray, const float* d, const float* target, const float* live,
-                                      const float* sdf_last, int64_t n, const float* out, const float* g, float* d_d, float* d_sdf,
-                                      void* stream) {
-    LS2FM_CHECK_ARG(n >= 1 && center && ray && d && target && live && out && g && d_d && ((sdf_last != nullptr) == (d_sdf != nullptr)));
-    tracing_term_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(center, ray, d, target, live, sdf_last, n, out, g,
-                                                                                        d_d, d_sdf);
+                                      const float* sdf_last, int64_t n, const float* out, const float* g_tl, const float* g_sd, float* d_d,
+                                      float* d_sdf, void* stream) {
+    LS2FM_CHECK_ARG(n >= 1 && center && ray && d && target && live && out && d_d && ((sdf_last != nullptr) == (d_sdf != nullptr)));
+    tracing_term_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(center, ray, d, target, live, sdf_last, n, out, g_tl,
+                                                                                        g_sd, d_d, d_sdf);
     return ls2fm_launch_status();
 }
 

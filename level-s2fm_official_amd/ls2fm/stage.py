@@ -518,19 +518,24 @@ class _TracingTerm(torch.autograd.Function):
                                               _lib.ptr(out), _lib.stream_ptr()), "ls2fm_tracing_term_fwd")
         ctx.save_for_backward(c, r, dd, t, lv, out, *([] if sl is None else [sl]))
         ctx.shapes = (d.shape, None if sdf_last is None else sdf_last.shape)
-        return out[:2]
+        # the two terms as tensors of their own (views of `out` made HERE, outside autograd): indexing a stacked result afterwards
+        # costs a zero fill + a copy per term in the backward -- graph nodes of a captured iteration
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
 
     @staticmethod
-    def backward(ctx, g):
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_tl, g_sd):
         from . import _lib
         lib = _lib.load()
         c, r, dd, t, lv, out = ctx.saved_tensors[:6]
         sl = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
-        g = g.contiguous()
+        g_tl = None if g_tl is None else g_tl.reshape(1).float().contiguous()
+        g_sd = None if g_sd is None else g_sd.reshape(1).float().contiguous()
         d_d = torch.empty_like(dd)
         d_s = None if sl is None else torch.empty_like(sl)
         _lib.check(lib.ls2fm_tracing_term_bwd(_lib.ptr(c), _lib.ptr(r), _lib.ptr(dd), _lib.ptr(t), _lib.ptr(lv), _lib.ptr(sl), lv.numel(),
-                                              _lib.ptr(out), _lib.ptr(g), _lib.ptr(d_d), _lib.ptr(d_s), _lib.stream_ptr()),
+                                              _lib.ptr(out), _lib.ptr(g_tl), _lib.ptr(g_sd), _lib.ptr(d_d), _lib.ptr(d_s), _lib.stream_ptr()),
                    "ls2fm_tracing_term_bwd")
         return None, None, d_d.view(ctx.shapes[0]), None, None, (None if d_s is None else d_s.view(ctx.shapes[1]))
 
@@ -1025,6 +1030,7 @@ class _Reproject(torch.autograd.Function):
         ctx.k_host, ctx.bound, ctx.has_sdf = k_host, float(bound), sdf_c is not None
         counted = on.view(torch.bool)
         ctx.mark_non_differentiable(counted)
+        ctx.set_materialize_grads(False)         # (no zero fill for the bool output's "gradient" in the backward)
         return sums[3].float(), counted
 
     @staticmethod
@@ -1033,6 +1039,8 @@ class _Reproject(torch.autograd.Function):
         from . import _lib
         lib = _lib.load()
         x, ps, view_start, obs_uv, sdf_c, sums = ctx.saved_tensors
+        if d_reproj is None:
+            return (None,) * 7
         d_x, d_ps = torch.empty_like(x), torch.empty_like(ps)
         g = d_reproj.detach().float().reshape(1).contiguous()
         _lib.check(lib.ls2fm_reproject_bwd(_lib.ptr(x), _lib.ptr(ps), _lib.ptr(view_start), ps.shape[0], ctx.k_host, _lib.ptr(obs_uv),
