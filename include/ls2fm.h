@@ -521,6 +521,11 @@ int ls2fm_ba_terms_fwd(const float* reproj, const float* sdfs, int64_t n, const 
 int ls2fm_ba_terms_bwd(const float* sdfs, int64_t n, const float* w_reproj, const float* g, float w_surf, float w_add,
                        float* d_reproj, float* d_sdfs, float* d_add, void* stream);
 
+/* out[0] = wa a[0] + wb b[0] of two device scalars (the loops' weighted sums of two loss terms, e.g. Initialization.py:252-255);
+ * bwd: d2[0] = g[0] wa, d2[1] = g[0] wb (one two-float buffer).  One launch each way instead of five elementwise kernels. */
+int ls2fm_weighted_pair_fwd(const float* a, const float* b, float wa, float wb, float* out, void* stream);
+int ls2fm_weighted_pair_bwd(const float* g, float wa, float wb, float* d2, void* stream);
+
 /* SDF.get_surface_pts' projection line (models/SDF.py:104-110):  out = p - normals / |normals|.detach() * sdf ,  length = |normals|
  * (p, normals, out [n,3]; sdf, length [n]) and its gradient w.r.t. normals and sdf (d p = g_out, the caller's); g_out / g_length
  * may be NULL (no upstream for that output).  One launch each way instead of ~14 elementwise kernels. */

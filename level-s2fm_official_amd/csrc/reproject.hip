@@ -298,6 +298,29 @@ ba_terms_bwd_kernel(const float* __restrict__ sdfs, int64_t n, const float* __re
 }
 }  // namespace
 
+namespace {
+__global__ void weighted_pair_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float wa, float wb, float* __restrict__ out) {
+    out[0] = fmaf(wb, b[0], wa * a[0]);
+}
+__global__ void weighted_pair_bwd_kernel(const float* __restrict__ g, float wa, float wb, float* __restrict__ d2) {
+    d2[0] = g[0] * wa;
+    d2[1] = g[0] * wb;
+}
+}  // namespace
+
+// wa a + wb b of two device scalars, and its gradient as ONE two-float buffer (the loops' weighted sums of two loss terms: two
+// multiplications and an addition, two more multiplications in the backward -- graph nodes of a captured iteration)
+extern "C" int ls2fm_weighted_pair_fwd(const float* a, const float* b, float wa, float wb, float* out, void* stream) {
+    LS2FM_CHECK_ARG(a && b && out);
+    weighted_pair_fwd_kernel<<<1, 1, 0, (hipStream_t)stream>>>(a, b, wa, wb, out);
+    return ls2fm_launch_status();
+}
+extern "C" int ls2fm_weighted_pair_bwd(const float* g, float wa, float wb, float* d2, void* stream) {
+    LS2FM_CHECK_ARG(g && d2);
+    weighted_pair_bwd_kernel<<<1, 1, 0, (hipStream_t)stream>>>(g, wa, wb, d2);
+    return ls2fm_launch_status();
+}
+
 extern "C" int ls2fm_ba_terms_fwd(const float* reproj, const float* sdfs, int64_t n, const float* add, float thresh, float w_lo, float w_hi,
                                   float w_surf, float w_add, float* out_surf, float* out_w, float* out_extra, void* stream) {
     LS2FM_CHECK_ARG(n >= 1 && reproj && sdfs && out_surf && out_w && out_extra);

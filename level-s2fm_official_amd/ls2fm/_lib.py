@@ -150,6 +150,8 @@ _SIGNATURES = {
     "ls2fm_se3_exp_bwd": (c_int32, [_P, _P, c_int32, _P, _P]),
     "ls2fm_tracing_term_fwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "ls2fm_tracing_term_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
+    "ls2fm_weighted_pair_fwd": (c_int32, [_P, _P, c_float, c_float, _P, _P]),
+    "ls2fm_weighted_pair_bwd": (c_int32, [_P, c_float, c_float, _P, _P]),
     "ls2fm_ba_terms_fwd": (c_int32, [_P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P]),
     "ls2fm_ba_terms_bwd": (c_int32, [_P, c_int64, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "ls2fm_surface_pts_fwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),

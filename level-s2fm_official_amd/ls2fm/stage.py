@@ -484,11 +484,10 @@ class TracingConsistency:
             ret["tracing_loss"] = terms[0]
             if raw and not self.use_sdfs:          # the caller weights it inside a fused node of its own (BALoop)
                 return ret["tracing_loss"]
-            loss = self.w_tracing * ret["tracing_loss"]
             if self.use_sdfs:
                 ret["sdf_surf"] = terms[1]
-                loss = loss + self.w_surf * ret["sdf_surf"]
-            return loss
+                return _weighted_pair(ret["tracing_loss"], ret["sdf_surf"], self.w_tracing, self.w_surf)
+            return self.w_tracing * ret["tracing_loss"]
         # (few, fat torch ops: in a captured iteration every elementwise kernel here and in its backward is ~8 us of launch gap)
         surface = torch.addcmul(self.center[0], self.ray[0], d.reshape(-1, 1))
         weight = self.live / self.live.sum()                                    # no graph: 1 / count on the live key points
@@ -538,6 +537,39 @@ class _TracingTerm(torch.autograd.Function):
                                               _lib.ptr(out), _lib.ptr(g_tl), _lib.ptr(g_sd), _lib.ptr(d_d), _lib.ptr(d_s), _lib.stream_ptr()),
                    "ls2fm_tracing_term_bwd")
         return None, None, d_d.view(ctx.shapes[0]), None, None, (None if d_s is None else d_s.view(ctx.shapes[1]))
+
+
+class _WeightedPair(torch.autograd.Function):
+    """wa a + wb b of two device scalars as one node each way (ls2fm_weighted_pair_fwd / _bwd).  The two gradients are the halves
+    of ONE two-float buffer: a producer that returned `a` and `b` as the halves of one buffer too (_MatchTerm) gets its upstream
+    back contiguous and needs no stacking kernel"""
+
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        from . import _lib
+        lib = _lib.load()
+        out = torch.empty((), device=a.device)
+        _lib.check(lib.ls2fm_weighted_pair_fwd(_lib.ptr(a.detach()), _lib.ptr(b.detach()), float(wa), float(wb), _lib.ptr(out),
+                                               _lib.stream_ptr()), "ls2fm_weighted_pair_fwd")
+        ctx.w = (float(wa), float(wb), a.shape, b.shape)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        wa, wb, sa, sb = ctx.w
+        d2 = torch.empty(2, device=g.device)
+        _lib.check(lib.ls2fm_weighted_pair_bwd(_lib.ptr(g.reshape(1).float().contiguous()), wa, wb, _lib.ptr(d2), _lib.stream_ptr()),
+                   "ls2fm_weighted_pair_bwd")
+        return d2[0].view(sa), d2[1].view(sb), None, None
+
+
+def _weighted_pair(a, b, wa, wb):
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.numel() == 1 and b.numel() == 1:
+        return _WeightedPair.apply(a, b, wa, wb)
+    return wa * a + wb * b
 
 
 class _BATerms(torch.autograd.Function):
@@ -600,11 +632,12 @@ class _MatchTerm(torch.autograd.Function):
         ctx.fixed, ctx.S = fixed, S
         ctx.shapes = [t.shape for t in ds]
         ctx.save_for_backward(*d, *sl)
-        return out
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]            # (tensors of their own: no select backward -- a fill + a copy per term -- behind them)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g0, g1):
         import ctypes
         from . import _lib
         lib = _lib.load()
@@ -614,7 +647,12 @@ class _MatchTerm(torch.autograd.Function):
         d, sl = list(saved[:S]), list(saved[S:])
         dd, dsl = [torch.empty_like(t) for t in d], [torch.empty_like(t) for t in sl]
         arr = lambda ts: (ctypes.c_void_p * S)(*[t.data_ptr() for t in ts])          # noqa: E731
-        g = g.contiguous()
+        if g0 is not None and g1 is not None and g0.dtype == torch.float32 and g1.dtype == torch.float32 and \
+                g1.data_ptr() == g0.data_ptr() + 4:
+            g = g0                       # the halves of one buffer (_WeightedPair's backward): the kernel reads g[0], g[1] from there
+        else:
+            zero = torch.zeros((), device=center.device)
+            g = torch.stack([(zero if t is None else t).reshape(()).float() for t in (g0, g1)])
         _lib.check(lib.ls2fm_match_term_bwd(_lib.ptr(center), _lib.ptr(ray), _lib.ptr(uv_obs), _lib.ptr(poses), k_host, S, n, arr(d), arr(sl),
                                             _lib.ptr(g), arr(dd), arr(dsl), _lib.stream_ptr()), "ls2fm_match_term_bwd")
         grads = [t.view(sh) for t, sh in zip(dd + dsl, ctx.shapes)]
@@ -813,7 +851,7 @@ class InitLoop:
             terms = _MatchTerm.apply(self._match, self._surface_buf.view(-1, 3), *ds, *sls)
             ret["reproj_error"], ret["sdf_surf"] = terms[0], terms[1]
             self._surface, self._finish = self._surface_buf, torch.stack(fins)
-            return self.w_reproj * ret["reproj_error"] + self.w_surf * ret["sdf_surf"]
+            return _weighted_pair(ret["reproj_error"], ret["sdf_surf"], self.w_reproj, self.w_surf)
         errs, sdfs, surface, finish = [], [], [], []
         for v in range(2):
             center, ray = self._kp_rays[v]

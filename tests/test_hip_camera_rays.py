@@ -195,7 +195,7 @@ def test_fused_match_term_matches_the_torch_lines():
     """ls2fm_match_term_fwd / _bwd against the torch lines of InitLoop._extra they replace (Camera.py:136, 168-178 +
     Initialization.py:154-160): surface points, cross-view projection, pixel error and |sdf| means over both views, and the
     gradients w.r.t. the traced depths and the last SDF values"""
-    from ls2fm.stage import _MatchTerm, host_intrinsic
+    from ls2fm.stage import _MatchTerm, _weighted_pair, host_intrinsic
     se3, intr, H, W, g = _setup()
     poses = cam.lie.se3_to_SE3(se3[:2]).contiguous()
     gen = torch.Generator().manual_seed(23)
@@ -209,10 +209,10 @@ def test_fused_match_term_matches_the_torch_lines():
              torch.cat([kps[1], kps[0]]).contiguous(), torch.stack([poses[1], poses[0]]).contiguous(), host_intrinsic(intr), n)
     surf = torch.zeros(2, n, 3, device=DEV)
     res = {}
-    for which in ("fused", "torch"):
-        d = [t.clone().requires_grad_(True) for t in d0]
+    for which in ("fused", "pair", "torch"):          # "pair": the loop's form -- the weighted sum as ONE node (ls2fm_weighted_pair_*),
+        d = [t.clone().requires_grad_(True) for t in d0]      # whose two gradients reach the match node as the halves of one buffer
         sl = [t.clone().requires_grad_(True) for t in s0]
-        if which == "fused":
+        if which != "torch":
             terms = _MatchTerm.apply(fixed, surf.view(-1, 3), *d, *sl)
             re, ss = terms[0], terms[1]
         else:
@@ -225,10 +225,15 @@ def test_fused_match_term_matches_the_torch_lines():
                 errs.append((uv[0] - kps[o]).norm(dim=-1)); sdfs.append(sl[v].reshape(-1)); pts_all.append(pts[0].detach())
             re, ss = torch.cat(errs).mean(), torch.cat(sdfs).abs().mean()
             ref_surf = torch.stack(pts_all)
-        (0.3 * re + 2.0 * ss).backward()
-        res[which] = (re.detach(), ss.detach(), [t.grad.clone() for t in d], [t.grad.clone() for t in sl])
+        total = _weighted_pair(re, ss, 0.3, 2.0) if which == "pair" else 0.3 * re + 2.0 * ss
+        total.backward()
+        res[which] = (re.detach(), ss.detach(), [t.grad.clone() for t in d], [t.grad.clone() for t in sl], total.detach())
     f, t = res["fused"], res["torch"]
     assert abs(float(f[0]) - float(t[0])) < 1e-5 * abs(float(t[0])) and abs(float(f[1]) - float(t[1])) < 1e-5 * abs(float(t[1]))
     assert torch.allclose(surf, ref_surf, rtol=1e-6, atol=1e-6)
     for a, b in zip(f[2] + f[3], t[2] + t[3]):
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-8), float((a - b).abs().max())
+    pr = res["pair"]
+    assert abs(float(pr[4]) - float(f[4])) <= 2e-7 * abs(float(f[4]))
+    for a, b in zip(pr[2] + pr[3], f[2] + f[3]):      # same kernels, same upstream values: the same bits
+        assert torch.equal(a, b)
