@@ -231,18 +231,29 @@ def test_config2_whole_batch_vs_oracle():
     sdf.zero_grad(); rad.zero_grad()
     ret = ren.forward(opt, center, ray, sdf, rad)
     bench.loss_head(ret).backward()
-    got = _all_grads(sdf, rad)
+    _check_c2_against_oracle(sdf, rad, center, ray, ret, bench.loss_head,
+                             lambda out: bench.loss_head({k: v.double() if torch.is_tensor(v) else v for k, v in out.items()}))
 
+
+def _check_c2_against_oracle(sdf, rad, center, ray, ret, oracle_loss, oracle_loss_f64, terms=None):
+    """outputs, every parameter gradient and both table gradients of the C2 batch against the CPU oracle's render +
+    `oracle_loss`; `terms`: (product's loss terms, oracle's term function) compared too"""
+    from conftest import per_element_check
+    got = _all_grads(sdf, rad)
     cfg = OF.dataset_config("ETH3D", dual_field=True, sample_intvs=128)
     osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sdf.state_dict().items()}
     ord_ = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in rad.state_dict().items()}
     oret = OF.render(cfg, center.cpu(), ray.cpu(), osd, ord_)
-    bench.loss_head(oret).backward()
+    if terms is not None:
+        mine, term_fn = terms
+        theirs = term_fn(oret)
+        for k in ("rgb_loss", "eikonal_loss", "DC_loss", "mse", "all"):
+            assert abs(float(mine[k]) - float(theirs[k])) <= 2e-5 * max(1.0, abs(float(theirs[k]))), (k, float(mine[k]), float(theirs[k]))
+    oracle_loss(oret).backward()
     for k in ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp"):
         assert rel_err(ret[k].cpu(), oret[k]) < 2e-5, k
     exact_beta = OF.beta_gradient_exact_sum(cfg, center.cpu(), ray.cpu(), {k: v.detach() for k, v in osd.items()},
-                                            {k: v.detach() for k, v in ord_.items()},
-                                            lambda out: bench.loss_head({k: v.double() if torch.is_tensor(v) else v for k, v in out.items()}))
+                                            {k: v.detach() for k, v in ord_.items()}, oracle_loss_f64)
     n_tables = 0
     for pre, st in (("s.", osd), ("r.", ord_)):
         for k, v in st.items():
@@ -256,3 +267,42 @@ def test_config2_whole_batch_vs_oracle():
                 assert n_big > 1000, (pre + k, n_big)                # the bar is exercised on thousands of entries
                 n_tables += 1
     assert n_tables == 2
+
+
+def test_config2_timed_path_whole_batch_vs_oracle():
+    """the path `bench.py` TIMES, compared whole.  Exactly the calls of bench.py's `render_step`
+    (`Renderer.forward_with_loss` with the fused `RenderLossHead(w_rgb=3, w_eikonal=2, w_dc=0, global_counts="uniform")`, rgb target
+    0.5, traced depth 0, `loss.backward(gradient=one)`; the interleaved table copy trusted as the bench trusts it) on the benchmark's
+    own 1024-ray batch and weights: the loss TERMS against oracle/losses.py (pipelines/Camera.py:515-537) on the oracle's render,
+    every output (2e-5), every parameter gradient (1e-4; d beta against its exactly summed value) and both 12 M-entry table
+    gradients entry by entry -- the same bars as the two-call form above, none edited."""
+    import bench
+    from oracle.losses import loss_head as oracle_head
+    from ls2fm.losses import RenderLossHead
+    opt = make_options("ETH3D", device=DEV, dual_field=True, sample_intvs=128)
+    torch.manual_seed(0)
+    from ls2fm.models.SDF import SDF
+    from ls2fm.models.RadF import RadF
+    from ls2fm.models.Renderer import Renderer
+    sdf, rad, ren = SDF(opt).to(DEV), RadF(opt).to(DEV), Renderer(opt)
+    bench.randomize([sdf, rad], seed=0)
+    n_rays = 1024
+    center, ray = bench.synthetic_rays(n_rays, float(opt.data.bound_max[0]), DEV, seed=0)
+    assert fused.can_render(ren, opt, center, ray, sdf, rad)
+    fused.trust_mirror_in_capture(sdf, rad)
+    head = RenderLossHead(DEV, w_rgb=3.0, w_eikonal=2.0, w_dc=0.0, global_counts="uniform")
+    rgb_gt = torch.full((1, n_rays, 3), 0.5, device=DEV)
+    depth_ref = torch.zeros(1, n_rays, device=DEV)
+    one = torch.ones((), device=DEV)
+    for p in list(sdf.parameters()) + list(rad.parameters()):
+        p.grad = None
+    ret, L = ren.forward_with_loss(opt, center, ray, sdf, rad, head, rgb_gt, d_points=depth_ref)
+    L["all"].backward(gradient=one)
+
+    def terms(out, f64=False):
+        gt = torch.full((1, n_rays, 3), 0.5, dtype=torch.float64 if f64 else torch.float32)
+        dp = torch.zeros(1, n_rays, dtype=gt.dtype)
+        return oracle_head(out, gt, dp, None, None, None, 3.0, 2.0, 0.0)
+    _check_c2_against_oracle(sdf, rad, center, ray, ret, lambda out: terms(out)["all"],
+                             lambda out: terms({k: v.double() if torch.is_tensor(v) else v for k, v in out.items()}, True)["all"],
+                             terms=(L, terms))

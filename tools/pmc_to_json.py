@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/<tag>_pmc_traffic.json from the two PMC summaries tools/collect_profiles.sh leaves in gpurun_out/
+"""profiles/<tag>_pmc_traffic.json from the two PMC summaries tools/collect_round.sh leaves in gpurun_out/
    (tools/pmc_summary.py output of the FETCH_SIZE and the WRITE_SIZE pass):   python tools/pmc_to_json.py r02 <git hash>"""
 import json, re, sys
 
