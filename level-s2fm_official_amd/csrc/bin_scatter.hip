@@ -58,6 +58,14 @@ namespace {
 #ifndef LS2FM_FILL_PROBE
 #define LS2FM_FILL_PROBE 0
 #endif
+// Round 6: how the staged items leave the LDS.  0 = one ITEM per lane (rounds 1-5): a 32-byte item is two 16-byte stores whose lanes
+// are 32 bytes apart -- every store instruction touches 16 lines and fills half of each; a 20-byte item five dword stores 20 bytes
+// apart (10 lines, a fifth of each).  1 = FLAT: the staging area is walked in store-sized chunks, consecutive lanes write consecutive
+// 16-byte (dual) / 4-byte (single field) pieces of the sorted order, which is contiguous in memory inside a (workgroup, slab) run:
+// the same number of store instructions, each covering whole lines except at run boundaries.
+#ifndef LS2FM_FILL_FLAT
+#define LS2FM_FILL_FLAT 1
+#endif
 #ifndef LS2FM_FILL_MINW
 #define LS2FM_FILL_MINW 5
 #endif
@@ -202,7 +210,19 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         });
         __syncthreads();
         const int staged = s_total < kWin ? s_total : kWin;
+#if LS2FM_FILL_FLAT
+        {
+            static_assert(sizeof(ItemT) == 20, "five words per item");
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(s_items);
+            uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(g_items);
+            for (int c = tid; c < 5 * staged; c += kFillThreads) {
+                const int q = (int)(((uint32_t)c * 52429u) >> 18);            // c / 5 for c < 2^16 (5 * kFillCap = 5440)
+                dst[5u * s_gidx[q] + (uint32_t)(c - 5 * q)] = src[c];
+            }
+        }
+#else
         for (int q = tid; q < staged; q += kFillThreads) g_items[s_gidx[q]] = s_items[q];
+#endif
     } else {
     // every item's slot in the workgroup's sorted order
     // (named scalars, 16 bits per slot: as arrays indexed by the lambda's pair number they went to scratch memory)
@@ -233,6 +253,21 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
 #if (LS2FM_FILL_PROBE & 1)
         if (staged < 0)                    // timing probe: no item stores
 #endif
+#if LS2FM_FILL_FLAT
+        for (int c = tid; c < 2 * staged; c += kFillThreads) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const int q = c >> 1, hf = c & 1;
+            const uint32_t gi = s_gidx[q];
+            const u32x4 v = reinterpret_cast<const u32x4*>(s_items)[c];
+            u32x4* dst = reinterpret_cast<u32x4*>(&g_items[gi]) + hf;
+#if LS2FM_FILL_NT
+            __builtin_nontemporal_store(v, dst);
+#else
+            *dst = v;
+#endif
+            if (DUAL && expl && hf == 0) bm.extra[gi] = s_extra[q];
+        }
+#else
         for (int q = tid; q < staged; q += kFillThreads) {
             const uint32_t gi = s_gidx[q];
 #if LS2FM_FILL_NT
@@ -255,6 +290,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
             g_items[gi] = s_items[q];
             if (DUAL && expl) bm.extra[gi] = s_extra[q];
         }
+#endif
     };
     if (!expl) {
         // ---- factored dual items

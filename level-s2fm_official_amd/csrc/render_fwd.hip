@@ -285,6 +285,11 @@ struct EncodeExtras {
     int n_explicit;           // dual field: leading levels whose scatter items are explicit and run-merged (bin_items.h)
     int n_prep_tasks;         // 3: both MLPs + the radiance chain (render); 1: the SDF MLP only (point queries)
     const float* pts;         // [n,3] free points instead of ray samples (point queries), or null
+    int probe;                // LS2FM_ENC_PROBE (measurements, round 6): 1 = walking order NOT pinned to XCDs (every XCD walks every
+                              // level over its eighth of the chunks: what a gather fused into the per-ray shading kernel would see;
+                              // same results); 2 = timing probe, WRONG results: a hashed level's corner loads restricted to one HALF
+                              // of its slice by entry index, lower half during the first half of an XCD's chunks of the level, upper
+                              // half during the second (one of the two passes an entry-range split between XCDs would make)
 };
 
 constexpr int kEncThreads = 512;             // sample points of one level per workgroup = kEncRows tiles of the scatter's counting sort
@@ -336,8 +341,13 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     }
     const int bx = (int)blockIdx.x - kEncReserved;
     const int xcd = bx & 7, j = bx >> 3;
-    const int unit = plan.start[xcd] + j;
-    if (unit >= plan.start[xcd + 1]) return;
+    int unit = plan.start[xcd] + j;
+    if (ex.probe == 1) {                                 // (measurement) chunk-major: XCD x walks chunks x, x + 8, .. of EVERY pass-level
+        const int n_pl = plan.start[8] / n_chunks;
+        const int ck = (j / n_pl) * 8 + xcd;
+        if (ck >= n_chunks) return;
+        unit = (j % n_pl) * n_chunks + ck;
+    } else if (unit >= plan.start[xcd + 1]) return;
     const int pl = unit / n_chunks;                      // pass-level; two grids: (level 0, grid 1), (level 0, grid 2), (level 1, ..
     const int chunk = unit % n_chunks;
     const bool two = !INTERLEAVED && table2 != nullptr;
@@ -367,6 +377,12 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
         if (INTERLEAVED) {
             const float4* __restrict__ table = reinterpret_cast<const float4*>(table1);
             float4 v[8];
+            if (ex.probe == 2 && lv.hashed) {            // (timing probe: wrong results) only the corners in one half of the slice
+                const uint32_t want = 2 * chunk >= n_chunks ? 1u : 0u, hb = lv.size >> 1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((((c.idx[k] - lv.offset) >= hb) ? 1u : 0u) != want) c.idx[k] = lv.offset + want * hb;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = table[c.idx[k]];
             float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
@@ -605,6 +621,7 @@ int ls2fm_launch_points_encode(const ls2fm_field_desc* field, const ls2fm_grid_d
     ex.n_explicit = 0;
     ex.n_prep_tasks = 1;
     ex.pts = pts;
+    ex.probe = 0;
     ray_encode_kernel<false><<<(unsigned)(kEncReserved + 8 * most), kEncThreads, 0, s>>>(
         make_level_set(grid), make_level_set(grid), fc, nullptr, nullptr, params->sdf_table, nullptr, w.p, w.p_pad, n_chunks, plan,
         ws + w.e1, nullptr, ws + w.j1, ex);
@@ -652,6 +669,9 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ex.tile_counts = nullptr; ex.scan_ticket = nullptr; ex.n_tiles = 0; ex.sshift = ls2fm_slab_shift(dual);
     ex.n_explicit = ls2fm_explicit_levels(sdf_grid, dual, field->n_samples);
     ex.n_prep_tasks = 3; ex.pts = nullptr;
+    static const int enc_probe = [] { const char* e = getenv("LS2FM_ENC_PROBE"); return e ? atoi(e) : 0; }();
+    ex.probe = enc_probe;
+    if (enc_probe == 1) most = (n_chunks + 7) / 8 * (L1 + (pair ? L2 : 0));
     if (prepare_bwd) {
         const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
         ex.tile_counts = bm.tile;

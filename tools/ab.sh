@@ -8,7 +8,7 @@ ARGS=$1; N=$2; shift; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
 for i in $(seq $N); do
   for v in "$@"; do
-    set -- $v; LIB=""; ENVS=""
+    LIB=""; ENVS=""
     for w in $v; do case $w in cur) ;; *.so) LIB=$ROOT/$w ;; *) ENVS="$ENVS $w" ;; esac; done
     env ${LIB:+LS2FM_LIB=$LIB} $ENVS python bench.py --no-cpu-baseline --steps 300 --warmup 30 $ARGS 2>/dev/null | tail -1 | python -c "
 import sys,json
