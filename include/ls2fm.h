@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LS2FM_ABI_VERSION 8
+#define LS2FM_ABI_VERSION 9
 #define LS2FM_MAX_LEVELS 16
 #define LS2FM_HIDDEN 64        /* SDF.arch.layers = [null, 64, 16]  (options/LevelS2fM.yaml:14) */
 #define LS2FM_FEAT 16
@@ -40,7 +40,8 @@ typedef enum ls2fm_status {
     LS2FM_ERR_INVALID_ARGUMENT = -1,
     LS2FM_ERR_UNSUPPORTED = -2,
     LS2FM_ERR_LAUNCH = -3,
-    LS2FM_ERR_WORKSPACE = -4
+    LS2FM_ERR_WORKSPACE = -4,
+    LS2FM_ERR_STARVED = -5     /* an EARLIER asynchronous call reported a starved in-launch hand-off (ls2fm_async_error) */
 } ls2fm_status;
 
 /* Geometry of one multiresolution hash grid (tcnn Grid/Hash/Linear, n_features_per_level = 2).
@@ -110,6 +111,13 @@ typedef struct ls2fm_param_grads {      /* mirrors ls2fm_params */
 
 int ls2fm_abi_version(void);
 const char* ls2fm_status_string(int status);
+/* Sticky error word of the ASYNCHRONOUS part of earlier calls (0 = none).  The render backward hands partial sums between
+ * workgroups of ONE launch (weight-gradient reduction rows / finalize tasks behind their producers); consumers poll with a bound, and
+ * one that gives up (producers starved of execution slots: a device cut down by a CU mask, a foreign kernel that never ends) poisons
+ * its outputs with NaN AND sets this word (1) in host-visible memory -- no synchronisation is needed to read it, and every later
+ * ls2fm_render_bwd returns LS2FM_ERR_STARVED until it is cleared.  clear != 0: reset after reading.  No reference counterpart
+ * (autograd's kernels have no in-launch hand-offs). */
+int ls2fm_async_error(int clear);
 
 /* ---------------------------------------------------------------------------------------------
  * Ray / AABB slab test.

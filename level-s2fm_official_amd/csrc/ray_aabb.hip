@@ -61,6 +61,7 @@ extern "C" const char* ls2fm_status_string(int status) {
         case LS2FM_ERR_UNSUPPORTED: return "unsupported configuration";
         case LS2FM_ERR_LAUNCH: return "HIP launch / runtime error";
         case LS2FM_ERR_WORKSPACE: return "workspace missing or too small";
+        case LS2FM_ERR_STARVED: return "an earlier call's in-launch hand-off was starved (ls2fm_async_error); its gradients are poisoned";
         default: return "unknown status";
     }
 }

@@ -30,7 +30,7 @@ finalize_kernel(FinalizeArgs fa) {
 // CU: 21 KB of LDS), the reducers are dispatched first and wait for nothing, so the waiters cannot starve them; the wait is
 // bounded anyway.  The ticket lives in the slack of the reduced-gradient block, which shade_bwd's leading workgroups zero.
 __global__ void __launch_bounds__(256)
-wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_red, int* __restrict__ ticket) {
+wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_red, int* __restrict__ ticket, int* __restrict__ err) {
     const int bid = (int)blockIdx.x;
     if (bid < n_red) {
         reduce_partials_row(wp, wg, bid);
@@ -51,6 +51,7 @@ wgrad_tail_kernel(WgradParts wp, float* __restrict__ wg, FinalizeArgs fa, int n_
     finalize_task(fa, task);                                     // reads the reduced block with L2-bypassing loads (wg_load)
     // The wait is bounded (HIP promises no dispatch order inside a launch): if the reducers were starved past the bound, this
     // task consumed incomplete sums -- poison its outputs so that the step fails loudly (NaN loss / gradient) instead of quietly
+    if (s_starved && threadIdx.x == 0 && err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (ls2fm_async_error)
     if (s_starved && threadIdx.x == 0 && (task < 2 || task >= 4 || fa.dual)) {
         const float nan = __builtin_nanf("");
         float* b = task < 2 ? fa.G.sdf_mlp[task].bias : (task < 4 ? fa.G.geo_mlp[task - 2].bias : fa.G.rad_mlp[task - 4].bias);
@@ -118,6 +119,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     LS2FM_CHECK_ARG(center && ray && grads->sdf_table && grads->beta && (!field->dual_field || grads->rad_table));
     if (!workspace) return LS2FM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    // an earlier backward's in-launch hand-off gave up (its gradients are poisoned): reported here, sticky until cleared
+    int* const err_word = ls2fm_async_error_word(s);
+    if (err_word && *static_cast<volatile int*>(err_word) != 0) return LS2FM_ERR_STARVED;
     const int dual = field->dual_field ? 1 : 0;
     const int L1 = sdf_grid->n_levels, L2 = dual ? rad_grid->n_levels : 0;
     const WsLayout w = make_ws_layout(n_rays, field->n_samples, L1, dual ? L2 : L1, dual);
@@ -221,7 +225,11 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // (only where the fill is long enough to hide the jobs' ~45 us chain of hand-offs: >= 32 k sample points; and while the level-1
     // sums -- 39 KB of per-ray partials per ray -- stay small beside the fill's own traffic: C5, 4096 rays x 256: 2.002 -> 1.984 ms;
     // C3, 8192 rays x 128: 3.074 -> 3.100)
-    const bool side_in_fill = side_in_fill_env && fused_wgrad && !db && !probe_no_side && w.p >= 32768 && n_rays <= 4096;
+    // (and only on a device with an order of magnitude more workgroup slots than the launch has WAITING workgroups -- the reduction
+    // rows and finalize tasks, ~180: side_jobs.h -- so that the producers they poll can never be kept off the chip by them)
+    const int n_waiters = kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec + kFinalizeTasks;
+    const bool side_in_fill = side_in_fill_env && fused_wgrad && !db && !probe_no_side && w.p >= 32768 && n_rays <= 4096 &&
+                              ls2fm_device_cus() >= n_waiters;      // (>= 4 workgroups of this launch fit a CU: 4x the slots)
     SideJobs sj{};
     if (side_in_fill) {
         const WgPartLayout pl = make_wg_part_layout(dual, n_rays, field->n_samples);
@@ -239,6 +247,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         sj.flags = reinterpret_cast<int*>(ws + w.wg + kWgFlagsAt);                  // (zeroed by shade_bwd's leading workgroups)
         static const int side_probe = [] { const char* e = getenv("LS2FM_SIDE_PROBE"); return e ? atoi(e) : 0; }();
         sj.probe = side_probe;
+        sj.err = err_word;
     }
     forked = !probe_no_side && !side_in_fill && ls2fm_side_stream(&sc, s) && hipEventRecord(sc.fork, s) == hipSuccess && hipStreamWaitEvent(sc.side, sc.fork, 0) == hipSuccess;
     hipStream_t gs = forked ? sc.side : s;
@@ -257,7 +266,7 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         const int n_red = kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec;
         const FinalizeArgs fa{*params, *grads, 3 + 2 * L1, 3 + 2 * L2, rad_in, dual, pk, ws + w.wg, ws + w.dbeta, n_rays, 0};
         wgrad_tail_kernel<<<n_red + kFinalizeTasks, 256, 0, gs>>>(parts, ws + w.wg, fa, n_red,
-                                                                 reinterpret_cast<int*>(ws + w.wg + WgLayout::total));
+                                                                 reinterpret_cast<int*>(ws + w.wg + WgLayout::total), err_word);
     }
     ls2fm_prof_end(LS2FM_PROF_FINALIZE, gs);
     if (forked && hipEventRecord(sc.join, sc.side) != hipSuccess) return fail(forked, sc, LS2FM_ERR_LAUNCH);

@@ -24,6 +24,10 @@ void ls2fm_prof_end(int id, hipStream_t stream);
 struct SideCtx { hipStream_t side; hipEvent_t fork, mid, join; };
 bool ls2fm_side_stream(SideCtx* out, hipStream_t caller);       // side stream + events of this caller stream
 int ls2fm_join_on_error(bool forked, const SideCtx& sc, hipStream_t caller, int status);
+// host-visible sticky error word of the asynchronous parts (ls2fm_async_error): device-writable pinned host memory, allocated at
+// the first call outside a stream capture; null until then (kernels skip a null word)
+int* ls2fm_async_error_word(hipStream_t stream);
+int ls2fm_device_cus();
 
 constexpr int kHidden = LS2FM_HIDDEN;     // 64
 constexpr int kOut = LS2FM_FEAT + 1;      // 17: sdf + 16 features

@@ -40,6 +40,18 @@ constexpr bool kProbeNoPos = (LS2FM_PROBE & 8) != 0, kProbeStage1 = (LS2FM_PROBE
 constexpr int kTLd = 20;       // floats per row of the wave-private transpose tile: 16 samples + 4 pad (16-B aligned rows)
 constexpr int kTRows = 48;     // da | gj | h of one hidden block (U / V: 36 rows, GF: 20)
 constexpr int kSwWg = kMfmaBwdSdfFloats - 4 * 4 * 64 + 64;       // WG: W1[0] as 64 floats instead of its operand-ordered 4 KB
+// Round 6: the fused-weight-gradient form with MORE tiles in flight per wave and FEWER waves per SIMD -- the
+// unified register file gives a wave 512 registers (256 + 256 accumulation registers) at one wave per SIMD.  LS2FM_BWD_NC_WG = 16-sample
+// tiles a wave works on side by side (1, 2 or 4: every weight operand read from LDS then feeds that many independent MFMA chains),
+// LS2FM_BWD_WAVES_WG = the occupancy the register budget is cut for.  The tiles are contracted into the weight-gradient accumulators
+// in tile order whatever NC is: results are bit-identical across the variants.
+#ifndef LS2FM_BWD_NC_WG
+#define LS2FM_BWD_NC_WG 1
+#endif
+#ifndef LS2FM_BWD_WAVES_WG
+#define LS2FM_BWD_WAVES_WG 2
+#endif
+template <bool WG> constexpr int bwd_nc() { return WG ? LS2FM_BWD_NC_WG : (kProbeNC1 ? 1 : 2); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 // the scatter's records: written once here, read once by scatter_fill (any XCD) -- optionally non-temporal (LS2FM_REC_NT)
@@ -193,13 +205,13 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
 // of 2 waves per CU.  (A workgroup walking several rays and keeping one partial was tried first: the loop-invariant kernel
 // arguments it keeps in scalar registers across the loop spill into vector registers -- 92 .. 136 B of scratch per lane.)
 template <bool DUAL, int MAXT, bool POSE, bool WG>
-__global__ void __launch_bounds__(MAXT, 2)
+__global__ void __launch_bounds__(MAXT, WG ? LS2FM_BWD_WAVES_WG : 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
                  Upstream up, float* __restrict__ out, ZeroJob zero, int64_t n_rays, float* __restrict__ slot_sdf,
                  float* __restrict__ slot_geo) {
     constexpr bool want_pose = POSE;
-    constexpr int NC = (WG || kProbeNC1) ? 1 : 2;               // 16-sample column tiles in flight per wave (a wave owns four)
+    constexpr int NC = bwd_nc<WG>();                            // 16-sample column tiles in flight per wave (a wave owns four)
     constexpr int kUnrollM = WG ? 4 : 1;         // the accumulators of a hidden block are registers: its loop is unrolled
     // leading workgroups: the zero fills the rest of the backward needs (weight-gradient accumulators, point-split coarse
     // levels of the gradient tables) -- no memset / kernel launches and no cross-stream edge in front of the scatter
@@ -216,7 +228,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     __shared__ float s_w[WG ? kSwWg : kMfmaBwdSdfFloats];     // MFMA-ordered weights of the field being processed (26 KB; WG:
                                                  // 22 KB, W1[0] compact); WG: also the buffer of the cross-wave sum of the
                                                  // weight-gradient registers
-    __shared__ __attribute__((aligned(16))) float s_t[WG ? MAXT / 64 : 1][WG ? kTRows * kTLd : 4];   // wave-private transpose tiles
+    __shared__ __attribute__((aligned(16))) float s_t[WG ? MAXT / 64 : 1][WG ? NC * kTRows * kTLd : 4];   // wave-private transpose tiles
     static_assert(kRegsSdf * 64 <= kSwWg && kRegsGeo * 64 <= kSwWg && kMfmaBwdGeoFloats <= kSwWg, "register sums / second field's weights fit in s_w");
     const int N = fc.n_samples;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
@@ -579,29 +591,38 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
 
         // (WG) U, V, GF of this tile as operands of the contraction over the samples: row jl (+ 16 mk), samples 4g .. 4g + 3.
         // A wave's DS operations execute in order: a tile's rows are rewritten right behind the reads of the previous rows.
-        float4 b_u[3], b_v[3], a_gf;
-        if (WG && kProbeNoTrans) { b_u[0] = b_u[1] = b_u[2] = b_v[0] = b_v[1] = b_v[2] = a_gf = make_float4(1.f, 2.f, 3.f, 4.f); }
+        float4 b_u[NC][3], b_v[NC][3], a_gf[NC];
+        if (WG && kProbeNoTrans) {
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) b_u[cc][0] = b_u[cc][1] = b_u[cc][2] = b_v[cc][0] = b_v[cc][1] = b_v[cc][2] = a_gf[cc] = make_float4(1.f, 2.f, 3.f, 4.f);
+        }
         if (WG && !kProbeNoTrans) {
             const int row2 = jl < 4 ? 32 + jl : 35;                  // rows 32..35 exist: lanes jl < 4 are the ones pos_col reads
 #pragma unroll
-            for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = ub[t][0];
-            __builtin_amdgcn_wave_barrier();
-            b_u[0] = ld4(xt + jl * kTLd + 4 * g); b_u[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_u[2] = ld4(xt + row2 * kTLd + 4 * g);
-            __builtin_amdgcn_wave_barrier();
+            for (int cc = 0; cc < NC; ++cc) {                        // (tile cc's own block of the wave's LDS area)
+                float* __restrict__ xc = xt + cc * (kTRows * kTLd);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = vb[t][0];
-            __builtin_amdgcn_wave_barrier();
-            b_v[0] = ld4(xt + jl * kTLd + 4 * g); b_v[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_v[2] = ld4(xt + row2 * kTLd + 4 * g);
-            __builtin_amdgcn_wave_barrier();
+                for (int t = 0; t < 9; ++t) xc[(4 * t + g) * kTLd + jl] = ub[t][cc];
+                __builtin_amdgcn_wave_barrier();
+                b_u[cc][0] = ld4(xc + jl * kTLd + 4 * g); b_u[cc][1] = ld4(xc + (16 + jl) * kTLd + 4 * g); b_u[cc][2] = ld4(xc + row2 * kTLd + 4 * g);
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < 5; ++t) xt[(4 * t + g) * kTLd + jl] = gfb[t][0];
-            __builtin_amdgcn_wave_barrier();
-            a_gf = ld4(xt + (1 + jl) * kTLd + 4 * g);
-            __builtin_amdgcn_wave_barrier();
-            gs16 += (a_gf.x + a_gf.y) + (a_gf.z + a_gf.w);           // db1[1 + jl], this group's four samples
-            g0s += fc.kappa * gsdf[0];                               // db1[0]
+                for (int t = 0; t < 9; ++t) xc[(4 * t + g) * kTLd + jl] = vb[t][cc];
+                __builtin_amdgcn_wave_barrier();
+                b_v[cc][0] = ld4(xc + jl * kTLd + 4 * g); b_v[cc][1] = ld4(xc + (16 + jl) * kTLd + 4 * g); b_v[cc][2] = ld4(xc + row2 * kTLd + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 5; ++t) xc[(4 * t + g) * kTLd + jl] = gfb[t][cc];
+                __builtin_amdgcn_wave_barrier();
+                a_gf[cc] = ld4(xc + (1 + jl) * kTLd + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+                gs16 += (a_gf[cc].x + a_gf[cc].y) + (a_gf[cc].z + a_gf[cc].w);      // db1[1 + jl], this group's four samples
+                g0s += fc.kappa * gsdf[cc];                                          // db1[0]
+            }
         }
-        const float gf0 = WG ? fc.kappa * gsdf[0] : 0.f;
+        float gf0[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) gf0[cc] = WG ? fc.kappa * gsdf[cc] : 0.f;
         // ---- SDF field
         f32x4 de[2][NC], rr[2][NC];
 #pragma unroll
@@ -642,12 +663,13 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                     da[cc][q] = fmaf(s1, tt[cc][q], s2 * w10 * qq[cc][q]);
                     gj[cc][q] = s1 * w10;
                     if (WG && !kProbeNoTrans) {       // this hidden block's DA | GJ | H, [hidden unit 4g + q][sample jl]
-                        xt[(4 * g + q) * kTLd + jl] = da[cc][q];
-                        xt[(16 + 4 * g + q) * kTLd + jl] = gj[cc][q];
-                        xt[(32 + 4 * g + q) * kTLd + jl] = h;
+                        float* __restrict__ xc = xt + cc * (kTRows * kTLd);
+                        xc[(4 * g + q) * kTLd + jl] = da[cc][q];
+                        xc[(16 + 4 * g + q) * kTLd + jl] = gj[cc][q];
+                        xc[(32 + 4 * g + q) * kTLd + jl] = h;
                         // dW1[0][16m + 4g + q] += sum over the tile's samples of gf0 H + S1 . Q: a row sum, packed one per lane
                         // (sixteen per-lane accumulators instead: spills; the summands through the LDS tile as a fourth block: +7 us)
-                        const float rs = row_sum16(fmaf(gf0, h, s1 * qq[cc][q]));
+                        const float rs = row_sum16(fmaf(gf0[cc], h, s1 * qq[cc][q]));
                         w1p += jl == 4 * m + q ? rs : 0.f;
                     }
                 }
@@ -675,23 +697,34 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 // contraction over the tile's 16 samples: the lane supplies row jl, samples 4g .. 4g + 3 of every operand (the
                 // tile's trip through LDS was in flight during the DE / RR products above)
                 __builtin_amdgcn_wave_barrier();
-                const float4 a_da = ld4(xt + jl * kTLd + 4 * g), a_gj = ld4(xt + (16 + jl) * kTLd + 4 * g), b_h = ld4(xt + (32 + jl) * kTLd + 4 * g);
+                float4 a_da[NC], a_gj[NC], b_h[NC];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    const float* __restrict__ xc = xt + cc * (kTRows * kTLd);
+                    a_da[cc] = ld4(xc + jl * kTLd + 4 * g); a_gj[cc] = ld4(xc + (16 + jl) * kTLd + 4 * g); b_h[cc] = ld4(xc + (32 + jl) * kTLd + 4 * g);
+                }
                 __builtin_amdgcn_wave_barrier();
                 f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c3 = acc1[m];
-                c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c3 = mfma4(a_gf.x, b_h.x, c3);
-                c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c3 = mfma4(a_gf.y, b_h.y, c3);
-                c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c3 = mfma4(a_gf.z, b_h.z, c3);
-                c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c3 = mfma4(a_gf.w, b_h.w, c3);
-                c0 = mfma4(a_gj.x, b_v[0].x, c0); c1 = mfma4(a_gj.x, b_v[1].x, c1);
-                c0 = mfma4(a_gj.y, b_v[0].y, c0); c1 = mfma4(a_gj.y, b_v[1].y, c1);
-                c0 = mfma4(a_gj.z, b_v[0].z, c0); c1 = mfma4(a_gj.z, b_v[1].z, c1);
-                c0 = mfma4(a_gj.w, b_v[0].w, c0); c1 = mfma4(a_gj.w, b_v[1].w, c1);
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {        // tile by tile, in tile order: the sums are those of NC = 1
+                    c0 = mfma4(a_da[cc].x, b_u[cc][0].x, c0); c1 = mfma4(a_da[cc].x, b_u[cc][1].x, c1); c3 = mfma4(a_gf[cc].x, b_h[cc].x, c3);
+                    c0 = mfma4(a_da[cc].y, b_u[cc][0].y, c0); c1 = mfma4(a_da[cc].y, b_u[cc][1].y, c1); c3 = mfma4(a_gf[cc].y, b_h[cc].y, c3);
+                    c0 = mfma4(a_da[cc].z, b_u[cc][0].z, c0); c1 = mfma4(a_da[cc].z, b_u[cc][1].z, c1); c3 = mfma4(a_gf[cc].z, b_h[cc].z, c3);
+                    c0 = mfma4(a_da[cc].w, b_u[cc][0].w, c0); c1 = mfma4(a_da[cc].w, b_u[cc][1].w, c1); c3 = mfma4(a_gf[cc].w, b_h[cc].w, c3);
+                    c0 = mfma4(a_gj[cc].x, b_v[cc][0].x, c0); c1 = mfma4(a_gj[cc].x, b_v[cc][1].x, c1);
+                    c0 = mfma4(a_gj[cc].y, b_v[cc][0].y, c0); c1 = mfma4(a_gj[cc].y, b_v[cc][1].y, c1);
+                    c0 = mfma4(a_gj[cc].z, b_v[cc][0].z, c0); c1 = mfma4(a_gj[cc].z, b_v[cc][1].z, c1);
+                    c0 = mfma4(a_gj[cc].w, b_v[cc][0].w, c0); c1 = mfma4(a_gj[cc].w, b_v[cc][1].w, c1);
+                }
                 acc0[m][0] = c0; acc0[m][1] = c1; acc1[m] = c3;
                 if (!kProbeNoPos) {
-                pacc[m][0] = pos_col<0, true>(pacc[m][0], a_da, a_gj, b_u[2], b_v[2]);
-                pacc[m][1] = pos_col<1, true>(pacc[m][1], a_da, a_gj, b_u[2], b_v[2]);
-                pacc[m][2] = pos_col<2, true>(pacc[m][2], a_da, a_gj, b_u[2], b_v[2]);
-                pacc[m][3] = pos_col<3, false>(pacc[m][3], a_da, a_gj, b_u[2], b_v[2]);       // (V has no bias row)
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                pacc[m][0] = pos_col<0, true>(pacc[m][0], a_da[cc], a_gj[cc], b_u[cc][2], b_v[cc][2]);
+                pacc[m][1] = pos_col<1, true>(pacc[m][1], a_da[cc], a_gj[cc], b_u[cc][2], b_v[cc][2]);
+                pacc[m][2] = pos_col<2, true>(pacc[m][2], a_da[cc], a_gj[cc], b_u[cc][2], b_v[cc][2]);
+                pacc[m][3] = pos_col<3, false>(pacc[m][3], a_da[cc], a_gj[cc], b_u[cc][2], b_v[cc][2]);       // (V has no bias row)
+                }
                 }
                 __builtin_amdgcn_sched_barrier(0);       // (the unrolled hidden blocks are not interleaved: their temporaries would add up)
             }
@@ -745,21 +778,28 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 }
                 if (!WG && live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
             }
-            float4 b_u[3], a_gf;
-            if (WG && kProbeNoTrans) { b_u[0] = b_u[1] = b_u[2] = a_gf = make_float4(1.f, 2.f, 3.f, 4.f); }
+            float4 b_u[NC][3], a_gf[NC];
+            if (WG && kProbeNoTrans) {
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) b_u[cc][0] = b_u[cc][1] = b_u[cc][2] = a_gf[cc] = make_float4(1.f, 2.f, 3.f, 4.f);
+            }
             if (WG && !kProbeNoTrans) {
                 const int row2 = jl < 4 ? 32 + jl : 35;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) xt[(4 * t + g) * kTLd + jl] = ub[t][0];
-                __builtin_amdgcn_wave_barrier();
-                b_u[0] = ld4(xt + jl * kTLd + 4 * g); b_u[1] = ld4(xt + (16 + jl) * kTLd + 4 * g); b_u[2] = ld4(xt + row2 * kTLd + 4 * g);
-                __builtin_amdgcn_wave_barrier();
+                for (int cc = 0; cc < NC; ++cc) {
+                    float* __restrict__ xc = xt + cc * (kTRows * kTLd);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xt[(4 * t + g) * kTLd + jl] = gf2b[t][0];
-                __builtin_amdgcn_wave_barrier();
-                a_gf = ld4(xt + jl * kTLd + 4 * g);
-                __builtin_amdgcn_wave_barrier();
-                gs16 += (a_gf.x + a_gf.y) + (a_gf.z + a_gf.w);
+                    for (int t = 0; t < 9; ++t) xc[(4 * t + g) * kTLd + jl] = ub[t][cc];
+                    __builtin_amdgcn_wave_barrier();
+                    b_u[cc][0] = ld4(xc + jl * kTLd + 4 * g); b_u[cc][1] = ld4(xc + (16 + jl) * kTLd + 4 * g); b_u[cc][2] = ld4(xc + row2 * kTLd + 4 * g);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xc[(4 * t + g) * kTLd + jl] = gf2b[t][cc];
+                    __builtin_amdgcn_wave_barrier();
+                    a_gf[cc] = ld4(xc + jl * kTLd + 4 * g);
+                    __builtin_amdgcn_wave_barrier();
+                    gs16 += (a_gf[cc].x + a_gf[cc].y) + (a_gf[cc].z + a_gf[cc].w);
+                }
             }
             f32x4 de2[2][NC];
 #pragma unroll
@@ -794,8 +834,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                         softplus100(aa[cc][q], h, s1, s2);
                         da[cc][q] = s1 * tt[cc][q];
                         if (WG && !kProbeNoTrans) {
-                            xt[(4 * g + q) * kTLd + jl] = da[cc][q];
-                            xt[(32 + 4 * g + q) * kTLd + jl] = h;
+                            float* __restrict__ xc = xt + cc * (kTRows * kTLd);
+                            xc[(4 * g + q) * kTLd + jl] = da[cc][q];
+                            xc[(32 + 4 * g + q) * kTLd + jl] = h;
                         }
                     }
                 }
@@ -817,19 +858,30 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 }
                 if (WG && !kProbeNoContract) {
                     __builtin_amdgcn_wave_barrier();
-                    const float4 a_da = ld4(xt + jl * kTLd + 4 * g), b_h = ld4(xt + (32 + jl) * kTLd + 4 * g);
+                    float4 a_da[NC], b_h[NC];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        const float* __restrict__ xc = xt + cc * (kTRows * kTLd);
+                        a_da[cc] = ld4(xc + jl * kTLd + 4 * g); b_h[cc] = ld4(xc + (32 + jl) * kTLd + 4 * g);
+                    }
                     __builtin_amdgcn_wave_barrier();
                     f32x4 c0 = acc0[m][0], c1 = acc0[m][1], c3 = acc1[m];
-                    c0 = mfma4(a_da.x, b_u[0].x, c0); c1 = mfma4(a_da.x, b_u[1].x, c1); c3 = mfma4(a_gf.x, b_h.x, c3);
-                    c0 = mfma4(a_da.y, b_u[0].y, c0); c1 = mfma4(a_da.y, b_u[1].y, c1); c3 = mfma4(a_gf.y, b_h.y, c3);
-                    c0 = mfma4(a_da.z, b_u[0].z, c0); c1 = mfma4(a_da.z, b_u[1].z, c1); c3 = mfma4(a_gf.z, b_h.z, c3);
-                    c0 = mfma4(a_da.w, b_u[0].w, c0); c1 = mfma4(a_da.w, b_u[1].w, c1); c3 = mfma4(a_gf.w, b_h.w, c3);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        c0 = mfma4(a_da[cc].x, b_u[cc][0].x, c0); c1 = mfma4(a_da[cc].x, b_u[cc][1].x, c1); c3 = mfma4(a_gf[cc].x, b_h[cc].x, c3);
+                        c0 = mfma4(a_da[cc].y, b_u[cc][0].y, c0); c1 = mfma4(a_da[cc].y, b_u[cc][1].y, c1); c3 = mfma4(a_gf[cc].y, b_h[cc].y, c3);
+                        c0 = mfma4(a_da[cc].z, b_u[cc][0].z, c0); c1 = mfma4(a_da[cc].z, b_u[cc][1].z, c1); c3 = mfma4(a_gf[cc].z, b_h[cc].z, c3);
+                        c0 = mfma4(a_da[cc].w, b_u[cc][0].w, c0); c1 = mfma4(a_da[cc].w, b_u[cc][1].w, c1); c3 = mfma4(a_gf[cc].w, b_h[cc].w, c3);
+                    }
                     acc0[m][0] = c0; acc0[m][1] = c1; acc1[m] = c3;
                     if (!kProbeNoPos) {
-                    pacc[m][0] = pos_col<0, false>(pacc[m][0], a_da, a_da, b_u[2], b_u[2]);
-                    pacc[m][1] = pos_col<1, false>(pacc[m][1], a_da, a_da, b_u[2], b_u[2]);
-                    pacc[m][2] = pos_col<2, false>(pacc[m][2], a_da, a_da, b_u[2], b_u[2]);
-                    pacc[m][3] = pos_col<3, false>(pacc[m][3], a_da, a_da, b_u[2], b_u[2]);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                    pacc[m][0] = pos_col<0, false>(pacc[m][0], a_da[cc], a_da[cc], b_u[cc][2], b_u[cc][2]);
+                    pacc[m][1] = pos_col<1, false>(pacc[m][1], a_da[cc], a_da[cc], b_u[cc][2], b_u[cc][2]);
+                    pacc[m][2] = pos_col<2, false>(pacc[m][2], a_da[cc], a_da[cc], b_u[cc][2], b_u[cc][2]);
+                    pacc[m][3] = pos_col<3, false>(pacc[m][3], a_da[cc], a_da[cc], b_u[cc][2], b_u[cc][2]);
+                    }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

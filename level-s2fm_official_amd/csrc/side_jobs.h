@@ -176,6 +176,7 @@ struct SideJobs {
     FinalizeArgs fa;
     int* flags;               // one word per job, zeroed by shade_bwd's zero job: [dec blocks | level-1 jobs | reduction rows]
     int probe;                // timing probe (wrong results): 1 no finalize tasks, 2 no reduction rows either, 4 no decoder tiles
+    int* err;                 // host-visible sticky error word (ls2fm_async_error) or null
 };
 
 // decoder blocks of the in-fill form: a block's four waves walk (tiles / blocks / 4) tiles two at a time, one memory round trip per
@@ -244,8 +245,14 @@ __device__ __forceinline__ void side_job_run(const SideJobs& sj, int job, float*
         if (sj.probe & 3) return;
         const bool ok = side_wait(f_red, sj.n_red, 1, s_flag);
         finalize_task_a(sj.fa, job, arena);
-        // bounded waits (HIP promises no dispatch order inside a launch): past the bound this task consumed incomplete sums -- poison
-        // its outputs so that the step fails loudly (NaN gradient) instead of quietly
+        // Bounded waits.  HIP promises no dispatch order inside a launch, so the protocol must not need one: the only workgroups of
+        // this launch that ever wait are the n_red + kFinalizeTasks (~180) consumers; every other workgroup -- the producers and the
+        // fill's own ~8 k -- runs to completion whatever is resident beside it.  Starvation therefore needs the device to offer no
+        // more than ~180 workgroup slots to this launch (the launcher requires an order of magnitude more: render_bwd.hip), e.g. under
+        // a CU mask or beside a foreign kernel that never ends.  Past the bound this task consumed incomplete sums: it poisons its
+        // outputs (NaN gradient) AND sets the host-visible sticky error word, which the next ls2fm_render_bwd reports
+        // (LS2FM_ERR_STARVED) -- loudly, not as one odd element.
+        if (!ok && threadIdx.x == 0 && sj.err) __hip_atomic_store(sj.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!ok && threadIdx.x == 0 && (job < 2 || job >= 4 || sj.fa.dual)) {
             const float nan = __builtin_nanf("");
             float* b = job < 2 ? sj.fa.G.sdf_mlp[job].bias : (job < 4 ? sj.fa.G.geo_mlp[job - 2].bias : sj.fa.G.rad_mlp[job - 4].bias);

@@ -6,6 +6,7 @@
 // streams) get different side streams and events, so they cannot order against each other's forks; concurrent calls on the
 // SAME stream from two threads are as undefined as any other concurrent use of one stream.
 // LS2FM_SERIAL=1 disables the fork, and so does the opt-in per-kernel profiler (overlapped kernels would time each other).
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -58,6 +59,39 @@ bool ls2fm_side_stream(SideCtx* out, hipStream_t caller) {
     }
     out->side = it->second.side; out->fork = it->second.fork; out->mid = it->second.mid; out->join = it->second.join;
     return true;
+}
+
+namespace {
+std::atomic<int*> g_err_word{nullptr};
+}
+int* ls2fm_async_error_word(hipStream_t stream) {
+    int* w = g_err_word.load(std::memory_order_acquire);
+    if (w) return w;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // (no allocation inside a capture)
+    std::lock_guard<std::mutex> lock(g_mu);
+    w = g_err_word.load(std::memory_order_acquire);
+    if (w) return w;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *static_cast<volatile int*>(p) = 0;
+    g_err_word.store(static_cast<int*>(p), std::memory_order_release);
+    return static_cast<int*>(p);
+}
+extern "C" int ls2fm_async_error(int clear) {
+    int* w = g_err_word.load(std::memory_order_acquire);
+    if (!w) return 0;
+    const int v = *static_cast<volatile int*>(w);
+    if (clear && v) *static_cast<volatile int*>(w) = 0;
+    return v;
+}
+int ls2fm_device_cus() {
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    return n_cus;
 }
 
 // an error after a fork: whatever was enqueued on the side stream is still joined into the caller's stream

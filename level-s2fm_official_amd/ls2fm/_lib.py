@@ -15,7 +15,7 @@ import torch
 MAX_LEVELS = 16
 HIDDEN = 64
 FEAT = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_RENDER_POINTS = 1 << 23     # LS2FM_MAX_RENDER_POINTS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -102,6 +102,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)        -- must list every symbol include/ls2fm.h declares
     "ls2fm_abi_version": (c_int32, []),
     "ls2fm_status_string": (c_char_p, [c_int32]),
+    "ls2fm_async_error": (c_int32, [c_int32]),
     "ls2fm_ray_aabb_intersect": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "ls2fm_grid_encode_fwd": (c_int32, [POINTER(GridDesc), _P, _P, c_int64, _P, _P, _P]),
     "ls2fm_grid_encode_bwd": (c_int32, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P]),
@@ -190,6 +191,11 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(f"libls2fm_hip.so ABI {lib.ls2fm_abi_version()} != python binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def async_error(clear: bool = False) -> int:
+    """sticky error word of the asynchronous parts of earlier calls (include/ls2fm.h: ls2fm_async_error); 0 = none"""
+    return int(load().ls2fm_async_error(1 if clear else 0))
 
 
 def check(status: int, what: str) -> None:

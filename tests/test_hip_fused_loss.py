@@ -153,3 +153,19 @@ def test_sharded_loss_head_gives_the_single_process_gradients(mode, fused_form, 
             assert terms[0][k] == terms[1][k]
         else:                         # a rank's terms are its share of the global means
             assert abs(terms[0][k] + terms[1][k] - full_terms[k]) <= 1e-5 * max(1.0, abs(full_terms[k])), k
+
+
+def test_no_async_error_after_a_backward_with_in_launch_hand_offs():
+    """ABI 9: the sticky error word of the backward's in-launch hand-offs (weight-gradient reduction rows / finalize tasks riding in
+    the scatter_fill launch, csrc/side_jobs.h).  A healthy step at the size that takes that path (>= 32 k samples) leaves it clear,
+    and a later backward is not refused (LS2FM_ERR_STARVED)."""
+    from ls2fm import _lib
+    opt, sdf, rad, ren, center, ray, gt, d_points, masks = _setup("ETH3D", True, 128, 512, 91)
+    head = RenderLossHead(DEV, 3.0, 2.0, 0.0)
+    for _ in range(2):
+        sdf.zero_grad(); rad.zero_grad()
+        ret, L = ren.forward_with_loss(opt, center, ray, sdf, rad, head, gt, d_points=d_points)
+        L["all"].backward()
+    torch.cuda.synchronize()
+    assert _lib.async_error() == 0
+    assert all(torch.isfinite(p.grad).all() for p in list(sdf.parameters()) + list(rad.parameters()) if p.grad is not None)

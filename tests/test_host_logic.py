@@ -31,6 +31,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     abi = int(re.search(r"#define\s+LS2FM_ABI_VERSION\s+(\d+)", header).group(1))          # library, binding and header agree
     assert lib.ls2fm_abi_version() == _lib.ABI_VERSION == abi
     assert lib.ls2fm_status_string(-2) == b"unsupported configuration"
+    assert b"starved" in lib.ls2fm_status_string(-5)
+    assert _lib.async_error() == 0 and _lib.async_error(clear=True) == 0      # nothing asynchronous has run: no word, no error
 
 
 def test_docs_carry_no_stale_abi_literal():
