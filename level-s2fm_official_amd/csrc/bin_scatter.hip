@@ -105,17 +105,28 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     // levels are walked last to first: the accumulate launch reads the lists first to last, i.e. most recently written first
     const int y_lv = (int)blockIdx.y - sj.rows, n_lv = (int)gridDim.y - sj.rows;
     const int tid = threadIdx.x, lane = tid & 63, l = level_base + (reverse ? n_lv - 1 - y_lv : y_lv);
-    if (blockIdx.x == 0 && y_lv == 0) {              // armed for the accumulate launch behind this one: unit counter, slab tickets
+    // Round 6: which TILE a workgroup fills.  Workgroup x of a row runs on XCD x % 8 (observed; the rows are multiples of 8 wide
+    // whenever this mapping is used), and the runs of neighbouring tiles are neighbours in a slab's list: a run is ~8 items = 256 B
+    // at a 32-byte granularity, so most runs end inside a cache line whose other part the NEXT tile's workgroup writes.  With
+    // tile = x the two halves of such a line are written through two different XCD L2s (two partial-line write-backs); with the
+    // XCDs walking contiguous tile ranges -- tile = (x % 8) (n_tiles / 8) + x / 8 -- they meet in one L2 a dispatch round apart.
+    // Any mapping gives the same items in the same places.  LS2FM_FILL_XCD_TILES=0: tile = x.
+#ifndef LS2FM_FILL_XCD_TILES
+#define LS2FM_FILL_XCD_TILES 1
+#endif
+    const int n_tiles_x = (int)gridDim.x;
+    const int tile_x = (LS2FM_FILL_XCD_TILES && (n_tiles_x & 7) == 0) ? ((int)blockIdx.x & 7) * (n_tiles_x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    if (tile_x == 0 && y_lv == 0) {              // armed for the accumulate launch behind this one: unit counter, slab tickets
         if (tid == 0) *acc_claim(bm) = 0;
         for (int q = tid; q < LS2FM_MAX_LEVELS * kBins; q += kFillThreads) bm.part_ticket[q] = 0;
     }
     static_assert(kBins <= kFillThreads, "one thread per slab for the run offsets");
     int pre_base = 0;
-    if (tid < kBins) pre_base = bm.start[l * kBins + tid] + bm.tile[((int64_t)l * bm.n_tiles + blockIdx.x) * kBins + tid];
+    if (tid < kBins) pre_base = bm.start[l * kBins + tid] + bm.tile[((int64_t)l * bm.n_tiles + tile_x) * kBins + tid];
     for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
     __syncthreads();
     const LevelC L = make_level_c(lv, l, sshift);
-    const int64_t i = (int64_t)blockIdx.x * kFillThreads + tid;
+    const int64_t i = (int64_t)tile_x * kFillThreads + tid;
     const bool live = i < n_points;
     uint32_t g[3] = {0u, 0u, 0u};
     float w[3] = {0.f, 0.f, 0.f}, d0 = 0.f, d1 = 0.f, r0 = 0.f, r1 = 0.f, e0 = 0.f, e1 = 0.f, qd[3] = {0.f, 0.f, 0.f};
@@ -354,7 +365,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     }       // (dual field)
     // the level's first workgroup also reduces the per-ray bounds of a single contribution (written by shade_bwd) to the
     // level's bound: the accumulate workgroups read two floats instead of n_rays each
-    if (blockIdx.x == 0) {
+    if (tile_x == 0) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(hist);
         for (int which = 0; which < (DUAL ? 2 : 1); ++which) {

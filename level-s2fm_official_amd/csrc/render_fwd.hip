@@ -289,7 +289,8 @@ struct EncodeExtras {
                               // level over its eighth of the chunks: what a gather fused into the per-ray shading kernel would see;
                               // same results); 2 = timing probe, WRONG results: a hashed level's corner loads restricted to one HALF
                               // of its slice by entry index, lower half during the first half of an XCD's chunks of the level, upper
-                              // half during the second (one of the two passes an entry-range split between XCDs would make)
+                              // half during the second (one of the two passes an entry-range split between XCDs would make);
+                              // 3 = timing probe: every corner reads entry 0 of its level (no table traffic); 4 = timing probe: no stores
 };
 
 constexpr int kEncThreads = 512;             // sample points of one level per workgroup = kEncRows tiles of the scatter's counting sort
@@ -325,8 +326,18 @@ __device__ __forceinline__ void locate_sample(const FieldC& fc, const float* __r
 
 // INTERLEAVED: dual field with the entry-interleaved table copy (ls2fm_params.dual_table): one 16-byte gather per corner
 // serves both grids -- the gathers are bound by the L2 -> L1 line rate, not by bytes.
+// (the measurement probes are compiled in only with -DLS2FM_ENC_PROBES: inside the shipped kernel their branches cost 14 registers --
+// 70 -> 84, five instead of seven waves per SIMD)
+#ifdef LS2FM_ENC_PROBES
+#define ENC_PROBE(ex) ((ex).probe)
+#else
+#define ENC_PROBE(ex) 0
+#endif
+#ifndef LS2FM_ENC_MINW
+#define LS2FM_ENC_MINW 1
+#endif
 template <bool INTERLEAVED>
-__global__ void __launch_bounds__(kEncThreads)
+__global__ void __launch_bounds__(kEncThreads, LS2FM_ENC_MINW)
 ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
                   const float* __restrict__ table1, const float* __restrict__ table2, int64_t n_points, int64_t p_pad,
                   int n_chunks, XcdPlan plan, float* __restrict__ enc1, float* __restrict__ enc2, float* __restrict__ jac,
@@ -342,7 +353,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
     const int bx = (int)blockIdx.x - kEncReserved;
     const int xcd = bx & 7, j = bx >> 3;
     int unit = plan.start[xcd] + j;
-    if (ex.probe == 1) {                                 // (measurement) chunk-major: XCD x walks chunks x, x + 8, .. of EVERY pass-level
+    if (ENC_PROBE(ex) == 1) {                                 // (measurement) chunk-major: XCD x walks chunks x, x + 8, .. of EVERY pass-level
         const int n_pl = plan.start[8] / n_chunks;
         const int ck = (j / n_pl) * 8 + xcd;
         if (ck >= n_chunks) return;
@@ -377,7 +388,11 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
         if (INTERLEAVED) {
             const float4* __restrict__ table = reinterpret_cast<const float4*>(table1);
             float4 v[8];
-            if (ex.probe == 2 && lv.hashed) {            // (timing probe: wrong results) only the corners in one half of the slice
+            if (ENC_PROBE(ex) == 3) {                         // (timing probe: wrong results) no table traffic: every corner reads the level's entry 0
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c.idx[k] = lv.offset;
+            }
+            if (ENC_PROBE(ex) == 2 && lv.hashed) {            // (timing probe: wrong results) only the corners in one half of the slice
                 const uint32_t want = 2 * chunk >= n_chunks ? 1u : 0u, hb = lv.size >> 1;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -394,10 +409,13 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                 y2 = fmaf(wt, v[k].z, y2);
                 y3 = fmaf(wt, v[k].w, y3);
             }
+            const bool st = ENC_PROBE(ex) != 4 || y0 == 1234.5f;          // (probe 4, timing only: no value / Jacobian stores)
+            if (st) {
             __builtin_nontemporal_store(y0, enc1 + (2 * l + 0) * p_pad + i);
             __builtin_nontemporal_store(y1, enc1 + (2 * l + 1) * p_pad + i);
             __builtin_nontemporal_store(y2, enc2 + (2 * l + 0) * p_pad + i);
             __builtin_nontemporal_store(y3, enc2 + (2 * l + 1) * p_pad + i);
+            }
 #pragma unroll
             for (int gd = 0; gd < 3; ++gd) {
                 float g0 = 0.f, g1 = 0.f;
@@ -407,8 +425,10 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                     g0 = fmaf(dw, v[k].x, g0);
                     g1 = fmaf(dw, v[k].y, g1);
                 }
+                if (st || g0 == 1234.5f) {
                 __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * p_pad + i) * 3 + gd);      // [channel][point][3]
                 __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * p_pad + i) * 3 + gd);
+                }
             }
         } else {
             const float* __restrict__ table = second ? table2 : table1;
@@ -670,8 +690,12 @@ extern "C" int ls2fm_render_fwd(const ls2fm_field_desc* field, const ls2fm_grid_
     ex.n_explicit = ls2fm_explicit_levels(sdf_grid, dual, field->n_samples);
     ex.n_prep_tasks = 3; ex.pts = nullptr;
     static const int enc_probe = [] { const char* e = getenv("LS2FM_ENC_PROBE"); return e ? atoi(e) : 0; }();
+#ifdef LS2FM_ENC_PROBES
     ex.probe = enc_probe;
-    if (enc_probe == 1) most = (n_chunks + 7) / 8 * (L1 + (pair ? L2 : 0));
+#else
+    ex.probe = 0; (void)enc_probe;
+#endif
+    if (ex.probe == 1) most = (n_chunks + 7) / 8 * (L1 + (pair ? L2 : 0));
     if (prepare_bwd) {
         const BinMeta bm = make_bin_meta(ws + w.bins, w.p);
         ex.tile_counts = bm.tile;
