@@ -190,6 +190,10 @@ def main():
     ap.add_argument("--overlap-groups", type=int, default=2, help="N > 1: level groups of the overlapped table-gradient reduction (2..4)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce after the backward instead of the "
                     "level-group reductions issued from inside it")
+    ap.add_argument("--capture-overlap", action="store_true",
+                    help="N > 1, all-reduce form, --launch graph / auto: record the level-group reductions INSIDE the captured step "
+                         "(second branch of the graph: communication stream -> RCCL's stream, beside the scatter of the later groups) "
+                         "instead of one message behind the backward")
     ap.add_argument("--split-loss", action="store_true", help="loss head as its own kernels after Renderer.forward (two-call form)")
     ap.add_argument("--exchange", choices=("shard", "allreduce"), default="allreduce",
                     help="N > 1: how the ranks exchange a step's gradients.  allreduce (default; BASELINE.json's step: fwd + bwd + "
@@ -276,6 +280,9 @@ def main():
         from ls2fm.optim import FusedAdam
         local_opt = FusedAdam([dict(params=list(sdf.parameters()), lr=1e-4), dict(params=list(rad.parameters()), lr=1e-4)],
                               scheduled_gamma=1.0)
+    if args.capture_overlap:
+        from ls2fm.dist import enable_capture_overlap
+        enable_capture_overlap(True)
     if reducer is not None and not args.no_overlap:
         # the ~105 MB gradient exchange is as long as the step on 7 xGMI links and all of it comes out of the backward's last
         # kernels: scatter the levels in 4 groups and all-reduce a group's table slices while the next ones are scattered
@@ -381,10 +388,38 @@ def main():
                 captured = None
                 capture_error = capture_error or "capture failed on another rank"
         t_graph = probe(True) if captured is not None else float("inf")
-        use_graph = captured is not None and not (t_eager < 0.98 * t_graph)      # a tie goes to the replay: its step time does not depend on the host
         launch_probe = {"eager_ms_per_step": t_eager * 1e3, "graph_ms_per_step": None if captured is None else t_graph * 1e3}
         if capture_error:
             launch_probe["capture_error"] = capture_error
+        # N > 1, all-reduce form: a THIRD candidate -- the captured step with the level-group reductions on a second branch of
+        # the graph (ls2fm.dist.enable_capture_overlap: the first group's all-reduce beside the scatter of the later groups).  On a
+        # one-rank group it can only lose (two scatter launch pairs, nothing to hide: 0.49 against 0.44 ms), so it is probed on
+        # real multi-GPU runs only (LS2FM_BENCH_PROBE_OVERLAP=1 forces it); every rank takes the decision from the same MAX-reduced times.
+        if (captured is not None and reducer is not None and not args.no_overlap and not args.capture_overlap
+                and (world > 1 or os.environ.get("LS2FM_BENCH_PROBE_OVERLAP", "0") == "1")):
+            from ls2fm.dist import enable_capture_overlap
+            plain, overlap_error = captured, None
+            enable_capture_overlap(True)
+            try:
+                captured = CapturedStep(whole_step, params, stream=s_main)
+            except Exception as e:                               # noqa: BLE001
+                overlap_error = f"{type(e).__name__}: {e}"[:300]
+            ok = torch.tensor([0.0 if overlap_error else 1.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            t_overlap = probe(True) if ok.item() >= 1.0 else float("inf")
+            times = torch.tensor([t_graph, t_overlap], device=dev, dtype=torch.float64)
+            dist.all_reduce(times, op=dist.ReduceOp.MAX)
+            t_graph_all, t_overlap_all = times.tolist()
+            launch_probe["graph_level_group_overlap_ms_per_step"] = None if t_overlap == float("inf") else t_overlap * 1e3
+            if overlap_error:
+                launch_probe["overlap_capture_error"] = overlap_error
+            if t_overlap_all < t_graph_all:
+                t_graph = t_overlap
+                args.capture_overlap = True                      # (the line's exchange.form says which graph ran)
+            else:
+                captured = plain
+                enable_capture_overlap(False)
+        use_graph = captured is not None and not (t_eager < 0.98 * t_graph)      # a tie goes to the replay: its step time does not depend on the host
         if rank == 0:
             print(f"[bench] launch probe: eager {t_eager * 1e3:.3f} ms/step, hipGraph {t_graph * 1e3:.3f} ms/step"
                   + (f" (capture failed: {capture_error})" if capture_error else ""), file=sys.stderr)
@@ -434,17 +469,45 @@ def main():
                             ("all-reduce" if args.no_overlap else f"all-reduce, {args.overlap_groups} level groups overlapped with the backward"),
                     "gradient_bytes": flat_bytes, "bytes_on_wire_per_gpu": 2 * (world - 1) / world * flat_bytes}
         if not shard:
-            exchange["form"] = ("all-reduce of the flat gradient buffer inside the captured step" if use_graph else exchange["form"])
-        if (shard and sharded_opt.n_groups <= 1) or (not shard and (args.no_overlap or use_graph)):
+            if use_graph:
+                exchange["form"] = (f"all-reduce inside the captured step, {args.overlap_groups} level groups on a second branch of the graph "
+                                    "(beside the scatter of the later groups)" if args.capture_overlap and not args.no_overlap else
+                                    "all-reduce of the flat gradient buffer inside the captured step")
+        # compute only = the same K steps of fwd + bwd with NO exchange and no update, launched eagerly, on EVERY N > 1 line
+        # (the first real scaling run separates exchange from compute whatever form it times).  The level-group
+        # reductions a backward would launch itself are switched off for these steps.
+        tabs = [p for p in params if hasattr(p, "_ls2fm_overlap_groups")]
+        held = [(p, p._ls2fm_overlap_groups) for p in tabs]
+        for p in tabs:
+            p._ls2fm_overlap_groups = 0
+        hook_held = [(p, p._ls2fm_group_exchange) for p in params if getattr(p, "_ls2fm_group_exchange", None) is not None]
+        for p, _ in hook_held:
+            p._ls2fm_group_exchange = None
+        try:
+            # launched like the timed steps: a hipGraph of fwd + bwd alone when those were replays
+            compute_step = render_step
+            if use_graph:
+                try:
+                    compute_step = CapturedStep(render_step, params, stream=s_main).replay
+                except Exception:                                # noqa: BLE001  (the line then says "eager")
+                    compute_step = render_step
+            for _ in range(3):
+                compute_step()
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                render_step()
+                compute_step()
             barrier()
-            t_compute = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
-            dist.all_reduce(t_compute, op=dist.ReduceOp.MAX)
-            exchange["compute_only_ms_per_step"] = float(t_compute.item()) * 1e3
-            exchange["exchange_and_update_ms_per_step"] = dt / args.steps * 1e3 - exchange["compute_only_ms_per_step"]
+        finally:
+            for p, v in held:
+                p._ls2fm_overlap_groups = v
+            for p, v in hook_held:
+                p._ls2fm_group_exchange = v
+        t_compute = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_compute, op=dist.ReduceOp.MAX)
+        exchange["compute_only_ms_per_step"] = float(t_compute.item()) * 1e3
+        exchange["compute_only_launch"] = "eager" if compute_step is render_step else "hipGraph replay"
+        exchange["exchange_and_update_ms_per_step"] = dt / args.steps * 1e3 - exchange["compute_only_ms_per_step"]
     # per-kernel device times (roofline): the same K steps launched eagerly with the library's HIP-event profiler on
     # (events cannot be read back from inside a graph replay); also gives the eager step time
     lib.ls2fm_profile_reset()

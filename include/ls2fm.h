@@ -256,6 +256,10 @@ typedef struct ls2fm_loss_spec {
     const float* d_total;         /* backward: DEVICE float[1] additional upstream of the weighted total, or NULL */
     float* d_depth_ref;           /* backward output: [n_rays] gradient w.r.t. depth_ref (overwritten), or NULL */
     uint32_t flags;               /* LS2FM_LOSS_*_FROM_GT */
+    uint32_t count_scale;         /* ABI 9 (in the struct's former padding: size and offsets unchanged).  > 1: every COUNT of `sums` is
+                                     multiplied by it in the forward's reduction -- a data-parallel run whose ranks hold the same number
+                                     of rays and no masks divides by the GLOBAL counts without a collective or a kernel between forward and
+                                     backward (ls2fm.dist "uniform"); 0 / 1: the local counts */
 } ls2fm_loss_spec;
 /* mask_eik / mask_mse := CameraSet.render's mask_bg, 0.05 < mean(rgb_gt[r]) < 0.95 (Camera.py:515), evaluated in the kernels
  * from rgb_gt; the pointer of the same name is ignored.  With these the loss head's only inputs that come out of a sphere

@@ -193,6 +193,7 @@ post_shade_kernel(ls2fm_loss_spec loss, const float* __restrict__ lpart, int64_t
     if (tid < kSums) {
         double v = 0.0;
         for (int q = 0; q < kPostThreads / 64; ++q) v += red[q][tid];
+        if ((tid & 1) && loss.count_scale > 1u) v *= (double)loss.count_scale;       // counts of a uniform data-parallel run
         red[0][tid] = v;
     }
     __syncthreads();

@@ -81,7 +81,8 @@ class LossSpec(Structure):
     """ls2fm_loss_spec: the loss head evaluated inside the render (forward epilogue / backward prologue)"""
     _fields_ = [("rgb_gt", c_void_p), ("depth_ref", c_void_p), ("mask_eik", c_void_p), ("mask_dc", c_void_p),
                 ("mask_mse", c_void_p), ("weights", c_void_p), ("terms", c_void_p), ("sums", c_void_p),
-                ("d_terms", c_void_p), ("d_total", c_void_p), ("d_depth_ref", c_void_p), ("flags", c_uint32)]
+                ("d_terms", c_void_p), ("d_total", c_void_p), ("d_depth_ref", c_void_p), ("flags", c_uint32),
+                ("count_scale", c_uint32)]
 
 
 LOSS_EIK_FROM_GT, LOSS_MSE_FROM_GT = 1, 2

@@ -30,6 +30,11 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= least
 
 
+def world_size() -> int:
+    """ranks of the process group (1 without one)"""
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def shard_rays(center: torch.Tensor, ray: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """center, ray [B,R,3] -> this rank's shard.  By view (axis 0) when B divides evenly over the ranks, otherwise
@@ -124,6 +129,22 @@ def comm_stream(device) -> torch.cuda.Stream:
     if idx not in _COMM_STREAMS:
         _COMM_STREAMS[idx] = torch.cuda.Stream(device=idx)
     return _COMM_STREAMS[idx]
+
+
+_CAPTURE_OVERLAP = {"on": None}
+
+
+def enable_capture_overlap(on: bool = True) -> None:
+    """level-group reductions also INSIDE a hipGraph capture (default: LS2FM_CAPTURE_OVERLAP, else off): the captured step then
+    has a second branch -- communication stream -> RCCL's stream -- that carries the first groups' all-reduce beside the scatter
+    of the later groups, and joins the capturing stream at GradAllReducer.all_reduce()"""
+    _CAPTURE_OVERLAP["on"] = bool(on)
+
+
+def capture_overlap_enabled() -> bool:
+    if _CAPTURE_OVERLAP["on"] is None:
+        return os.environ.get("LS2FM_CAPTURE_OVERLAP", "0") == "1"
+    return _CAPTURE_OVERLAP["on"]
 
 
 def enable_table_overlap(sdf_field, rad_field=None, n_groups: int = 2) -> None:

@@ -420,7 +420,17 @@ def _loss_struct(fl, depth_ref, terms, sums, d_terms=None, d_total=None, d_depth
     s.weights, s.terms, s.sums = ptr(fl.weights), ptr(terms), ptr(sums)
     s.d_terms, s.d_total, s.d_depth_ref = ptr(d_terms), ptr(d_total), ptr(d_depth_ref)
     s.flags = fl.flags
+    s.count_scale = _uniform_count_scale(fl)
     return s
+
+
+def _uniform_count_scale(fl) -> int:
+    """world size when the loss head's global counts are "uniform" under a process group (the forward's reduction then multiplies
+    its counts itself: no collective, no kernel between forward and backward), else 0"""
+    from . import dist as _dist
+    if getattr(fl, "global_counts", None) == "uniform" and _dist.is_distributed():
+        return int(_dist.world_size())
+    return 0
 
 
 class _Render(torch.autograd.Function):
@@ -485,7 +495,7 @@ class _Render(torch.autograd.Function):
                                    ptr(depth), ptr(nmlp), ptr(ws), ctypes.byref(opts), stream_ptr()), "ls2fm_render_fwd")
         if fl is not None:
             from . import dist as _dist
-            if _dist.is_distributed():        # world-size-invariant means: global counts (and sums) before the backward
+            if _dist.is_distributed() and lspec.count_scale <= 1:       # world-size-invariant means: global counts (and sums) before the backward
                 _dist.globalize_loss_sums(sums, fl.global_counts)
                 check(lib.ls2fm_loss_terms_from_sums(ptr(sums), ptr(fl.weights), ptr(terms), stream_ptr()),
                       "ls2fm_loss_terms_from_sums")
@@ -525,10 +535,15 @@ class _Render(torch.autograd.Function):
         # multi-GPU: scatter the levels in groups and all-reduce a group's table slices while the next group is scattered
         from . import dist as _dist
         n_groups = int(getattr(ps[0], "_ls2fm_overlap_groups", 0)) if _dist.is_distributed() else 0
-        if n_groups > 1 and torch.cuda.is_current_stream_capturing():
+        if n_groups > 1 and torch.cuda.is_current_stream_capturing() and not (
+                _dist.capture_overlap_enabled() and getattr(ps[0], "_ls2fm_group_exchange", None) is None):
             # captured steps: a pipelined sharded optimizer issues its chain at step(), a GradAllReducer reduces the flat buffer
-            # as one message on the capturing stream (ls2fm.dist) -- a communication-stream branch that forks again into RCCL's
-            # own stream is the depth-three fork tree that takes a capture down on ROCm 7.2
+            # as one message on the capturing stream (ls2fm.dist).  Rounds 2 - 5 refused the level-group overlap inside a capture
+            # outright: the render's backward then forked a side stream of its own, and a communication-stream branch that forks
+            # again into RCCL's stream was the depth-three fork tree that takes hipStreamEndCapture down on ROCm 7.2.  Since
+            # round 5 the backward is ONE chain on the capturing stream (csrc/side_jobs.h), so capturing stream -> communication
+            # stream -> RCCL's stream is a tree of depth two: ls2fm.dist.enable_capture_overlap() / LS2FM_CAPTURE_OVERLAP=1 records
+            # the first group's all-reduce on a second branch of the graph, beside the scatter of the later groups.
             n_groups = 0
         if n_groups > 1 and getattr(ps[0], "_ls2fm_group_exchange", None) is not None and fl is not None and fl.depth_node is not None:
             # a traced-depth node rides in this backward (ls2fm_depth_backward adds into the tables BEHIND the scatter: a group's

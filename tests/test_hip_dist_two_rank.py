@@ -92,6 +92,65 @@ def test_two_ranks_one_gpu_reproduce_the_single_process_gradients(overlap, tmp_p
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _capture_overlap_worker(rank, world, port, out_dir):
+    """the level-group reductions recorded INSIDE a hipGraph capture (ls2fm.dist.enable_capture_overlap): the
+    captured step forks capturing stream -> communication stream -> RCCL's stream for the first group and joins at all_reduce()"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "level-s2fm_official_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LS2FM_DIST_SINGLE="1")
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    from ls2fm import dist as ldist
+    from ls2fm.graph import CapturedStep
+    from ls2fm.losses import RenderLossHead
+    from ls2fm.options import make_options
+    from test_hip_fused_render import _randomized, _rays
+    from helpers import named_grads
+    n_rays = 512
+    opt = make_options("ETH3D", device=dev, dual_field=True, sample_intvs=128)       # (>= 32 k samples: side jobs inside the fill)
+    sdf, rad, ren = _randomized(opt, 121)
+    center, ray = _rays(n_rays, float(opt.data.bound_max[0]), 122)
+    gt = torch.rand(1, n_rays, 3, generator=torch.Generator().manual_seed(123)).to(dev)
+    head = RenderLossHead(dev, 3.0, 2.0, 0.0, global_counts="uniform")
+    params = list(sdf.parameters()) + list(rad.parameters())
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    try:
+        ldist.enable_table_overlap(sdf, rad, n_groups=2)
+        red = ldist.GradAllReducer(params)
+        s_main = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(s_main)
+
+        def whole_step():
+            _step(opt, sdf, rad, ren, head, center, ray, gt, None, {})
+            red.all_reduce()
+        whole_step()
+        torch.cuda.synchronize()
+        want = {**{"s." + k: v.clone() for k, v in named_grads(sdf).items()}, **{"r." + k: v.clone() for k, v in named_grads(rad).items()}}
+        ldist.enable_capture_overlap(True)
+        cap = CapturedStep(whole_step, params, stream=s_main)
+        for _ in range(3):
+            for p in params:
+                if p.grad is not None:
+                    p.grad.zero_()
+            cap.replay()
+        torch.cuda.synchronize()
+        got = {**{"s." + k: v for k, v in named_grads(sdf).items()}, **{"r." + k: v for k, v in named_grads(rad).items()}}
+        for k in want:
+            assert torch.equal(got[k], want[k]), k          # same kernels, same level groups: the same bits
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_level_group_reductions_inside_a_capture(tmp_path):
+    mp.spawn(_capture_overlap_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
+
+
 def test_one_rank_rccl_overlapped_reduction(tmp_path):
     """the same step through a real RCCL communicator (world size 1: all this box allows): the overlapped reduction's streams,
     events, coalesced launches and async handles run against the backend the multi-GPU bench uses; the sums are identities"""

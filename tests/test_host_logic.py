@@ -53,7 +53,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.Linear) == 24
     assert ctypes.sizeof(_lib.Params) == 8 + 48 + 8 + 8 + 8 + 48 + 72 + 8
     assert ctypes.sizeof(_lib.ParamGrads) == 8 + 48 + 8 + 8 + 48 + 72
-    assert ctypes.sizeof(_lib.LossSpec) == 12 * 8 and _lib.LossSpec.flags.offset == 88    # ls2fm_loss_spec: eleven pointers, uint32 flags (+pad)
+    assert ctypes.sizeof(_lib.LossSpec) == 12 * 8 and _lib.LossSpec.flags.offset == 88 and _lib.LossSpec.count_scale.offset == 92   # ls2fm_loss_spec: eleven pointers, uint32 flags, uint32 count_scale
     assert ctypes.sizeof(_lib.RenderOpts) == 8 + 8 + 8 + 4 * 8 + 8 + 8 + 8     # int32 (+pad), pointer, int32 (+pad), void* [4], void* x 3
     assert _lib.RenderOpts.loss_inputs_ready.offset == 56 and _lib.RenderOpts.depth_grad_ready.offset == 64
     assert _lib.RenderOpts.depth_bwd.offset == 72 and ctypes.sizeof(_lib.DepthBackward) == 48 and _lib.DepthBackward.workspace.offset == 40
