@@ -142,10 +142,9 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (loss)
         up.loss = LossUp{loss->rgb_gt, loss->depth_ref, loss->mask_eik, loss->mask_dc, loss->mask_mse, loss->weights, loss->sums,
                          loss->d_terms, loss->d_total, loss->d_depth_ref, loss->flags};
-    static const int fused_env = [] { const char* e = getenv("LS2FM_FUSED_WGRAD"); return e ? atoi(e) : 1; }();
     // (rays of fewer than 64 samples -- BASELINE configs[0]: 256 rays x 32 -- leave half of a wave's lanes empty in the fused form:
     // C1 0.171 fused against 0.154 ms with the separate launches)
-    const int fused_wgrad = fused_env && field->n_samples >= 64;
+    const int fused_wgrad = ls2fm_fused_wgrad(field->n_samples) ? 1 : 0;
     // the tracing's own backward (ls2fm_depth_backward): a second internal branch.  Its stages are those of ls2fm_sdf_points_bwd
     // over the track points, MERGED into this call's own chains: the per-point rows it leaves (front: gather pass, points_bwd,
     // scans) are contracted by this call's SDF weight-gradient kernel as extra tiles (no second wgrad_mlp / reduction / weight-norm

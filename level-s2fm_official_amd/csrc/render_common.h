@@ -252,10 +252,18 @@ struct WgPartLayout {
     int64_t total;
     int n_slots;
 };
+// the render's backward contracts the MLPs' weight gradients inside shade_bwd (one partial per ray) for rays of >= 64 samples unless
+// LS2FM_FUSED_WGRAD=0 (round 4's separate wgrad_mlp launches, for A/B runs): ONE predicate for the kernels' choice and the workspace
+static inline bool ls2fm_fused_wgrad(int n_samples) {
+    static const int env = [] { const char* e = getenv("LS2FM_FUSED_WGRAD"); return e ? atoi(e) : 1; }();
+    return env != 0 && n_samples >= 64;
+}
 static inline WgPartLayout make_wg_part_layout(int dual, int64_t n_rays, int n_samples) {
     WgPartLayout L;
     int64_t o = 0;
-    L.n_slots = n_samples > 1 ? (int)n_rays : 0;       // free points: wgrad_mlp.hip
+    // per-ray slots (39 KB per ray, dual field) only where shade_bwd fills them (round-5 advisor: short rays, free points and A/B runs
+    // with the switch off carried them unused -- 2.5 GB at 64 k rays)
+    L.n_slots = ls2fm_fused_wgrad(n_samples) ? (int)n_rays : 0;
     L.l1_sdf = o; o += (int64_t)(kL1Seg + kWgradMlpBlocks) * kRegsSdf * 64;
     L.l1_geo = o; o += dual ? (int64_t)kWgradMlpBlocks * kRegsGeo * 64 : 0;
     L.dec = o; o += (int64_t)kWgradMlpBlocks * kRegsDec * 64;

@@ -668,17 +668,42 @@ class _HostPicks:
     iteration.  `dev[:k]` are the pixel indices, `dev[k:]` the tail values (the view); `device_picks=True` on a loop keeps the
     device-side draw."""
     RING = 8
+    _instances = 0          # every loop instance draws from a stream of its own (round-5 advisor: they all replayed ONE sequence)
 
-    def __init__(self, n_total, k, device, tail=1):
+    def __init__(self, n_total, k, device, tail=1, shared=False):
+        """shared=True (a loop under torch.distributed: every rank must evaluate the replicated terms on the SAME pixels and view):
+        the generator is seeded with rank 0's seed -- one 8-byte broadcast at construction, no collective per iteration -- and
+        the view index comes from the same generator (`view(V)`) instead of the process-global, per-rank `random` module."""
         import numpy as np
         self.n, self.k, self.tail = int(n_total), int(k), int(tail)
-        self.rng = np.random.default_rng(int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF)
+        seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * _HostPicks._instances) & 0x7FFFFFFFFFFFFFFF
+        _HostPicks._instances += 1
+        from . import dist as _dist
+        self.shared = bool(shared) and _dist.is_distributed()
+        if self.shared:
+            import torch.distributed as tdist
+            t = torch.tensor([seed], dtype=torch.long, device=device if tdist.get_backend() == "nccl" else "cpu")
+            tdist.broadcast(t, 0)
+            seed = int(t.item())
+        self.rng = np.random.default_rng(seed)
         self.dev = torch.zeros(self.k + self.tail, dtype=torch.long, device=device)
         cuda = self.dev.is_cuda
         self.host = [torch.zeros(self.k + self.tail, dtype=torch.long).pin_memory() if cuda else torch.zeros(self.k + self.tail, dtype=torch.long)
                      for _ in range(self.RING if cuda else 1)]
         self.events = [None] * len(self.host)
         self.slot = 0
+
+    def view(self, n_views):
+        """the iteration's random view (the reference: `random.randint(0, V - 1)`): from this generator when the picks are shared
+        between ranks, else from the `random` module as the reference draws it"""
+        return int(self.rng.integers(0, n_views)) if self.shared else random.randint(0, n_views - 1)
+
+    def shared_pixels(self, rays_idx):
+        """a device-side pixel draw under a shared pick: rank 0's"""
+        if self.shared:
+            import torch.distributed as tdist
+            tdist.broadcast(rays_idx, 0)
+        return rays_idx
 
     def draw(self, *tail_values):
         h, ev = self.host[self.slot], self.events[self.slot]
@@ -756,7 +781,7 @@ class RefineLoop:
         # an iteration's picks as device tensors, updated in place: the ray pick and the key-point rays are formed INSIDE the step
         dev = self.poses.device
         k = self.rand_rays // self.poses.shape[0]
-        self._picks = _HostPicks(views.H * views.W, k, dev, tail=1)          # pixel indices + the view, one buffer, one copy per iteration
+        self._picks = _HostPicks(views.H * views.W, k, dev, tail=1, shared=distributed)   # pixel indices + the view, one buffer, one copy per iteration
         self._idx, self._view = self._picks.dev[:k], self._picks.dev[k:]
         self.device_picks = bool(device_picks)
         self._fixed = _FixedPoseRays(views, self.poses)
@@ -768,12 +793,12 @@ class RefineLoop:
     def step(self, rays_idx=None, view=None):
         V = self.poses.shape[0]
         if rays_idx is None and view is None and not self.device_picks:
-            self._picks.draw(random.randint(0, V - 1))
+            self._picks.draw(self._picks.view(V))
             return self.stage.step()
         if rays_idx is None:
-            rays_idx = torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // V]
+            rays_idx = self._picks.shared_pixels(torch.randperm(self.views.H * self.views.W, device=self.poses.device)[: self.rand_rays // V])
         self._idx.copy_(rays_idx)
-        self._view.fill_(random.randint(0, V - 1) if view is None else int(view))
+        self._view.fill_(self._picks.view(V) if view is None else int(view))
         return self.stage.step()
 
     def run(self, n_iters=None, picks=None):
@@ -1144,7 +1169,7 @@ class BALoop:
                                  extra_prepare=self._prepare, input_fn=self._inputs, share_gradients=bool(static),
                                  shard_views=bool(distributed), reducer="auto" if distributed else None)
         k = self.rand_rays // se3.shape[0]
-        self._picks = _HostPicks(views.H * views.W, k, se3.device, tail=1)
+        self._picks = _HostPicks(views.H * views.W, k, se3.device, tail=1, shared=distributed)
         self._idx, self._view = self._picks.dev[:k], self._picks.dev[k:]
         self.device_picks = bool(device_picks)
         self._keys = ("loss_all", "PSNR", "rgb_loss", "DC_loss", "eikonal_loss", "sdf_surf", "tracing_loss", "reproj_error", "w_reproj")
@@ -1213,12 +1238,12 @@ class BALoop:
     def step(self, rays_idx=None, view=None):
         V = self.rot.shape[0]
         if rays_idx is None and view is None and not self.device_picks:
-            self._picks.draw(random.randint(0, V - 1))
+            self._picks.draw(self._picks.view(V))
         else:
             if rays_idx is None:
-                rays_idx = torch.randperm(self.views.H * self.views.W, device=self.rot.device)[: self.rand_rays // V]
+                rays_idx = self._picks.shared_pixels(torch.randperm(self.views.H * self.views.W, device=self.rot.device)[: self.rand_rays // V])
             self._idx.copy_(rays_idx)
-            self._view.fill_(random.randint(0, V - 1) if view is None else int(view))
+            self._view.fill_(self._picks.view(V) if view is None else int(view))
         ret = self.stage.step()
         with torch.no_grad():
             self.xyzs_all[self.obs_point] = self._new_points                                     # BA.py:181

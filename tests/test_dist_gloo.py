@@ -293,3 +293,44 @@ def test_single_process_paths_are_noops():
     p.grad = torch.ones(3)
     ldist.GradAllReducer([p]).all_reduce()
     assert torch.equal(p.grad, torch.ones(3))
+
+
+def _picks_worker(rank, world, port, out_dir):
+    """ADVICE r5 (stage.py): under distributed=True every rank must evaluate the replicated terms on the same pixels and view;
+    the default picks came from per-rank generators.  Shared picks: rank 0's seed, broadcast once; the view from the same stream."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ls2fm.stage import _HostPicks
+        torch.manual_seed(1000 + 17 * rank)                      # the ranks' own seeds differ
+        import random
+        random.seed(5 + rank)
+        shared = _HostPicks(4096, 16, "cpu", tail=1, shared=True)
+        local = _HostPicks(4096, 16, "cpu", tail=1, shared=False)
+        again = _HostPicks(4096, 16, "cpu", tail=1, shared=True)
+        rows = []
+        for _ in range(3):
+            shared.draw(shared.view(7))
+            rows.append(shared.dev.clone())
+        local.draw(local.view(7))
+        again.draw(again.view(7))
+        mine = torch.stack(rows)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1])                     # same pixels, same view, every iteration
+        assert len(set(mine[0, :16].tolist())) == 16 and int(mine[:, 16].max()) < 7
+        assert not torch.equal(mine[0], mine[1])                 # a stream, not a constant
+        assert not torch.equal(again.dev, mine[0])               # a second loop instance does not replay the first one's sequence
+        loc = [torch.zeros_like(local.dev) for _ in range(world)]
+        dist.all_gather(loc, local.dev)
+        assert not torch.equal(loc[0][:16], loc[1][:16])         # (unshared picks stay per-rank)
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_default_picks_two_rank_gloo(tmp_path):
+    mp.spawn(_picks_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
