@@ -32,12 +32,26 @@ constexpr int kMaxParts = 16;
 
 typedef unsigned long long u64;
 
+// -DLS2FM_ITEM_PROBE24 (round 6, TIMING PROBE, wrong second-grid gradients): the dual item WITHOUT its second-grid words -- 24 bytes --
+// with LS2FM_EXPLICIT_LEVELS=0: what the fill / accumulate pair would take if an item were a quarter smaller (profiles/r06_item_bytes_probe.txt)
+#ifdef LS2FM_ITEM_PROBE24
+struct __attribute__((aligned(8))) Item {
+    uint32_t ij;
+    float wx;
+    float a0, a1, b0, b1;
+};
+#define LS2FM_ITEM_C0(it) ((it).b0)
+#define LS2FM_ITEM_C1(it) ((it).b1)
+#else
 struct __attribute__((aligned(16))) Item {      // 32 bytes: BOTH grids of a dual-field pair, factored over the two x-corners
     uint32_t ij;           // local entry index of x-corner 0 (low 16 bits) and 1 (high 16 bits); 0xFFFF = not in this slab
     float wx;              // x weight: px(0) = 1 - wx, px(1) = wx
     float a0, a1, b0, b1;  // SDF grid, per feature: A = pyz de + qyz rr ; B = qd_x pyz rr
     float c0, c1;          // second grid: C = pyz de2
 };
+#define LS2FM_ITEM_C0(it) ((it).c0)
+#define LS2FM_ITEM_C1(it) ((it).c1)
+#endif
 
 // Single field (the reference's default, options/LevelS2fM.yaml:9 `dual_field: false`, and every point query): the two
 // x-corners' contributions are formed where the records are read and travel EXPLICITLY -- 20 bytes instead of the 24 a
@@ -60,7 +74,10 @@ template <> struct ItemOf<true> { typedef Item type; };
 constexpr int kMaxExplicitLevels = 6;
 __host__ __device__ __forceinline__ Item explicit_item(uint32_t ij, const float* v) {        // v[0..6] -> the item, v[7] -> extra
     Item it;
-    it.ij = ij; it.wx = v[0]; it.a0 = v[1]; it.a1 = v[2]; it.b0 = v[3]; it.b1 = v[4]; it.c0 = v[5]; it.c1 = v[6];
+    it.ij = ij; it.wx = v[0]; it.a0 = v[1]; it.a1 = v[2]; it.b0 = v[3]; it.b1 = v[4];
+#ifndef LS2FM_ITEM_PROBE24
+    it.c0 = v[5]; it.c1 = v[6];
+#endif
     return it;
 }
 

@@ -121,10 +121,33 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         for (int q = tid; q < LS2FM_MAX_LEVELS * kBins; q += kFillThreads) bm.part_ticket[q] = 0;
     }
     static_assert(kBins <= kFillThreads, "one thread per slab for the run offsets");
-    int pre_base = 0;
-    if (tid < kBins) pre_base = bm.start[l * kBins + tid] + bm.tile[((int64_t)l * bm.n_tiles + tile_x) * kBins + tid];
-    for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
-    __syncthreads();
+    // Round 6: the workgroup's item count per slab is NOT counted again here (rounds 1-5: a pass over the pairs -- eight hashes and
+    // 4-8 LDS atomics per thread -- and two barriers): the gather pass counted exactly these items (same classification,
+    // bin_items.h) and the scans left, per (tile, slab), the number of items of the EARLIER tiles: the difference of two
+    // neighbouring rows is this tile's count (the last tile: against the slab's total).  Timing probes of this round (no item
+    // stores at all: 70 of 90 us) showed the kernel bound by its own instruction count, not by its stores.
+    // LS2FM_FILL_COUNT_{DUAL,SINGLE}: 1 (default) = counted here, in the ONE hash pass, with LDS atomics; 0 = taken from the scan
+    // results as described above (no atomics, one barrier fewer -- but the offsets' loads then have a consumer at the head of the
+    // workgroup's chain instead of at its staging).  Measured at C2 (profiles/r06_ab_fill_count.txt), rounds 1-5's separate counting
+    // pass | from the scan rows | counted in the hash pass:  dual field 87.0 | 84.3 | 81.2 us;  single field 64.0 | 66.8 | 63.7 us.
+#ifndef LS2FM_FILL_COUNT_DUAL
+#define LS2FM_FILL_COUNT_DUAL 1
+#endif
+#ifndef LS2FM_FILL_COUNT_SINGLE
+#define LS2FM_FILL_COUNT_SINGLE 1
+#endif
+    constexpr bool kCountHere = DUAL ? (LS2FM_FILL_COUNT_DUAL != 0) : (LS2FM_FILL_COUNT_SINGLE != 0);
+    int pre_base = 0, n_mine = 0;
+    if (tid < kBins) {
+        const int* row = bm.tile + ((int64_t)l * bm.n_tiles + tile_x) * kBins + tid;
+        const int before = row[0];
+        pre_base = bm.start[l * kBins + tid] + before;
+        if (!kCountHere) n_mine = (tile_x + 1 < bm.n_tiles ? row[kBins] : bm.count[l * kBins + tid]) - before;
+    }
+    if (kCountHere) {
+        for (int b = tid; b < kBins; b += kFillThreads) hist[b] = 0;
+        __syncthreads();
+    }
     const LevelC L = make_level_c(lv, l, sshift);
     const int64_t i = (int64_t)tile_x * kFillThreads + tid;
     const bool live = i < n_points;
@@ -153,28 +176,33 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     const bool expl = DUAL && l < n_explicit;               // (workgroup-uniform) explicit, run-merged dual items on this level
     const bool halves = DUAL && !expl;                      // factored items: a merged run would be two half items per pair
     const RunFlags rf = wave_runs(g, live, lane, halves ? kMergeMinDual : kMergeMinSingle);
-    for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned, uint32_t, uint32_t) { atomicAdd(&hist[slab], 1); });
-    __syncthreads();
-    // runs: offsets in the sorted order (exclusive prefix over the slabs, wave 0)
-    if (tid < 64) {
-        int run = 0;
-#pragma unroll
-        for (int c = 0; c < (kBins + 63) / 64; ++c) {
-            const int b = 64 * c + lane;
-            const int cnt = b < kBins ? hist[b] : 0;
-            const int incl = wave_scan_incl_i32(cnt, lane);
-            if (b < kBins) lds_off[b] = run + incl - cnt;
-            run += __shfl(incl, 63, 64);
+    // ---- ONE pass over the pairs' hashes (rounds 1-5: one per counting / ranking / window pass).  Kept per pair c: ij (both
+    // x-corners' local indices, each relative to its own slab), the slab of the pair's first item in byte c of sb0 (bit 7: the pair
+    // is split into two half items), the second half item's slab in byte c of sb1.  Nothing here (nor in the factors below) needs
+    // the run offsets: the work runs while their loads from the top are in flight.
+    // (named scalars: as arrays indexed by the lambda's pair number they went to scratch memory)
+    uint32_t ij0 = 0u, ij1 = 0u, ij2 = 0u, ij3 = 0u, sb0 = 0u, sb1 = 0u;
+    auto or_ij = [&](unsigned c, uint32_t v) { if (c == 0) ij0 |= v; else if (c == 1) ij1 |= v; else if (c == 2) ij2 |= v; else ij3 |= v; };
+    auto get_ij = [&](unsigned c) { return c == 0 ? ij0 : (c == 1 ? ij1 : (c == 2 ? ij2 : ij3)); };
+    static_assert(kBins <= 128, "a slab fits seven bits");
+    for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
+        // (selects, not branches: as `if / else` on two variables the compiler made them a two-element array in scratch memory)
+        const bool first = i0 != 0xFFFFu;
+        or_ij(c, (first ? i0 : 0u) | (i1 != 0xFFFFu ? i1 << 16 : 0u));
+        const uint32_t field = ((uint32_t)slab | ((first && i1 == 0xFFFFu) ? 0x80u : 0u)) << (8 * c);
+        sb0 |= first ? field : 0u;
+        sb1 |= first ? 0u : field;
+        if (kCountHere) atomicAdd(&hist[slab], 1);
+    });
+    // the items of pair c from the kept fields: f(slab, second half item?, ij word of the item)
+    auto pair_items = [&](unsigned c, auto&& f) {
+        const uint32_t ijc = get_ij(c), s0 = (sb0 >> (8 * c)) & 0xFFu;
+        if ((s0 & 0x80u) == 0u) f((int)s0, false, ijc);
+        else {
+            f((int)(s0 & 0x7Fu), false, (ijc & 0xFFFFu) | 0xFFFF0000u);
+            f((int)((sb1 >> (8 * c)) & 0x7Fu), true, (ijc & 0xFFFF0000u) | 0xFFFFu);
         }
-        if (lane == 0) s_total = run;
-    }
-    __syncthreads();
-    if (tid < kBins) {                   // (slab tid: this thread is its only reader and writer here)
-        run_len[tid] = hist[tid];
-        base[tid] = pre_base;
-        hist[tid] = 0;
-    }
-    __syncthreads();
+    };
     // the two x-corners' values of corner pair c = by + 2 bz, both grids:
     //   corner 0: px0 A - B [, px0 C]      corner 1: wx A + B [, wx C]        (exactly what slab_accumulate forms from a factored item)
     auto pair_factors = [&](unsigned c, float (&a)[2], float (&b)[2], float (&cc)[2]) {
@@ -189,36 +217,80 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         cc[0] = pyz * e0;
         cc[1] = pyz * e1;
     };
+    float val[DUAL ? 1 : 16];                                // single field: the pairs' explicit corner values
+    float fa[DUAL ? 4 : 1][2], fb[DUAL ? 4 : 1][2], fcc[DUAL ? 4 : 1][2];       // dual field, factored items
+#ifndef LS2FM_FILL_SINGLE_LATE_VAL
+#define LS2FM_FILL_SINGLE_LATE_VAL 0
+#endif
+    auto single_values = [&]() {
+        const float px0 = 1.0f - w[0];
+#pragma unroll
+        for (unsigned c = 0; c < 4; ++c) {
+            float a[2], b[2], cc[2];
+            pair_factors(c, a, b, cc);
+            val[(DUAL ? 0 : 4) * c + 0] = fmaf(px0, a[0], -b[0]);
+            val[(DUAL ? 0 : 4) * c + (DUAL ? 0 : 1)] = fmaf(px0, a[1], -b[1]);
+            val[(DUAL ? 0 : 4) * c + (DUAL ? 0 : 2)] = fmaf(w[0], a[0], b[0]);
+            val[(DUAL ? 0 : 4) * c + (DUAL ? 0 : 3)] = fmaf(w[0], a[1], b[1]);
+        }
+        if (rf.cont != 0ull) run_sums<DUAL ? 1 : 16>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
+    };
+    if constexpr (!DUAL) {
+        if (!LS2FM_FILL_SINGLE_LATE_VAL) single_values();
+    } else if (!expl) {
+#pragma unroll
+        for (unsigned c = 0; c < 4; ++c) pair_factors(c, fa[c], fb[c], fcc[c]);
+    }
+    // ---- the run lengths (counted above, or the first consumer of the loads issued at the top)
+    if (kCountHere) __syncthreads();
+    if (tid < kBins) {                   // (slab tid: this thread is its only reader and writer here)
+        run_len[tid] = kCountHere ? hist[tid] : n_mine;
+        base[tid] = pre_base;
+        hist[tid] = 0;                   // running rank
+    }
+    __syncthreads();
+    // runs: offsets in the sorted order (exclusive prefix over the slabs, wave 0)
+    if (tid < 64) {
+        int run = 0;
+#pragma unroll
+        for (int c = 0; c < (kBins + 63) / 64; ++c) {
+            const int b = 64 * c + lane;
+            const int cnt = b < kBins ? run_len[b] : 0;
+            const int incl = wave_scan_incl_i32(cnt, lane);
+            if (b < kBins) lds_off[b] = run + incl - cnt;
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) s_total = run;
+    }
+    __syncthreads();
+    // an item's rank inside its (workgroup, slab) run.  Long runs (coarse levels: consecutive samples of a ray fall into the same
+    // cell) are stored permuted, so that the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same
+    // entry (same-address LDS atomics serialise): position = rank * K mod n with K prime > n
+    auto take_rank = [&](int slab) {
+        int rank = atomicAdd(&hist[slab], 1);
+        const int n_run = run_len[slab];
+        if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
+        return rank;
+    };
     if constexpr (!DUAL) {
         // ---- single field: 20-byte explicit items, ONE staging area for all of them (26 KB): ranked and staged in one pass
         // over the pairs (the windowed form below enumerates them once more: 52 -> 57 us)
-        float val[16];
-        {
-            const float px0 = 1.0f - w[0];
+        if (LS2FM_FILL_SINGLE_LATE_VAL) single_values();
+        if (rf.head) {
 #pragma unroll
-            for (unsigned c = 0; c < 4; ++c) {
-                float a[2], b[2], cc[2];
-                pair_factors(c, a, b, cc);
-                val[4 * c + 0] = fmaf(px0, a[0], -b[0]);
-                val[4 * c + 1] = fmaf(px0, a[1], -b[1]);
-                val[4 * c + 2] = fmaf(w[0], a[0], b[0]);
-                val[4 * c + 3] = fmaf(w[0], a[1], b[1]);
-            }
+            for (unsigned c = 0; c < 4; ++c)
+                pair_items(c, [&](int slab, bool, uint32_t ij) {
+                    ItemT it;
+                    it.ij = ij;
+                    it.v00 = val[4 * c + 0]; it.v01 = val[4 * c + 1];
+                    it.v10 = val[4 * c + 2]; it.v11 = val[4 * c + 3];
+                    const int rank = take_rank(slab);
+                    const int slot = lds_off[slab] + rank;
+                    const uint32_t gi = (uint32_t)(base[slab] + rank);
+                    if (slot < kWin) { s_items[slot] = it; s_gidx[slot] = gi; }
+                    else g_items[gi] = it;                           // more split pairs than the staging area holds: direct write
+                });
         }
-        if (rf.cont != 0ull) run_sums<16>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
-        for_each_item_merged(L, g, rf, false, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
-            ItemT it;
-            it.ij = i0 | (i1 << 16);
-            it.v00 = val[4 * c + 0]; it.v01 = val[4 * c + 1];
-            it.v10 = val[4 * c + 2]; it.v11 = val[4 * c + 3];
-            int rank = atomicAdd(&hist[slab], 1);
-            const int n_run = run_len[slab];                 // (long runs are stored permuted: see below)
-            if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
-            const int slot = lds_off[slab] + rank;
-            const uint32_t gi = (uint32_t)(base[slab] + rank);
-            if (slot < kWin) { s_items[slot] = it; s_gidx[slot] = gi; }
-            else g_items[gi] = it;                           // more split pairs than the staging area holds: direct write
-        });
         __syncthreads();
         const int staged = s_total < kWin ? s_total : kWin;
 #if LS2FM_FILL_FLAT
@@ -247,16 +319,11 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         return (int)(second ? v >> 16 : v & 0xFFFFu);
     };
     static_assert(kFillThreads * 8 <= 0xFFFF, "slots fit 16 bits");
-    for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned c, uint32_t i0, uint32_t) {
-        int rank = atomicAdd(&hist[slab], 1);
-        // long runs (coarse levels: consecutive samples of a ray fall into the same cell) are stored permuted, so that
-        // the 64 lanes of an accumulate wave, which read consecutive items, do not all hit the same entry (same-address
-        // LDS atomics serialise): position = rank * K mod n with K prime > n
-        const int n_run = run_len[slab];
-        if (n_run > 64) rank = (int)(((long long)rank * 1000003ll) % n_run);
-        const int slot = lds_off[slab] + rank;
-        put_slot(c, i0 == 0xFFFFu, slot);
-    });
+    if (rf.head) {
+#pragma unroll
+        for (unsigned c = 0; c < 4; ++c)
+            pair_items(c, [&](int slab, bool second, uint32_t) { put_slot(c, second, lds_off[slab] + take_rank(slab)); });
+    }
     const int total = s_total;
     auto write_out = [&](int win) {
         // runs of one slab are contiguous in the sorted order and in memory: consecutive threads write consecutive items
@@ -265,10 +332,22 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         if (staged < 0)                    // timing probe: no item stores
 #endif
 #if LS2FM_FILL_FLAT
+#ifdef LS2FM_ITEM_PROBE24
+        for (int c = tid; c < 3 * staged; c += kFillThreads) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(2)));          // (8-byte chunks of a 24-byte item)
+            const int q = (int)(((uint32_t)c * 43691u) >> 17), hf = c - 3 * q;
+#else
         for (int c = tid; c < 2 * staged; c += kFillThreads) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const int q = c >> 1, hf = c & 1;
+#endif
+#if (LS2FM_FILL_PROBE & 4)
+            const uint32_t gi = s_gidx[q] & 0x7FFFu;                                   // timing probe: every store inside a 1 MB window (cache-resident)
+#elif (LS2FM_FILL_PROBE & 8)
+            const uint32_t gi = (uint32_t)(((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (kFillCap + 64) + win + q);     // timing probe: the workgroup's items CONTIGUOUS (streaming stores, no scatter)
+#else
             const uint32_t gi = s_gidx[q];
+#endif
             const u32x4 v = reinterpret_cast<const u32x4*>(s_items)[c];
             u32x4* dst = reinterpret_cast<u32x4*>(&g_items[gi]) + hf;
 #if LS2FM_FILL_NT
@@ -304,30 +383,32 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
 #endif
     };
     if (!expl) {
-        // ---- factored dual items
-        float fa[4][2], fb[4][2], fcc[4][2];
-#pragma unroll
-        for (unsigned c = 0; c < 4; ++c) pair_factors(c, fa[c], fb[c], fcc[c]);
+        // ---- factored dual items (factors formed above, indices and slabs kept from the one hash pass)
         for (int win = 0; win < total; win += kWin) {
             if (win > 0) __syncthreads();                     // the previous window has been written out
-            for_each_item_merged(L, g, rf, halves, [&](int slab, unsigned c, uint32_t i0, uint32_t i1) {
-                const int rel = get_slot(c, i0 == 0xFFFFu) - win;
-                if (rel < 0 || rel >= kWin) return;
-                ItemT it;
-                it.ij = i0 | (i1 << 16);
-                it.wx = w[0];
-                it.a0 = fa[c][0]; it.a1 = fa[c][1];
-                it.b0 = fb[c][0]; it.b1 = fb[c][1];
-                it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
-                s_items[rel] = it;
-                s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
-            });
+            if (rf.head) {
+#pragma unroll
+                for (unsigned c = 0; c < 4; ++c)
+                    pair_items(c, [&](int slab, bool second, uint32_t ij) {
+                        const int rel = get_slot(c, second) - win;
+                        if (rel < 0 || rel >= kWin) return;
+                        ItemT it;
+                        it.ij = ij;
+                        it.wx = w[0];
+                        it.a0 = fa[c][0]; it.a1 = fa[c][1];
+                        it.b0 = fb[c][0]; it.b1 = fb[c][1];
+#ifndef LS2FM_ITEM_PROBE24
+                        it.c0 = fcc[c][0]; it.c1 = fcc[c][1];
+#endif
+                        s_items[rel] = it;
+                        s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
+                    });
+            }
             __syncthreads();
             write_out(win);
         }
     } else {
         // ---- explicit dual items, pair by pair: the pair's eight corner values, their sums over the run, its item(s)
-        const uint32_t lmask = (1u << L.sshift) - 1u;
         const float px0 = 1.0f - w[0];
         for (int win = 0; win < total; win += kWin) {         // (one window unless nothing merged)
             if (win > 0) __syncthreads();
@@ -340,23 +421,14 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
                 v8[4] = px0 * cc[0]; v8[5] = px0 * cc[1];
                 v8[6] = w[0] * cc[0]; v8[7] = w[0] * cc[1];
                 if (rf.cont != 0ull) run_sums<8>(v8, rf.cont, lane);              // wave-uniform
-                if (rf.head) {
-                    const uint32_t cy = g[1] + (c & 1u), cz = g[2] + (c >> 1);
-                    const uint32_t i0 = level_index(L, g[0], cy, cz), i1 = level_index(L, g[0] + 1u, cy, cz);
-                    const uint32_t s0 = i0 >> L.sshift, s1 = i1 >> L.sshift;
-                    auto stage = [&](int slab, bool second, uint32_t ij) {
+                if (rf.head)
+                    pair_items(c, [&](int slab, bool second, uint32_t ij) {
                         const int rel = get_slot(c, second) - win;
                         if (rel < 0 || rel >= kWin) return;
                         s_items[rel] = explicit_item(ij, v8);
                         s_extra[rel] = v8[7];
                         s_gidx[rel] = (uint32_t)(base[slab] + (rel + win - lds_off[slab]));
-                    };
-                    if (s0 == s1) stage((int)s0, false, (i0 & lmask) | ((i1 & lmask) << 16));
-                    else {
-                        stage((int)s0, false, (i0 & lmask) | (0xFFFFu << 16));
-                        stage((int)s1, true, 0xFFFFu | ((i1 & lmask) << 16));
-                    }
-                }
+                    });
             }
             __syncthreads();
             write_out(win);
@@ -677,7 +749,11 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
         quantum_of(cur.bound1, plan.headroom_bits, to_fixed1, to_float1);
         quantum_of(cur.bound2, plan.headroom_bits, to_fixed2, to_float2);
         auto add_item = [&](const ItemT& it, float x9) {
+#if (LS2FM_FILL_PROBE & 12)
+            const uint32_t i0 = it.ij & 0xFFFu, i1 = (it.ij >> 16) & 0xFFFu;       // (the fill probes leave stale / foreign items in the lists: stay inside the slab)
+#else
             const uint32_t i0 = it.ij & 0xFFFFu, i1 = it.ij >> 16;
+#endif
             if constexpr (DUAL) {
                 if (cur.expl) {                // explicit item (bin_items.h: explicit_item): the corners' values as they are
                     if (i0 != 0xFFFFu) {
@@ -685,13 +761,13 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
                         add_fixed(slot, it.wx, to_fixed1);
                         add_fixed(slot + E, it.a0, to_fixed1);
                         add_fixed(slot + 2 * E, it.b1, to_fixed2);
-                        add_fixed(slot + 3 * E, it.c0, to_fixed2);
+                        add_fixed(slot + 3 * E, LS2FM_ITEM_C0(it), to_fixed2);
                     }
                     if (i1 != 0xFFFFu) {
                         u64* slot = acc + i1;
                         add_fixed(slot, it.a1, to_fixed1);
                         add_fixed(slot + E, it.b0, to_fixed1);
-                        add_fixed(slot + 2 * E, it.c1, to_fixed2);
+                        add_fixed(slot + 2 * E, LS2FM_ITEM_C1(it), to_fixed2);
                         add_fixed(slot + 3 * E, x9, to_fixed2);
                     }
                     return;
@@ -701,15 +777,15 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
                     u64* slot = acc + i0;
                     add_fixed(slot, fmaf(px0, it.a0, -it.b0), to_fixed1);
                     add_fixed(slot + E, fmaf(px0, it.a1, -it.b1), to_fixed1);
-                    add_fixed(slot + 2 * E, px0 * it.c0, to_fixed2);
-                    add_fixed(slot + 3 * E, px0 * it.c1, to_fixed2);
+                    add_fixed(slot + 2 * E, px0 * LS2FM_ITEM_C0(it), to_fixed2);
+                    add_fixed(slot + 3 * E, px0 * LS2FM_ITEM_C1(it), to_fixed2);
                 }
                 if (i1 != 0xFFFFu) {
                     u64* slot = acc + i1;
                     add_fixed(slot, fmaf(it.wx, it.a0, it.b0), to_fixed1);
                     add_fixed(slot + E, fmaf(it.wx, it.a1, it.b1), to_fixed1);
-                    add_fixed(slot + 2 * E, it.wx * it.c0, to_fixed2);
-                    add_fixed(slot + 3 * E, it.wx * it.c1, to_fixed2);
+                    add_fixed(slot + 2 * E, it.wx * LS2FM_ITEM_C0(it), to_fixed2);
+                    add_fixed(slot + 3 * E, it.wx * LS2FM_ITEM_C1(it), to_fixed2);
                 }
             } else {
                 if (i0 != 0xFFFFu) {
@@ -864,7 +940,9 @@ bool levels_fit(const ls2fm_grid_desc* grid, int sshift) {
 // floats of workspace the scatter needs: meta + worst case 8 items (4 pairs, each split) of 32 bytes per (point, level) + the
 // explicit dual items' ninth word
 int64_t ls2fm_bins_workspace_floats(int n_levels, int64_t n_points) {
+#ifndef LS2FM_ITEM_PROBE24
     static_assert(sizeof(Item) == 32 && sizeof(ItemS) == 20, "item layouts");
+#endif
     return meta_ints(n_points) + part_acc_floats(n_points) + extra_floats(n_points) + 8 * 8 * (int64_t)n_levels * n_points + 64;
 }
 

@@ -227,7 +227,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     // (and only on a device with an order of magnitude more workgroup slots than the launch has WAITING workgroups -- the reduction
     // rows and finalize tasks, ~180: side_jobs.h -- so that the producers they poll can never be kept off the chip by them)
     const int n_waiters = kRegsSdf + (dual ? kRegsGeo : 0) + kRegsDec + kFinalizeTasks;
-    const bool side_in_fill = side_in_fill_env && fused_wgrad && !db && !probe_no_side && w.p >= 32768 && n_rays <= 4096 &&
+    static const int64_t side_max_rays = [] { const char* e = getenv("LS2FM_SIDE_IN_FILL_MAX_RAYS"); return e ? atoll(e) : 4096ll; }();
+    const bool side_in_fill = side_in_fill_env && fused_wgrad && !db && !probe_no_side && w.p >= 32768 && n_rays <= side_max_rays &&
                               ls2fm_device_cus() >= n_waiters;      // (>= 4 workgroups of this launch fit a CU: 4x the slots)
     SideJobs sj{};
     if (side_in_fill) {
