@@ -219,24 +219,19 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     };
     float val[DUAL ? 1 : 16];                                // single field: the pairs' explicit corner values
     float fa[DUAL ? 4 : 1][2], fb[DUAL ? 4 : 1][2], fcc[DUAL ? 4 : 1][2];       // dual field, factored items
-#ifndef LS2FM_FILL_SINGLE_LATE_VAL
-#define LS2FM_FILL_SINGLE_LATE_VAL 0
-#endif
-    auto single_values = [&]() {
+    if constexpr (!DUAL) {
+        // (formed here, ahead of the barriers; behind them -- as in rounds 1-5 -- measured the same: 66.5 vs 66.6 us)
         const float px0 = 1.0f - w[0];
 #pragma unroll
         for (unsigned c = 0; c < 4; ++c) {
             float a[2], b[2], cc[2];
             pair_factors(c, a, b, cc);
-            val[(DUAL ? 0 : 4) * c + 0] = fmaf(px0, a[0], -b[0]);
-            val[(DUAL ? 0 : 4) * c + (DUAL ? 0 : 1)] = fmaf(px0, a[1], -b[1]);
-            val[(DUAL ? 0 : 4) * c + (DUAL ? 0 : 2)] = fmaf(w[0], a[0], b[0]);
-            val[(DUAL ? 0 : 4) * c + (DUAL ? 0 : 3)] = fmaf(w[0], a[1], b[1]);
+            val[4 * c + 0] = fmaf(px0, a[0], -b[0]);
+            val[4 * c + 1] = fmaf(px0, a[1], -b[1]);
+            val[4 * c + 2] = fmaf(w[0], a[0], b[0]);
+            val[4 * c + 3] = fmaf(w[0], a[1], b[1]);
         }
-        if (rf.cont != 0ull) run_sums<DUAL ? 1 : 16>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
-    };
-    if constexpr (!DUAL) {
-        if (!LS2FM_FILL_SINGLE_LATE_VAL) single_values();
+        if (rf.cont != 0ull) run_sums<16>(val, rf.cont, lane);          // wave-uniform: this wave has runs to merge
     } else if (!expl) {
 #pragma unroll
         for (unsigned c = 0; c < 4; ++c) pair_factors(c, fa[c], fb[c], fcc[c]);
@@ -275,7 +270,6 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     if constexpr (!DUAL) {
         // ---- single field: 20-byte explicit items, ONE staging area for all of them (26 KB): ranked and staged in one pass
         // over the pairs (the windowed form below enumerates them once more: 52 -> 57 us)
-        if (LS2FM_FILL_SINGLE_LATE_VAL) single_values();
         if (rf.head) {
 #pragma unroll
             for (unsigned c = 0; c < 4; ++c)

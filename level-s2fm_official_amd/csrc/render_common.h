@@ -291,16 +291,13 @@ constexpr int kSideFlagInts = 4096;
 constexpr int kWgFlagsAt = (WgLayout::total + 63) / 64 * 64;
 constexpr int kWgBlockFloats = kWgFlagsAt + kSideFlagInts;
 
-// rows of the per-sample SoA arrays are p_pad floats apart: at the benchmark's 131 072 samples that is a power of two, and the 32
-// rows a wave of the shading kernels reads lie exactly 512 KB apart.  LS2FM_ROW_SKEW (floats, a multiple of 64) de-tunes the stride.
-static inline int64_t ls2fm_row_skew() {
-    static const int64_t skew = [] { const char* e = getenv("LS2FM_ROW_SKEW"); const int64_t v = e ? atoll(e) : 0; return v / 64 * 64; }();
-    return skew;
-}
+// (rows of the per-sample SoA arrays are p_pad floats apart: at the benchmark's 131 072 samples a power of two, the 32 rows a wave of
+// the shading kernels reads lie exactly 512 KB apart.  De-tuning the stride by 64 / 192 / 1088 floats was measured in round 6: no
+// effect on any kernel -- the memory system hashes its channels.)
 static inline WsLayout make_ws_layout(int64_t n_rays, int n_samples, int l1, int l2, int dual) {
     WsLayout w;
     w.p = n_rays * n_samples;
-    w.p_pad = (w.p + 63) / 64 * 64 + ls2fm_row_skew();
+    w.p_pad = (w.p + 63) / 64 * 64;
     w.r_pad = (n_rays + 63) / 64 * 64;
     w.l1 = l1; w.l2 = l2; w.dual = dual;
     int64_t o = 0;
