@@ -531,7 +531,7 @@ def main():
         # HBM-side bytes of that kernel: PMC counters cannot be read from inside the process; the committed counter summary of
         # this same command (profiles/, collected per MI355X_MICROARCH.md: separate --pmc passes) is QUOTED when the workload
         # is the default one -- with the commit it was measured at, so a stale figure is recognisable
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(q)), "")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")) if os.path.exists(q)), "")
         if roofline and os.path.exists(pmc) and (args.rays, args.samples, args.dataset, dual) == (1024, 128, "ETH3D", True):
             doc = json.load(open(pmc))
             if roofline["kernel"].startswith("scatter_pair") and "scatter_fill" in doc and "slab_accumulate" in doc:
@@ -554,7 +554,12 @@ def main():
                 "hbm": {"bytes_per_ray": bytes_per_pt * args.samples, "achieved": n_pts * bytes_per_pt / step_s / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": n_pts * bytes_per_pt / step_s / 1e9 / HBM_PEAK_GBS},
                 "mfma": {"flops_per_ray": flops_per_pt * args.samples, "achieved": n_pts * flops_per_pt / step_s / 1e12,
-                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": n_pts * flops_per_pt / step_s / 1e12 / F32_PEAK_TFLOPS}}
+                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": n_pts * flops_per_pt / step_s / 1e12 / F32_PEAK_TFLOPS,
+                         # SURVEY 8d's per-sample figure counts the UN-collapsed radiance decoder; the kernels execute the collapsed
+                         # affine map (and the fused weight gradients): the fraction by the FLOPs actually executed
+                         "useful_flops_per_step": roofline.get("useful_flops_per_step"),
+                         "useful_achieved": roofline.get("useful_flops_per_step", 0.0) / step_s / 1e12,
+                         "useful_frac": roofline.get("useful_flops_per_step", 0.0) / step_s / 1e12 / F32_PEAK_TFLOPS}}
     if args.inference and roofline:
         roofline.pop("whole_step", None)        # (the whole-step figures are the training step's)
     out = {

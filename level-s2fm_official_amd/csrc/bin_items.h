@@ -33,7 +33,7 @@ constexpr int kMaxParts = 16;
 typedef unsigned long long u64;
 
 // -DLS2FM_ITEM_PROBE24 (round 6, TIMING PROBE, wrong second-grid gradients): the dual item WITHOUT its second-grid words -- 24 bytes --
-// with LS2FM_EXPLICIT_LEVELS=0: what the fill / accumulate pair would take if an item were a quarter smaller (profiles/r06_item_bytes_probe.txt)
+// with LS2FM_EXPLICIT_LEVELS=0: what the fill / accumulate pair would take if an item were a quarter smaller (profiles/r06_notes.md section 2)
 #ifdef LS2FM_ITEM_PROBE24
 struct __attribute__((aligned(8))) Item {
     uint32_t ij;

@@ -128,7 +128,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     // stores at all: 70 of 90 us) showed the kernel bound by its own instruction count, not by its stores.
     // LS2FM_FILL_COUNT_{DUAL,SINGLE}: 1 (default) = counted here, in the ONE hash pass, with LDS atomics; 0 = taken from the scan
     // results as described above (no atomics, one barrier fewer -- but the offsets' loads then have a consumer at the head of the
-    // workgroup's chain instead of at its staging).  Measured at C2 (profiles/r06_ab_fill_count.txt), rounds 1-5's separate counting
+    // workgroup's chain instead of at its staging).  Measured at C2 (profiles/r06_notes.md section 3, profiles/r06_raw/c16_*), rounds 1-5's separate counting
     // pass | from the scan rows | counted in the hash pass:  dual field 87.0 | 84.3 | 81.2 us;  single field 64.0 | 66.8 | 63.7 us.
 #ifndef LS2FM_FILL_COUNT_DUAL
 #define LS2FM_FILL_COUNT_DUAL 1

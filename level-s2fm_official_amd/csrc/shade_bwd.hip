@@ -205,7 +205,7 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
 // of 2 waves per CU.  (A workgroup walking several rays and keeping one partial was tried first: the loop-invariant kernel
 // arguments it keeps in scalar registers across the loop spill into vector registers -- 92 .. 136 B of scratch per lane.)
 // (This kernel has two run-time modes on MI355X -- 121-123 and 132-135 us at C2, 85 / 97 us single field -- that flip between
-// processes and between phases of one process.  Measured and ruled out in round 6 (profiles/r06_shade_bwd_modes.md): the code's
+// processes and between phases of one process.  Measured and ruled out in round 6 (profiles/r06_notes.md section 6): the code's
 // alignment (kernel aligned to 1 / 4 / 64 KB), instruction-cache misses (identical counters in both modes), the rows' power-of-two
 // stride (LS2FM_ROW_SKEW), which library build is loaded.)
 template <bool DUAL, int MAXT, bool POSE, bool WG>

@@ -104,4 +104,8 @@ def dominant_kernel_roofline(lib, n_points: int, dual: bool, hbm_peak_gbs: float
         "algorithmic_per_launch": amount,
         "all_kernels_avg_us": {k: round(v[0], 2) for k, v in sorted(times.items(), key=lambda kv: -kv[1][2])},
         "all_kernels_frac_of_peak": _fractions(times, work, hbm_peak_gbs, f32_peak_tflops),
+        # FLOPs the dense kernels of one step actually EXECUTE (collapsed radiance decoder, fused weight gradients): what a whole-step
+        # MFMA fraction may be credited with (SURVEY 8d's 115 kFLOP per sample counts the un-collapsed decoder, which nothing runs)
+        "useful_flops_per_step": float(sum(work[k][1] for k in ("shade_fwd", "shade_bwd", "wgrad_mlp_sdf", "wgrad_mlp_geo")
+                                           if k in times and k in work)),
     }

@@ -17,6 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MO
 done
 mv gpurun_out/${TAG}_pmc_FETCH_SIZE.txt gpurun_out/${TAG}_pmc_fetch.txt; mv gpurun_out/${TAG}_pmc_WRITE_SIZE.txt gpurun_out/${TAG}_pmc_write.txt
 mv gpurun_out/${TAG}_pmc_TCC_HIT_sum_.txt gpurun_out/${TAG}_pmc_l2.txt; mv gpurun_out/${TAG}_pmc_SQ_INSTS_VAL.txt gpurun_out/${TAG}_pmc_mfma.txt
+mkdir -p profiles; python tools/pmc_to_json.py ${TAG} ${LS2FM_COMMIT:-unknown} > /dev/null 2>&1; cp profiles/${TAG}_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 for c in C1 C3 C4 C5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/${TAG}_bench_$c.json 2>/dev/null; done
 python bench.py --inference --rays 8192 --no-cpu-baseline > gpurun_out/${TAG}_bench_inference_8192rays.json 2>/dev/null
@@ -28,6 +29,9 @@ python bench.py --with-update --no-cpu-baseline > gpurun_out/${TAG}_bench_with_u
 # metric's step: fwd + bwd + all-reduce, launched like N = 1) eager and captured, and the opt-in sharded form
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_auto.json 2>/dev/null
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch eager > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_eager.json 2>/dev/null
+LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph --capture-overlap > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_graph_level_groups.json 2>/dev/null
+rocprofv3 --kernel-trace -d gpurun_out/tl -- env LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph --capture-overlap --steps 50 --warmup 10 >/dev/null 2>&1
+python tools/prof_timeline.py gpurun_out/tl 30 > gpurun_out/${TAG}_timeline_graph_replay_1rank_rccl_level_groups.txt; rm -rf gpurun_out/tl
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --launch graph > gpurun_out/${TAG}_bench_1rank_rccl_allreduce_graph.json 2>/dev/null
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic.json 2>/dev/null
 LS2FM_DIST_SINGLE=1 python bench.py --force-dist --no-cpu-baseline --shard --launch graph > gpurun_out/${TAG}_bench_1rank_rccl_shard_monolithic_graph.json 2>/dev/null

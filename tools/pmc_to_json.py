@@ -35,5 +35,10 @@ doc = {"_about": "HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WR
        "_commit": commit}
 for name in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
     doc[name] = {"fetch_raw": fetch.get(name, 0.0), "fetch": 2 * fetch.get(name, 0.0), "write": write.get(name, 0.0)}
+if "scatter_fill" in doc and "slab_accumulate" in doc:
+    # the table-gradient scatter AS LAUNCHED: both passes with everything that rides in them (the weight-gradient tail's jobs inside
+    # the fill launch, the split slabs' combine inside the accumulate launch) -- what the pair's roofline.traffic is quoted from
+    doc["scatter_pair_as_launched"] = {k: doc["scatter_fill"][k] + doc["slab_accumulate"][k] for k in ("fetch_raw", "fetch", "write")}
+    doc["scatter_pair_as_launched"]["total"] = doc["scatter_pair_as_launched"]["fetch"] + doc["scatter_pair_as_launched"]["write"]
 json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in doc.items() if not k.startswith("_")}, indent=1)[:1500])
