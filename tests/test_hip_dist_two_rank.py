@@ -19,6 +19,33 @@ def _free_port():
         return s.getsockname()[1]
 
 
+_TRANSIENT = ("Address already in use", "Connection refused", "Connection reset", "connect() timed out", "unhandled system error",
+              "ncclSystemError", "ncclUnhandledCudaError", "store", "Socket Timeout")
+
+
+def _spawn(fn, args, nprocs, port_at=1):
+    """mp.spawn with ONE retry for failures of the rendezvous / communicator set-up (a spawned process group on a box that has just
+    torn another one down: seen once in ~80 spawns of a full-suite run, never in isolation) -- on a fresh port.  An assertion of the
+    worker (a NUMERIC disagreement) is never retried.  Every first failure is written to gpurun_out/flaky_dist.txt."""
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+        return
+    except Exception as e:                                        # noqa: BLE001
+        text = f"{type(e).__name__}: {e}"
+        try:
+            out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "flaky_dist.txt"), "a") as f:
+                f.write(f"==== {fn.__name__} {args}\n{text}\n")
+        except OSError:
+            pass
+        if "AssertionError" in text or not any(t in text for t in _TRANSIENT):
+            raise
+    args = list(args)
+    args[port_at] = _free_port()
+    mp.spawn(fn, args=tuple(args), nprocs=nprocs, join=True)
+
+
 def _step(opt, sdf, rad, ren, head, center, ray, gt, dref, masks):
     for p in list(sdf.parameters()) + list(rad.parameters()):
         p.grad = None
@@ -88,7 +115,7 @@ def _worker(rank, world, port, overlap, out_dir, backend="gloo"):
 
 @pytest.mark.parametrize("overlap", [False, True])
 def test_two_ranks_one_gpu_reproduce_the_single_process_gradients(overlap, tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), overlap, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), overlap, str(tmp_path)), 2)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
@@ -147,14 +174,14 @@ def _capture_overlap_worker(rank, world, port, out_dir):
 
 
 def test_one_rank_rccl_level_group_reductions_inside_a_capture(tmp_path):
-    mp.spawn(_capture_overlap_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _spawn(_capture_overlap_worker, (1, _free_port(), str(tmp_path)), 1)
     assert (tmp_path / "ok0").exists()
 
 
 def test_one_rank_rccl_overlapped_reduction(tmp_path):
     """the same step through a real RCCL communicator (world size 1: all this box allows): the overlapped reduction's streams,
     events, coalesced launches and async handles run against the backend the multi-GPU bench uses; the sums are identities"""
-    mp.spawn(_worker, args=(1, _free_port(), True, str(tmp_path), "nccl"), nprocs=1, join=True)
+    _spawn(_worker, (1, _free_port(), True, str(tmp_path), "nccl"), 1)
     assert (tmp_path / "ok0").exists()
 
 
@@ -222,7 +249,7 @@ def _stage_worker(rank, world, port, out_dir, backend, async_gather, shard_group
 
 @pytest.mark.parametrize("async_gather", [False, True])
 def test_two_ranks_sharded_stage_matches_single_process_trajectory(async_gather, tmp_path):
-    mp.spawn(_stage_worker, args=(2, _free_port(), str(tmp_path), "gloo", async_gather), nprocs=2, join=True)
+    _spawn(_stage_worker, (2, _free_port(), str(tmp_path), "gloo", async_gather), 2)
     assert (tmp_path / "stage_ok0").exists() and (tmp_path / "stage_ok1").exists()
 
 
@@ -230,7 +257,7 @@ def test_two_ranks_sharded_stage_matches_single_process_trajectory(async_gather,
 def test_two_ranks_pipelined_sharded_stage_matches_single_process_trajectory(async_gather, tmp_path):
     """ShardedAdam(n_groups = 2) under RenderStage: a traced-depth node rides in the render's backward, so the per-group chain
     (reduce-scatter -> Adam on the slice -> all-gather, small tensors replicated) is issued at step(); same 8-step trajectory"""
-    mp.spawn(_stage_worker, args=(2, _free_port(), str(tmp_path), "gloo", async_gather, 2), nprocs=2, join=True)
+    _spawn(_stage_worker, (2, _free_port(), str(tmp_path), "gloo", async_gather, 2), 2)
     assert (tmp_path / "stage_ok0").exists() and (tmp_path / "stage_ok1").exists()
 
 
@@ -320,21 +347,21 @@ def _pipelined_worker(rank, world, port, out_dir, backend, n_groups):
 
 @pytest.mark.parametrize("n_groups", [2, 3])
 def test_two_ranks_pipelined_exchange_from_inside_the_backward(n_groups, tmp_path):
-    mp.spawn(_pipelined_worker, args=(2, _free_port(), str(tmp_path), "gloo", n_groups), nprocs=2, join=True)
+    _spawn(_pipelined_worker, (2, _free_port(), str(tmp_path), "gloo", n_groups), 2)
     assert (tmp_path / "pipe_ok0").exists() and (tmp_path / "pipe_ok1").exists()
 
 
 def test_one_rank_rccl_pipelined_exchange(tmp_path):
     """the pipelined form against a real RCCL communicator (world size 1): reduce_scatter_tensor / all_gather_into_tensor per
     level group on the communication stream, events recorded inside ls2fm_render_bwd, Adam on the communication stream"""
-    mp.spawn(_pipelined_worker, args=(1, _free_port(), str(tmp_path), "nccl", 2), nprocs=1, join=True)
+    _spawn(_pipelined_worker, (1, _free_port(), str(tmp_path), "nccl", 2), 1)
     assert (tmp_path / "pipe_ok0").exists()
 
 
 def test_one_rank_rccl_sharded_stage(tmp_path):
     """the sharded step's collectives (reduce_scatter_tensor, all_gather_into_tensor in place, the communication stream) against
     a real RCCL communicator (world size 1: all this box allows)"""
-    mp.spawn(_stage_worker, args=(1, _free_port(), str(tmp_path), "nccl", True), nprocs=1, join=True)
+    _spawn(_stage_worker, (1, _free_port(), str(tmp_path), "nccl", True), 1)
     assert (tmp_path / "stage_ok0").exists()
 
 
@@ -402,7 +429,7 @@ def _loop_worker(rank, world, port, out_dir, backend, which, capture):
 
 @pytest.mark.parametrize("which", ["ba", "refine"])
 def test_two_ranks_view_sharded_loops_match_the_single_process_trajectory(which, tmp_path):
-    mp.spawn(_loop_worker, args=(2, _free_port(), str(tmp_path), "gloo", which, False), nprocs=2, join=True)
+    _spawn(_loop_worker, (2, _free_port(), str(tmp_path), "gloo", which, False), 2)
     assert (tmp_path / "loop_ok0").exists() and (tmp_path / "loop_ok1").exists()
 
 
@@ -411,5 +438,5 @@ def test_one_rank_rccl_captured_loops(which, tmp_path):
     """the CAPTURED iteration under a real RCCL communicator (world size 1: what this box allows): the loss-count, trip-count and
     gradient all-reduces are recorded into the iteration's hipGraph (tracings on the capturing stream: no side-stream branch forks
     again into RCCL's stream) -- same trajectory as the captured single-process loop"""
-    mp.spawn(_loop_worker, args=(1, _free_port(), str(tmp_path), "nccl", which, True), nprocs=1, join=True)
+    _spawn(_loop_worker, (1, _free_port(), str(tmp_path), "nccl", which, True), 1)
     assert (tmp_path / "loop_ok0").exists()
