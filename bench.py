@@ -226,6 +226,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU, on the CPUs of the GPU's NUMA node -- BEFORE the HIP runtime initialises (ls2fm/numa.py: the host memory it
+    # sets up then is read by running kernels; `shade_bwd` takes 123 us from the GPU's node and 135 us from the other socket's).
+    # What a launcher's `numactl --cpunodebind` does; LS2FM_NUMA_BIND=0 leaves the placement to the scheduler.
+    from ls2fm.numa import bind_to_gpu_numa_node
+    numa_node = bind_to_gpu_numa_node(local_rank if os.environ.get("LS2FM_BENCH_BACKEND", "nccl") == "nccl" else 0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path); the CPU figure is the "
                          "`cpu_baseline` leg of the GPU run")
@@ -576,6 +581,7 @@ def main():
                    "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "dual_field": dual,
                    "parallelism": f"dp{world} (rays sharded by view)"},
         "roofline": roofline,
+        "host_numa_node": numa_node,         # the GPU's NUMA node this process was bound to before the runtime started (None: not bound)
     }
     if exchange is not None:
         out["exchange"] = exchange

@@ -204,10 +204,10 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
 // WG: weight gradients contracted here (header, 3.), one partial per ray.  MAXT = 128: rays of up to 128 samples, 4 workgroups
 // of 2 waves per CU.  (A workgroup walking several rays and keeping one partial was tried first: the loop-invariant kernel
 // arguments it keeps in scalar registers across the loop spill into vector registers -- 92 .. 136 B of scratch per lane.)
-// (This kernel has two run-time modes on MI355X -- 121-123 and 132-135 us at C2, 85 / 97 us single field -- that flip between
-// processes and between phases of one process.  Measured and ruled out in round 6 (profiles/r06_notes.md section 6): the code's
-// alignment (kernel aligned to 1 / 4 / 64 KB), instruction-cache misses (identical counters in both modes), the rows' power-of-two
-// stride (LS2FM_ROW_SKEW), which library build is loaded.)
+// (This kernel has two run-time modes on MI355X -- 121-126 and 132-137 us at C2, 85 / 97 us single field -- set by the NUMA node the
+// host process INITIALISES on: the GPU's socket or the other one (profiles/r06_notes.md section 6; not the code's alignment, not
+// instruction-cache misses, not the rows' stride, not the workspace's placement, not the stream).  ls2fm/numa.py binds a process to
+// its GPU's node.)
 template <bool DUAL, int MAXT, bool POSE, bool WG>
 __global__ void __launch_bounds__(MAXT, WG ? LS2FM_BWD_WAVES_WG : 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,

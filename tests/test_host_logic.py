@@ -288,3 +288,19 @@ def test_level_table_of_every_dataset_preset_matches_the_written_out_values(data
     assert sensitive == {"DTU": [], "ETH3D": [15], "BlendedMVS": [15], "scannet": [5, 10, 15]}[dataset]
     if dataset == "ETH3D":
         assert ref["levels"][15]["resolutions_within_libm_envelope"] == [10240, 10241] and int(d.resolution[15]) == 10241
+
+
+def test_numa_binding_is_safe_without_a_gpu_topology(monkeypatch):
+    """ls2fm.numa (round 6): the NUMA binding of a GPU process reads sysfs only and changes nothing when the topology is not there
+    (this container) or the switch is off"""
+    from ls2fm import numa
+    assert numa._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    before = os.sched_getaffinity(0)
+    monkeypatch.setenv("LS2FM_NUMA_BIND", "0")
+    assert numa.bind_to_gpu_numa_node(0) is None and os.sched_getaffinity(0) == before
+    monkeypatch.delenv("LS2FM_NUMA_BIND")
+    node = numa.gpu_numa_node(0)
+    if node is None:                                       # no KFD topology here: nothing is bound
+        assert numa.bind_to_gpu_numa_node(0) is None and os.sched_getaffinity(0) == before
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")            # a UUID form: not resolved, not an error
+    assert numa.gpu_numa_node(0) is None
