@@ -3,6 +3,8 @@ scene box via the DTU preset, 2 views x 512 rays x 128 samples, dual field, 256 
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "level-s2fm_official_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from ls2fm.numa import bind_to_gpu_numa_node
+bind_to_gpu_numa_node(0)          # (the GPU's NUMA node, before the runtime starts: ls2fm/numa.py)
 import torch
 import bench
 from ls2fm import stage

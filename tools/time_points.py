@@ -3,6 +3,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "level-s2fm_official_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ls2fm.numa import bind_to_gpu_numa_node
+bind_to_gpu_numa_node(0)          # (the GPU's NUMA node, before the runtime starts: ls2fm/numa.py)
 import torch
 from bench import randomize
 from ls2fm.options import make_options
