@@ -226,9 +226,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # one process per GPU, on the CPUs of the GPU's NUMA node -- BEFORE the HIP runtime initialises (ls2fm/numa.py: the host memory it
-    # sets up then is read by running kernels; `shade_bwd` takes 123 us from the GPU's node and 135 us from the other socket's).
-    # What a launcher's `numactl --cpunodebind` does; LS2FM_NUMA_BIND=0 leaves the placement to the scheduler.
+    # one process per GPU, on the CPUs of the GPU's NUMA node -- BEFORE the HIP runtime initialises (ls2fm/numa.py): what a launcher's
+    # `numactl --cpunodebind` does.  (Until round 6 `shade_bwd` depended on it -- its waves read the dispatch packet in host memory:
+    # 123 us from the GPU's node, 135 from the other socket; now 115 us from either, LS2FM_NUMA_BIND=0 measures the same.)
     from ls2fm.numa import bind_to_gpu_numa_node
     numa_node = bind_to_gpu_numa_node(local_rank if os.environ.get("LS2FM_BENCH_BACKEND", "nccl") == "nccl" else 0)
     if not torch.cuda.is_available():

@@ -23,7 +23,8 @@ pose_grad_kernel(FieldC fc, LevelSet lv1, LevelSet lv2, int dual, WsLayout w, co
     __shared__ float s_red[MAXT / 64][6];
     const int N = fc.n_samples;
     const int64_t r = blockIdx.x;
-    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    // (derived, not blockDim.x: the compiler read that from the dispatch packet -- host memory, shade_bwd.hip)
+    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = ((N + 63) / 64 * 64) >> 6;
     const bool live = n < N;
     const int nn = live ? n : N - 1;
     const int64_t i = r * N + nn;
@@ -115,7 +116,7 @@ pose_grad_kernel(FieldC fc, LevelSet lv1, LevelSet lv2, int dual, WsLayout w, co
         float sc = 0.f, sr = 0.f;
         for (int q = 0; q < n_waves; ++q) { sc += s_red[q][a]; sr += s_red[q][3 + a]; }
         // view embedding [d, sin(f d), cos(f d)] (models/base.py:143-151) through the collapsed decoder columns 6..32
-        const float da = gm.d[a];
+        const float da = a == 0 ? gm.d[0] : (a == 1 ? gm.d[1] : gm.d[2]);      // (selects: a dynamically indexed ray record becomes an LDS alloca indexed by the flat work-item id, read from the dispatch packet in HOST memory: shade_bwd.hip)
         for (int k = 0; k < 3; ++k) {
             const float gz = ws[w.dzr + k * w.r_pad + r];
             float dv = pk->wc[k][6 + a];

@@ -192,6 +192,24 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
         if (st != LS2FM_OK) return st;
         up.loss.d_depth_ref = nullptr;                   // (shade_bwd leaves it alone: the branch is reading it)
     }
+#ifdef LS2FM_DEBUG_PTRS
+    {   // (diagnosis, round 6: which of shade_bwd's pointers is not device memory?)
+        static int once = 0;
+        if (!once++) {
+            auto show = [](const char* name, const void* p) {
+                hipPointerAttribute_t a{};
+                if (!p) { fprintf(stderr, "[ptr] %-12s null\n", name); return; }
+                const hipError_t e = hipPointerGetAttributes(&a, p);
+                if (e != hipSuccess) (void)hipGetLastError();
+                fprintf(stderr, "[ptr] %-12s %p  err %d  type %d  device %d  managed %d\n", name, p, (int)e, (int)a.type, a.device, (int)a.isManaged);
+            };
+            show("center", center); show("ray", ray); show("ws", ws); show("pk", pk);
+            show("rgb_gt", up.loss.rgb_gt); show("depth_ref", up.loss.depth_ref); show("weights", up.loss.weights); show("sums", up.loss.sums);
+            show("d_terms", up.loss.d_terms); show("d_total", up.loss.d_total); show("d_depth_ref", up.loss.d_depth_ref);
+            show("sdf_table", grads->sdf_table); show("beta", grads->beta);
+        }
+    }
+#endif
     ls2fm_prof_begin(LS2FM_PROF_SHADE_BWD, s);
     // (leading workgroups of this launch zero the weight-gradient accumulators and the atomically flushed table ranges)
     // the MLPs' weight gradients are contracted inside shade_bwd (LS2FM_FUSED_WGRAD=0: round 4's separate wgrad_mlp launches,

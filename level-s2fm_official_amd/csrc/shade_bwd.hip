@@ -204,10 +204,9 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
 // WG: weight gradients contracted here (header, 3.), one partial per ray.  MAXT = 128: rays of up to 128 samples, 4 workgroups
 // of 2 waves per CU.  (A workgroup walking several rays and keeping one partial was tried first: the loop-invariant kernel
 // arguments it keeps in scalar registers across the loop spill into vector registers -- 92 .. 136 B of scratch per lane.)
-// (This kernel has two run-time modes on MI355X -- 121-126 and 132-137 us at C2, 85 / 97 us single field -- set by the NUMA node the
-// host process INITIALISES on: the GPU's socket or the other one (profiles/r06_notes.md section 6; not the code's alignment, not
-// instruction-cache misses, not the rows' stride, not the workspace's placement, not the stream).  ls2fm/numa.py binds a process to
-// its GPU's node.)
+// (Rounds 5-6: this kernel had two run-time modes on MI355X -- 121-126 and 132-137 us at C2, 85 / 97 us single field -- set by the NUMA
+// node the host process initialised on.  Cause, found in round 6 (profiles/r06_notes.md section 6): its waves read the DISPATCH PACKET,
+// which lives in host memory -- see n_threads / dz_g below.  Without those reads: 115 us (74.5 single field) from either socket.)
 template <bool DUAL, int MAXT, bool POSE, bool WG>
 __global__ void __launch_bounds__(MAXT, WG ? LS2FM_BWD_WAVES_WG : 2)
 shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
@@ -219,8 +218,14 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     constexpr int kUnrollM = WG ? 4 : 1;         // the accumulators of a hidden block are registers: its loop is unrolled
     // leading workgroups: the zero fills the rest of the backward needs (weight-gradient accumulators, point-split coarse
     // levels of the gradient tables) -- no memset / kernel launches and no cross-stream edge in front of the scatter
+    // The workgroup size is DERIVED (the launcher's formula), never read as blockDim.x.  Round 6: in the fused-weight-gradient
+    // variants the compiler fetched blockDim.x from the DISPATCH PACKET (`.amdhsa_user_sgpr_dispatch_ptr 1`; the other variants take
+    // it from the hidden kernel arguments) -- the AQL queue lives in HOST memory: ~290 uncached 32-byte reads over PCIe per launch
+    // (TCC_EA0_RDREQ_IO_32B; every other kernel of the step: 0), one on every workgroup's critical path at the head of its MFMA part.
+    // That is what made the kernel 123 us from the GPU's NUMA node and 135 us from the other socket (profiles/r06_notes.md section 6).
+    const int n_threads = (fc.n_samples + 63) / 64 * 64;
     if ((int)blockIdx.x < zero.blocks) {
-        zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+        zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, n_threads);
         return;
     }
     __shared__ float s_part[MAXT / 64][8];
@@ -235,7 +240,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     __shared__ __attribute__((aligned(16))) float s_t[WG ? MAXT / 64 : 1][WG ? NC * kTRows * kTLd : 4];   // wave-private transpose tiles
     static_assert(kRegsSdf * 64 <= kSwWg && kRegsGeo * 64 <= kSwWg && kMfmaBwdGeoFloats <= kSwWg, "register sums / second field's weights fit in s_w");
     const int N = fc.n_samples;
-    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
+    const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = n_threads >> 6;
     const int64_t r = (int64_t)blockIdx.x - zero.blocks;
     const int jl = lane & 15, g = lane >> 4;
     const int64_t P = w.p_pad;
@@ -251,13 +256,13 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         const float4* src = reinterpret_cast<const float4*>(&pk->bs);
         float4* dst = reinterpret_cast<float4*>(s_w);
         constexpr int n_stage = WG ? kMfmaBwdSdfFloats - 4 * 4 * 64 : kMfmaBwdSdfFloats;       // (w10 is the last member)
-        for (int q = n; q < n_stage / 4; q += blockDim.x) dst[q] = src[q];
+        for (int q = n; q < n_stage / 4; q += n_threads) dst[q] = src[q];
         if (WG && n < 64) s_w[n_stage + n] = pk->bs.w10[n >> 4][n & 3][16 * ((n >> 2) & 3)];      // W1[0][hidden unit n]
     }
     if (n < 32) s_bound[n] = 0;
     // the decoder's feature columns, read per lane (o = 4t + g) in every tile: from LDS (one base register + immediate offsets;
     // as global loads the compiler kept fifteen 64-bit addresses alive across the tile loop -- and spilled them)
-    for (int q = n; q < 3 * 68; q += blockDim.x) (&s_wc[0][0])[q] = (&pk->wc[0][0])[q];
+    for (int q = n; q < 3 * 68; q += n_threads) (&s_wc[0][0])[q] = (&pk->wc[0][0])[q];
 
     // =========================================================================== 1. one thread per sample
     {
@@ -476,7 +481,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         __syncthreads();          // every wave is done with the SDF weights
         const float4* src = reinterpret_cast<const float4*>(&pk->bg);
         float4* dst = reinterpret_cast<float4*>(s_w);
-        for (int q = n; q < kMfmaBwdGeoFloats / 4; q += blockDim.x) dst[q] = src[q];
+        for (int q = n; q < kMfmaBwdGeoFloats / 4; q += n_threads) dst[q] = src[q];
         __syncthreads();          // second field's weights staged
     }
     // this lane's levels are the same in every half and column (l = 8 mk + 2 g + hv): keep the running maxima of the
@@ -502,6 +507,11 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
         uint32_t is[NC];                  // point index (32-bit offsets: uniform base + VGPR offset addressing)
         bool live_c[NC];
         float pw[NC][3], xg[NC][3], dz[NC][3], gns[NC][3], gnk[NC][3], gsdf[NC];
+        // this lane GROUP's component (g < 3) of dz and of kappa g_n, picked where the values still sit in LDS.  (Picked later from the
+        // register arrays -- `g == 0 ? dz[cc][0] : ...` -- the compiler folded the selects into ONE dynamically addressed load of a
+        // private array, promoted that array to LDS indexed by the flat work-item id, and read the workgroup's sizes for it from the
+        // dispatch packet in HOST memory: the kernel's NUMA dependence, n_threads above.)
+        float dz_g[NC], gnk_g[NC];
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
             const int sl = 64 * wave + 16 * (NC * half + cc) + jl;       // sample slot in the workgroup
@@ -517,6 +527,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 gns[cc][a] = gnk[cc][a] * fc.inv_ext[a];
             }
             gsdf[cc] = y[6];
+            dz_g[cc] = y[g < 3 ? g : 0];
+            gnk_g[cc] = fc.kappa * y[3 + (g < 3 ? g : 0)];
         }
         float ub[9][NC];
 #pragma unroll
@@ -536,17 +548,21 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 const bool on = ch < ch1;
                 ub[t][cc] = on ? f_e1[(uint32_t)ch * P32 + is[cc]] : 0.f;
                 // J rows are [channel][point][3]: one 12-byte load per (channel, sample)
-                struct __attribute__((aligned(4))) J3 { float v[3]; };
-                J3 jv{{0.f, 0.f, 0.f}};
-                if (on) jv = *reinterpret_cast<const J3*>(f_j1 + ((uint32_t)ch * P32 + is[cc]) * 3u);
-                float acc = 0.f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) acc = fmaf(jv.v[a], gns[cc][a], acc);
+                // (a 4-byte-aligned 3-vector, NOT a struct of float[3]: the conditionally assigned struct stayed an alloca, which the
+                // compiler promoted to LDS indexed by the FLAT work-item id -- and for that it read the workgroup's y / z sizes from the
+                // dispatch packet, i.e. from host memory, on every workgroup's critical path: round 6, n_threads above)
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                typedef f32x3 f32x3_a4 __attribute__((aligned(4)));
+                f32x3 jv = {0.f, 0.f, 0.f};
+                if (on) jv = *reinterpret_cast<const f32x3_a4*>(f_j1 + ((uint32_t)ch * P32 + is[cc]) * 3u);
+                float acc = fmaf(jv.x, gns[cc][0], 0.f);
+                acc = fmaf(jv.y, gns[cc][1], acc);
+                acc = fmaf(jv.z, gns[cc][2], acc);
                 vb[t][cc] = acc;
             }
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
-            const float kg = g == 0 ? gnk[cc][0] : (g == 1 ? gnk[cc][1] : gnk[cc][2]);
+            const float kg = gnk_g[cc];
             vb[8][cc] = g < 3 ? kg / fc.rescale : 0.f;
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
@@ -580,7 +596,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
                 if (g < 3) {
                     const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
                     (out + w.p3)[(uint32_t)g * P32 + is[cc]] = pg;
-                    (out + w.dz)[(uint32_t)g * P32 + is[cc]] = g == 0 ? dz[cc][0] : (g == 1 ? dz[cc][1] : dz[cc][2]);
+                    (out + w.dz)[(uint32_t)g * P32 + is[cc]] = dz_g[cc];
                 }
             }
 

@@ -1,12 +1,12 @@
 """Process placement: run on the CPUs of the GPU's NUMA node.
 
-Measured on MI355X (profiles/r06_notes.md section 6): the host memory the HIP runtime sets up when a process initialises lands on the
-NUMA node of the thread that touches it first, and `shade_bwd` -- one round of workgroups whose duration is a workgroup's latency --
-runs 123 us when that node is the GPU's and 135 us when it is the other socket's (single field 85 / 97 us), for the same binary,
-whatever stream, whatever the workspace's placement; moving the process AFTER initialisation changes little.  Kernel arguments are not it
-(HIP_FORCE_DEV_KERNARG=1 changes nothing).  One process per GPU, pinned to the GPU's node BEFORE the runtime initialises, is what a
-launcher's `numactl --cpunodebind` does; this module does it from inside the process, without touching the HIP runtime: the GPU's PCI
-address comes from the KFD topology in sysfs.
+Measured on MI355X (profiles/r06_notes.md section 6): the host memory the HIP runtime sets up when a process initialises -- the AQL
+queues among it -- lands on the NUMA node of the thread that touches it first, and whatever the GPU reads from it pays that node's
+distance: `shade_bwd`, whose waves read the dispatch packet until round 6, ran 123 us from the GPU's node and 135 us from the other
+socket's.  The kernels no longer make such reads (tools/check_host_reads.py keeps it that way), so nothing measured depends on this
+module any more; one process per GPU, pinned to the GPU's node BEFORE the runtime initialises, is still what a launcher's
+`numactl --cpunodebind` does (host-side launch latency, pinned staging buffers), and this module does it from inside the process,
+without touching the HIP runtime: the GPU's PCI address comes from the KFD topology in sysfs.
 
     from ls2fm.numa import bind_to_gpu_numa_node
     bind_to_gpu_numa_node(local_rank)          # before the first torch.cuda / ls2fm call;  LS2FM_NUMA_BIND=0 turns it off

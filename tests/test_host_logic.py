@@ -304,3 +304,16 @@ def test_numa_binding_is_safe_without_a_gpu_topology(monkeypatch):
         assert numa.bind_to_gpu_numa_node(0) is None and os.sched_getaffinity(0) == before
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")            # a UUID form: not resolved, not an error
     assert numa.gpu_numa_node(0) is None
+
+
+def test_no_kernel_reads_through_the_dispatch_or_queue_pointer():
+    """Round 6: the AQL queue lives in HOST memory; a kernel whose descriptor asks for the dispatch (or queue) pointer reads it from its
+    waves over PCIe -- `shade_bwd` did (a private array promoted to LDS, indexed by the flat work-item id: ~290 uncached reads per
+    launch, 123 us from the GPU's NUMA node, 135 us from the other socket).  No kernel of the shipped library may."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_host_reads", os.path.join(ROOT, "tools", "check_host_reads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, n = mod.offenders(_lib.LIB_PATH)
+    assert n > 50, n                      # the parser found the library's kernels
+    assert not bad, bad
