@@ -223,6 +223,9 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     // it from the hidden kernel arguments) -- the AQL queue lives in HOST memory: ~290 uncached 32-byte reads over PCIe per launch
     // (TCC_EA0_RDREQ_IO_32B; every other kernel of the step: 0), one on every workgroup's critical path at the head of its MFMA part.
     // That is what made the kernel 123 us from the GPU's NUMA node and 135 us from the other socket (profiles/r06_notes.md section 6).
+#ifdef LS2FM_BWD_FULL_PROBE        // (experiment: all 32 encoding channels live, known at compile time -- valid for 16-level grids only)
+    ch1 = 32; ch2 = 32;
+#endif
     const int n_threads = (fc.n_samples + 63) / 64 * 64;
     if ((int)blockIdx.x < zero.blocks) {
         zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, n_threads);
