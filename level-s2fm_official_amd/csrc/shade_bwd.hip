@@ -207,9 +207,12 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
 // (Rounds 5-6: this kernel had two run-time modes on MI355X -- 121-126 and 132-137 us at C2, 85 / 97 us single field -- set by the NUMA
 // node the host process initialised on.  Cause, found in round 6 (profiles/r06_notes.md section 6): its waves read the DISPATCH PACKET,
 // which lives in host memory -- see n_threads / dz_g below.  Without those reads: 115 us (74.5 single field) from either socket.)
-template <bool DUAL, int MAXT, bool POSE, bool WG>
+// FULL: all 32 encoding channels of both grids are live (16-level grids: every shipped preset) -- known at compile time, the sixteen
+// per-channel predicates of a tile's operand loads, their exec-mask branches and the zero fills behind them are gone (round 6:
+// shade_bwd 115.0 -> 111.8 us, single field 74.8 -> 72.2; bit-identical).  Instantiated for the fused-weight-gradient form only.
+template <bool DUAL, int MAXT, bool POSE, bool WG, bool FULL = false>
 __global__ void __launch_bounds__(MAXT, WG ? LS2FM_BWD_WAVES_WG : 2)
-shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const Packed* __restrict__ pk,
+shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout w, const Packed* __restrict__ pk,
                  const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ fws,
                  Upstream up, float* __restrict__ out, ZeroJob zero, int64_t n_rays, float* __restrict__ slot_sdf,
                  float* __restrict__ slot_geo) {
@@ -223,9 +226,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1, int ch2, WsLayout w, const
     // it from the hidden kernel arguments) -- the AQL queue lives in HOST memory: ~290 uncached 32-byte reads over PCIe per launch
     // (TCC_EA0_RDREQ_IO_32B; every other kernel of the step: 0), one on every workgroup's critical path at the head of its MFMA part.
     // That is what made the kernel 123 us from the GPU's NUMA node and 135 us from the other socket (profiles/r06_notes.md section 6).
-#ifdef LS2FM_BWD_FULL_PROBE        // (experiment: all 32 encoding channels live, known at compile time -- valid for 16-level grids only)
-    ch1 = 32; ch2 = 32;
-#endif
+    const int ch1 = FULL ? 32 : ch1_arg, ch2 = FULL ? 32 : ch2_arg;
     const int n_threads = (fc.n_samples + 63) / 64 * 64;
     if ((int)blockIdx.x < zero.blocks) {
         zero_job_run(zero, (int)blockIdx.x, (int)threadIdx.x, n_threads);
@@ -972,9 +973,12 @@ int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, i
     float* slot_sdf = ws + w.mpart + pl.slot_sdf;
     float* slot_geo = ws + w.mpart + pl.slot_geo;
     const unsigned grid = (unsigned)(n_rays + zero.blocks);
+    const bool full = ch1 == 32 && (!dual || ch2 == 32);
+#define LS2FM_SHADE_BWD3(DUAL, MAXT, POSE, WG, FULL)                                                                                \
+    shade_bwd_kernel<DUAL, MAXT, POSE, WG, FULL><<<grid, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero, \
+                                                                         n_rays, slot_sdf, slot_geo)
 #define LS2FM_SHADE_BWD2(DUAL, MAXT, POSE, WG)                                                                                \
-    shade_bwd_kernel<DUAL, MAXT, POSE, WG><<<grid, threads, 0, s>>>(fc, lsc, ch1, ch2, w, pk, center, ray, ws, up, ws, zero, \
-                                                                   n_rays, slot_sdf, slot_geo)
+    do { if (WG && full) LS2FM_SHADE_BWD3(DUAL, MAXT, POSE, WG, WG); else LS2FM_SHADE_BWD3(DUAL, MAXT, POSE, WG, false); } while (0)
 #define LS2FM_SHADE_BWD(DUAL, MAXT)                                                                                          \
     do {                                                                                                                    \
         if (fused_wgrad) { if (want_pose) LS2FM_SHADE_BWD2(DUAL, MAXT, true, true); else LS2FM_SHADE_BWD2(DUAL, MAXT, false, true); } \
@@ -984,5 +988,6 @@ int ls2fm_launch_shade_bwd(const FieldC& fc, const LevelScales& lsc, int dual, i
     else      { if (threads <= 128) LS2FM_SHADE_BWD(false, 128); else if (threads <= 256) LS2FM_SHADE_BWD(false, 256); else LS2FM_SHADE_BWD(false, 512); }
 #undef LS2FM_SHADE_BWD
 #undef LS2FM_SHADE_BWD2
+#undef LS2FM_SHADE_BWD3
     return LS2FM_OK;
 }
