@@ -317,3 +317,25 @@ def test_no_kernel_reads_through_the_dispatch_or_queue_pointer():
     bad, n = mod.offenders(_lib.LIB_PATH)
     assert n > 50, n                      # the parser found the library's kernels
     assert not bad, bad
+
+
+def test_hand_issued_loads_stay_untouched_until_their_wait():
+    """Advisor r5: `slab_accumulate_persistent_kernel` issues scalar loads and its unit claim by hand and completes them at a LATER
+    s_waitcnt; the compiler does not know the destination registers are in flight.  `tools/check_async_regs.py` follows every path from
+    each such instruction to its wait in the shipped library's ISA: nothing on the way may read or write the destination (a copy, a
+    spill, a re-use would) -- run on every build, i.e. on every compiler bump."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    spec = importlib.util.spec_from_file_location("check_async_regs", os.path.join(ROOT, "tools", "check_async_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    errors, n_sload, n_atomic = mod.check(_lib.LIB_PATH)
+    assert n_sload >= 16 and n_atomic == 4, (n_sload, n_atomic)       # four template instances, each with the four loads + the claim
+    assert not errors, errors
+    # the walker does flag a copy made before the wait (and follows a taken branch to find it)
+    rows = [(0, "s_load_dword", "s8, s[2:3], 0x0"), (8, "s_cbranch_scc1", "1"), (12, "s_endpgm", ""),
+            (16, "s_mov_b32", "s9, s8"), (20, "s_waitcnt", "lgkmcnt(0)"), (24, "s_add_u32", "s8, s8, 1")]
+    at = {a: i for i, (a, _, _) in enumerate(rows)}
+    bad = mod.walk(rows, at, 0, mod.regs("s8"), lambda a: "lgkmcnt(0)" in a)
+    assert [b[0] for b in bad] == [16], bad
