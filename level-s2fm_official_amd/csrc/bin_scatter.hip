@@ -101,6 +101,12 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         if (job < sj.dec_blocks + sj.l1_jobs + sj.n_red + kFinalizeTasks) side_job_run(sj, job, reinterpret_cast<float*>(s_raw), &s_total);
         return;
     }
+    // issue-priority experiment (round 6, profiles/r06_notes.md section 9): LS2FM_FILL_PRIO = 1: raised until the hash pass is done (a young
+    // workgroup's record loads go out first), 2: raised behind it (a workgroup that has its items staged leaves first).  Default 0.
+#ifndef LS2FM_FILL_PRIO
+#define LS2FM_FILL_PRIO 0
+#endif
+    if (LS2FM_FILL_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     ItemT* __restrict__ g_items = reinterpret_cast<ItemT*>(bm.items);
     // levels are walked last to first: the accumulate launch reads the lists first to last, i.e. most recently written first
     const int y_lv = (int)blockIdx.y - sj.rows, n_lv = (int)gridDim.y - sj.rows;
@@ -236,6 +242,8 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
 #pragma unroll
         for (unsigned c = 0; c < 4; ++c) pair_factors(c, fa[c], fb[c], fcc[c]);
     }
+    if (LS2FM_FILL_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (LS2FM_FILL_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     // ---- the run lengths (counted above, or the first consumer of the loads issued at the top)
     if (kCountHere) __syncthreads();
     if (tid < kBins) {                   // (slab tid: this thread is its only reader and writer here)
@@ -805,12 +813,18 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
             const int last_n = hi_n > lo_n ? hi_n - 1 : lo_n;
             const bool expl_n = DUAL && (more ? cur.expl : nxt.expl);    // (uniform)
             const float* __restrict__ extra_n = bm.extra + (more ? cur.start : nxt.start);
+            // (issue-priority experiment, round 6: LS2FM_ACC_PRIO = 1 raises a wave while it issues the next batch's loads.  Default 0.)
+#ifndef LS2FM_ACC_PRIO
+#define LS2FM_ACC_PRIO 0
+#endif
+            if (LS2FM_ACC_PRIO == 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int u = 0; u < kAccBatch; ++u) {                        // unconditional loads, masked where they are used
                 const int j = lo_n + tid + u * kAccThreads;
                 buf[u] = load_item(list_n + (j < hi_n ? j : last_n));
                 if (DUAL) bufx[u] = expl_n ? extra_n[j < hi_n ? j : last_n] : 0.f;
             }
+            if (LS2FM_ACC_PRIO == 1) __builtin_amdgcn_s_setprio(0);
             // The claim: lane 0 of wave 0, issued WITHOUT waiting for the returned value (as a builtin under `if (tid == 0)` the
             // compiler waits for it at the end of the branch: one memory round trip per unit in front of wave 0's adds), BEHIND
             // the batch loads just issued: every vmcnt the compiler computes for loads older than the atomic is merely one too

@@ -328,6 +328,20 @@ __device__ __forceinline__ void locate_sample(const FieldC& fc, const float* __r
 // serves both grids -- the gathers are bound by the L2 -> L1 line rate, not by bytes.
 // (the measurement probes are compiled in only with -DLS2FM_ENC_PROBES: inside the shipped kernel their branches cost 14 registers --
 // 70 -> 84, five instead of seven waves per SIMD)
+// Issue priority (round 6, profiles/r06_notes.md section 9).  LS2FM_ENC_PRIO_{PAIR,ONE} for the interleaved two-grid walk / the one-grid
+// walk: 1 = a wave runs at raised priority until its eight gathers are issued (young waves get their loads out before older ones
+// interpolate), 2 = the reverse: raised BEHIND the loads (a wave that has its data interpolates, stores and frees its slot first).
+// Two grids (16-byte gathers, 70 registers): 98 -> 111 / 105 us, left alone.  One grid (8-byte gathers, the reference's default
+// field): 77 -> 75.6 / 71.9 us at C2's shape -- 2 is its default.
+#ifndef LS2FM_ENC_PRIO_PAIR
+#define LS2FM_ENC_PRIO_PAIR 0
+#endif
+#ifndef LS2FM_ENC_PRIO_ONE
+#define LS2FM_ENC_PRIO_ONE 2
+#endif
+#define ENC_PRIO_MODE (INTERLEAVED ? LS2FM_ENC_PRIO_PAIR : LS2FM_ENC_PRIO_ONE)
+#define ENC_PRIO_HEAD(x) do { if (ENC_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(x); } while (0)
+#define ENC_PRIO_TAIL(x) do { if (ENC_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(x); } while (0)
 #ifdef LS2FM_ENC_PROBES
 #define ENC_PROBE(ex) ((ex).probe)
 #else
@@ -350,6 +364,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
         if (blockIdx.x == 3 && tid == 0 && ex.scan_ticket) *ex.scan_ticket = 0;      // armed for the scans in the shade_fwd launch
         return;
     }
+    ENC_PRIO_HEAD(2);
     const int bx = (int)blockIdx.x - kEncReserved;
     const int xcd = bx & 7, j = bx >> 3;
     int unit = plan.start[xcd] + j;
@@ -400,6 +415,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = table[c.idx[k]];
+            ENC_PRIO_HEAD(0); ENC_PRIO_TAIL(2);
             float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -435,6 +451,7 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
             float2 v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+            ENC_PRIO_HEAD(0); ENC_PRIO_TAIL(2);
             float y0 = 0.f, y1 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

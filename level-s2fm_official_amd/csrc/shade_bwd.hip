@@ -28,6 +28,20 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Issue priority (round 6, profiles/r06_notes.md section 9).  The two waves of a SIMD belong to two rays that started together: left
+// alone they reach their MFMA clusters and their softplus / LDS parts at the same time and queue for the same pipe.  With the
+// priority raised around the MFMA clusters of the SDF field's hidden blocks and dropped for the VALU part between them, the wave
+// that gets to its MFMAs first keeps the matrix pipe and the other one's VALU work fills the gaps -- the pair falls out of step:
+// shade_bwd 111.4 -> 106.0 us at C2 (single field 72.8 -> 70.6, C3 832 -> 821), bit-identical.  LS2FM_BWD_PRIO: 0 = no s_setprio,
+// 1 = raised for the whole hidden-block loop (107 us at C2, but +1 % at C3), 2 = around the MFMA clusters (the default).  Measured
+// and not kept: a tile's operand loads at the highest priority (no change), the VALU position columns lowered (108), a constant
+// priority by the parity of the wave's slot (111: no gain), the same toggling in the second field's loop (no change), and the same
+// scheme in shade_fwd (four waves per SIMD there: 57 - 60 against 57.6 us); __builtin_amdgcn_iglp_opt(0 / 1) in the hidden-block loop (106).
+#ifndef LS2FM_BWD_PRIO
+#define LS2FM_BWD_PRIO 2
+#endif
+#define BWD_PRIO_LOOP(x) do { if (LS2FM_BWD_PRIO == 1) __builtin_amdgcn_s_setprio(x); } while (0)
+#define BWD_PRIO_MFMA(x) do { if (LS2FM_BWD_PRIO == 2) __builtin_amdgcn_s_setprio(x); } while (0)
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -655,8 +669,10 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
         for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) { de[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; rr[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        BWD_PRIO_LOOP(1);
 #pragma unroll kUnrollM
         for (int m = 0; m < 4; ++m) {
+            BWD_PRIO_MFMA(1);
             f32x4 aa[NC], qq[NC], tt[NC];
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) { aa[cc] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[cc] = aa[cc]; tt[cc] = aa[cc]; }
@@ -676,6 +692,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                     for (int cc = 0; cc < NC; ++cc) tt[cc] = mfma4(a1, gfb[t][cc], tt[cc]);
                 }
             }
+            BWD_PRIO_MFMA(0);
             float da[NC][4], gj[NC][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -698,6 +715,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                     }
                 }
             }
+            BWD_PRIO_MFMA(1);
 #pragma unroll
             for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
@@ -753,6 +771,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                 __builtin_amdgcn_sched_barrier(0);       // (the unrolled hidden blocks are not interleaved: their temporaries would add up)
             }
         }
+        BWD_PRIO_LOOP(0); BWD_PRIO_MFMA(0);
         if (want_pose && g == 0) {
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc)
@@ -783,7 +802,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
         }   // pass 0
         // ---- second field: plain first-order backward of its Geometry MLP
         if (DUAL && pass == 1) {
-            const float* __restrict__ g_w1ta = s_w + 4 * 9 * 64;        // [m][4][lane]
+                const float* __restrict__ g_w1ta = s_w + 4 * 9 * 64;        // [m][4][lane]
             const float* __restrict__ g_w0ta = g_w1ta + 4 * 4 * 64;     // [mk][m][r][lane]
             float gf2b[4][NC];
 #pragma unroll
@@ -832,6 +851,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
             for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) de2[mk][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            BWD_PRIO_LOOP(1); BWD_PRIO_MFMA(1);
 #pragma unroll kUnrollM
             for (int m = 0; m < 4; ++m) {
                 f32x4 aa[NC], tt[NC];
@@ -910,6 +930,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            BWD_PRIO_LOOP(0); BWD_PRIO_MFMA(0);
             if (want_pose && g == 0) {
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc)

@@ -21,6 +21,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// issue-priority experiment (round 6, profiles/r06_notes.md section 9; shade_bwd.hip gains 5 % from it): LS2FM_FWD_PRIO = 1 raises a
+// wave's priority inside the hidden-block loop, 2 only around its MFMA clusters.  Four waves per SIMD here: 59.9 - 60.3 / 57.0 - 57.6
+// against 57.3 - 57.9 us -- default 0, no s_setprio.
+#ifndef LS2FM_FWD_PRIO
+#define LS2FM_FWD_PRIO 0
+#endif
+#define FWD_PRIO_LOOP(x) do { if (LS2FM_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(x); } while (0)
+#define FWD_PRIO_MFMA(x) do { if (LS2FM_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(x); } while (0)
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -127,8 +135,10 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
         for (int mk = 0; mk < 3; ++mk) racc[mk][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    FWD_PRIO_LOOP(1);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+        FWD_PRIO_MFMA(1);
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -138,6 +148,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = mfma4(a, ub[t][c], acc[c]);
         }
+        FWD_PRIO_MFMA(0);
         float ga[CT][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -151,6 +162,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
                 f0p[c] = fmaf(w10, h, f0p[c]);
             }
         }
+        FWD_PRIO_MFMA(1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float a1 = s_w1a[(m * 4 + q) * 64 + lane];
@@ -167,6 +179,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             }
     }
 
+    FWD_PRIO_LOOP(0); FWD_PRIO_MFMA(0);
     // sdf and the analytic normal  n = kappa (R_p / rescale + inv_ext . J^T R_enc)
     float sdf[CT], nrm[CT][3];
     float part[CT][3];
