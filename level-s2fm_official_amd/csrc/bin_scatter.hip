@@ -468,9 +468,29 @@ struct SlabPlan {
     int n_explicit;                      // dual field: leading levels with explicit, run-merged items (bin_items.h)
 };
 
+// LS2FM_ACC_CVT: how a contribution becomes a 64-bit fixed-point integer.  0: __float2ll_rn(v * to_fixed) -- there is no f32 -> i64
+// instruction: the compiler's expansion is ~12 VALU instructions, eight times per item, half of this kernel's SIMD cycles.  1: through
+// the double's mantissa -- fma((double) v, to_fixed, 1.5 * 2^52) rounds v * to_fixed (exact in double) to the nearest integer, ties to
+// even, exactly as __float2ll_rn does, and leaves it in the low 52 bits of the result (two's complement, |.| < 2^51); what is above
+// them is the constant 0x4338 in the top 16 bits, whose low dword is zero: ONE 32-bit subtraction on the high dword.  Three
+// instructions (v_cvt_f64_f32, v_fma_f64, v_add_u32) and the same integers bit for bit, PROVIDED |v * to_fixed| < 2^51: a single
+// item is at most 64 contributions (a run merged inside a wave, bin_items.h: wave_runs), each < 2^(62 - headroom) -- make_plan
+// keeps headroom_bits >= 18 (it is 4 + log2(points): only batches under 16 384 points see the floor, as a 2^-44-of-the-bound
+// quantum instead of a finer one).
+// Round 6, same session, alternating libraries (profiles/r06_raw/c55_ab_cvt.txt): 1 380 -> 920 VALU instructions in the kernel; slab_accumulate
+// 69.1 / 69.3 / 68.8 -> 66.8 / 66.6 / 66.6 us (single field 46.0 -> 45.2, C3 399 -> 397, C5 243 -> 241); gradient digests identical.
+#ifndef LS2FM_ACC_CVT
+#define LS2FM_ACC_CVT 1
+#endif
+constexpr int kMinHeadroomBits = LS2FM_ACC_CVT ? 18 : 4;
 __device__ __forceinline__ void add_fixed(u64* slot, float v, float to_fixed) {
     // v * to_fixed is exact (power-of-two scale); |.| < 2^62 / worst-case hits by construction of the quantum
+#if LS2FM_ACC_CVT
+    const double d = fma((double)v, (double)to_fixed, 6755399441055744.0);
+    atomicAdd(slot, (u64)__double_as_longlong(d) - 0x4338000000000000ull);
+#else
     atomicAdd(slot, (u64)__float2ll_rn(v * to_fixed));        // two's complement: integer sums are exact
+#endif
 }
 
 __device__ __forceinline__ void quantum_of(float bound, int headroom_bits, float& to_fixed, double& to_float) {
@@ -1017,6 +1037,7 @@ HostPlan make_plan(const ls2fm_grid_desc* grid, int64_t n_points, int sshift, in
         for (int l = 0; l < LS2FM_MAX_LEVELS; ++l) h.plan.parts[l] = 1;
         h.plan.headroom_bits = 4;                // 8 corners per point (+1)
         while ((1ll << (h.plan.headroom_bits - 4)) < n_points) ++h.plan.headroom_bits;
+        if (h.plan.headroom_bits < kMinHeadroomBits) h.plan.headroom_bits = kMinHeadroomBits;        // (add_fixed, LS2FM_ACC_CVT)
         h.plan.n_explicit = n_explicit < LS2FM_MAX_LEVELS ? n_explicit : 0;        // (the kernels' flag is a dual-field one)
         h.zero_lo = h.zero_hi = -1;
         const int64_t target = 16384;            // items a workgroup should process (a hashed-level slab sees ~4P/slabs)
