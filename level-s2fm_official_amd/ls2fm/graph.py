@@ -45,7 +45,21 @@ class CapturedStep:
             torch.cuda.synchronize()
             gc.collect()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=side):
+            # A process group's watchdog THREAD polls the events of the collectives issued so far (hipEventQuery, every ~100 ms
+            # until it has seen each one complete).  Under the default capture mode ("global") such a call from ANY thread while
+            # this one captures is an error -- it invalidates the capture and the watchdog aborts the process ("operation not
+            # permitted when stream is capturing": seen twice in ~25 full GPU test runs, in a loop's capture behind eager
+            # warm-up steps with a one-rank RCCL group; an N > 1 bench would meet it the same way).  So: let the watchdog retire
+            # what the warm-up issued (everything has completed: the device is idle), and capture in "thread_local" mode --
+            # only THIS thread's unsafe calls are errors; kernels other threads launch on the capturing stream (autograd's
+            # workers) are recorded as before.
+            mode = "global"
+            dist = getattr(torch, "distributed", None)
+            if dist is not None and dist.is_available() and dist.is_initialized():
+                import time
+                time.sleep(0.35)
+                mode = "thread_local"
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
                 self.outputs = fn()
         finally:
             if gc_was_on:

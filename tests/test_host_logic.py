@@ -339,3 +339,23 @@ def test_hand_issued_loads_stay_untouched_until_their_wait():
     at = {a: i for i, (a, _, _) in enumerate(rows)}
     bad = mod.walk(rows, at, 0, mod.regs("s8"), lambda a: "lgkmcnt(0)" in a)
     assert [b[0] for b in bad] == [16], bad
+
+
+def test_fixed_point_conversion_through_the_doubles_mantissa_is_rint():
+    """`slab_accumulate`'s add_fixed (csrc/bin_scatter.hip, LS2FM_ACC_CVT): fma((double) v, 2^shift, 1.5 * 2^52), reinterpreted, minus
+    0x4338 << 48 -- must be the round-to-nearest-even integer of v * 2^shift (what __float2ll_rn gave) whenever |v * 2^shift| < 2^51.
+    The device code is three instructions; this restates its arithmetic in numpy (the product is exact in double: fma = multiply, add)."""
+    rng = np.random.default_rng(5)
+    v = np.concatenate([
+        rng.standard_normal(200000).astype(np.float32) * np.float32(3.0e-3),
+        (rng.integers(-2**22, 2**22, 20000).astype(np.float32) + np.float32(0.5)) * np.float32(2.0**-30),      # exact ties
+        np.array([0.0, -0.0, 1e-45, -1e-45, 2.0**-20, -(2.0**-20), np.nextafter(np.float32(2.0**-10), np.float32(0))], np.float32)])
+    for shift in (30, 41, 20):
+        scale = np.float64(2.0**shift)
+        prod = v.astype(np.float64) * scale
+        keep = np.abs(prod) < 2.0**51
+        d = prod[keep] + np.float64(6755399441055744.0)
+        bits = d.view(np.uint64) - np.uint64(0x4338000000000000)
+        want = np.rint(prod[keep]).astype(np.int64)
+        assert np.array_equal(bits.view(np.int64), want)
+        assert keep.sum() > 200000
