@@ -330,6 +330,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
     auto write_out = [&](int win) {
         // runs of one slab are contiguous in the sorted order and in memory: consecutive threads write consecutive items
         const int staged = total - win < kWin ? total - win : kWin;
+        if (LS2FM_FILL_PRIO == 3) __builtin_amdgcn_s_setprio(2);           // (3: raised for the write-out only)
 #if (LS2FM_FILL_PROBE & 1)
         if (staged < 0)                    // timing probe: no item stores
 #endif
@@ -383,6 +384,7 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
             if (DUAL && expl) bm.extra[gi] = s_extra[q];
         }
 #endif
+        if (LS2FM_FILL_PRIO == 3) __builtin_amdgcn_s_setprio(0);
     };
     if (!expl) {
         // ---- factored dual items (factors formed above, indices and slabs kept from the one hash pass)
@@ -860,9 +862,11 @@ slab_accumulate_persistent_kernel(LevelSet lv, SlabPlan plan, BinMeta bm, int ss
 #if (LS2FM_ACC_PROBE & 1)
             if (now[0].ij == 0x12345678u)        // timing probe: (almost) no LDS atomics
 #endif
+            if (LS2FM_ACC_PRIO == 2) __builtin_amdgcn_s_setprio(2);            // (2: raised for the adds)
 #pragma unroll
             for (int u = 0; u < kAccBatch; ++u)
                 if (b0 + tid + u * kAccThreads < cur.j_hi) add_item(now[u], DUAL ? nowx[u] : 0.f);
+            if (LS2FM_ACC_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             b0 += BT;
         } while (b0 < cur.j_hi);
         PACC_STAMP(cur.uid, 1);
