@@ -29,6 +29,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define FWD_PRIO_LOOP(x) do { if (LS2FM_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(x); } while (0)
 #define FWD_PRIO_MFMA(x) do { if (LS2FM_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(x); } while (0)
+// LS2FM_FWD_NT (round 6): the per-sample outputs (sdf, normal, colour, both feature blocks: what shade_bwd reads back ~100 us later, and the
+// caller's [R, N] tensors) leave with non-temporal stores: shade_fwd 57.7 -> 56.4 us at C2, 378 -> 372 at 8192 rays, shade_bwd unchanged
+// (profiles/r06_raw/c71_ab_fwd_nt.txt).
+#ifndef LS2FM_FWD_NT
+#define LS2FM_FWD_NT 1
+#endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -249,7 +255,11 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             }
         } else {
             if (vec) {
+#if LS2FM_FWD_NT
+                { typedef float f32x2 __attribute__((ext_vector_type(2))); f32x2 v = {acc[0][q], acc[1][q]}; __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(row + i0)); }
+#else
                 *reinterpret_cast<float2*>(row + i0) = make_float2(acc[0][q], acc[1][q]);
+#endif
             } else {
                 if (l0) row[i0] = acc[0][q];
                 if (l1) row[i1] = acc[1][q];
@@ -350,13 +360,24 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     const float col_n[3] = {s_x[nx][4], s_x[nx][5], s_x[nx][6]};
     const float sigma = sigma_of(sdf_n, pk->alpha, pk->beta);
     if (live) {
+#if LS2FM_FWD_NT
+        __builtin_nontemporal_store(sdf_n, sdfs_out + i);
+        __builtin_nontemporal_store(sdf_n, SDFV + i);
+#else
         sdfs_out[i] = sdf_n;
         SDFV[i] = sdf_n;
+#endif
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
+#if LS2FM_FWD_NT
+            __builtin_nontemporal_store(nrm_n[a], normals_out + i * 3 + a);
+            __builtin_nontemporal_store(nrm_n[a], NRM + a * p_pad + i);
+            __builtin_nontemporal_store(col_n[a], RGBS + a * p_pad + i);
+#else
             normals_out[i * 3 + a] = nrm_n[a];
             NRM[a * p_pad + i] = nrm_n[a];
             RGBS[a * p_pad + i] = col_n[a];
+#endif
         }
     }
 
