@@ -37,6 +37,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // and not kept: a tile's operand loads at the highest priority (no change), the VALU position columns lowered (108), a constant
 // priority by the parity of the wave's slot (111: no gain), the same toggling in the second field's loop (no change), and the same
 // scheme in shade_fwd (four waves per SIMD there: 57 - 60 against 57.6 us); __builtin_amdgcn_iglp_opt(0 / 1) in the hidden-block loop (106).
+// LS2FM_BWD_PART_NT (round 6): the per-ray weight-gradient partials (39 KB per ray) leave with non-temporal stores: shade_bwd 105.6 -> 103.6 us,
+// the fill (whose leading rows read them) 79.9 -> 81.9, the step 0.4098 -> 0.4078 ms in three alternating pairs (profiles/r06_raw/c73_ab_part_nt.txt)
+#ifndef LS2FM_BWD_PART_NT
+#define LS2FM_BWD_PART_NT 1
+#endif
 #ifndef LS2FM_BWD_PRIO
 #define LS2FM_BWD_PRIO 2
 #endif
@@ -209,7 +214,11 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
     }
     if (wave == 0) {
 #pragma unroll
+#if LS2FM_BWD_PART_NT
+        for (int q = 0; q < R; ++q) __builtin_nontemporal_store(regs[q], dst + q * 64);
+#else
         for (int q = 0; q < R; ++q) dst[q * 64] = regs[q];
+#endif
     }
 }
 
