@@ -35,6 +35,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef LS2FM_FWD_NT
 #define LS2FM_FWD_NT 1
 #endif
+#ifndef LS2FM_FWD_FULL
+#define LS2FM_FWD_FULL 1
+#endif
+#ifndef LS2FM_FWD_FULL_J
+#define LS2FM_FWD_FULL_J 0
+#endif
+#ifndef LS2FM_FWD_OFF32
+#define LS2FM_FWD_OFF32 1
+#endif
+#ifndef LS2FM_FWD_SCHED_BAR
+#define LS2FM_FWD_SCHED_BAR 0
+#endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -48,9 +60,12 @@ __device__ __forceinline__ float sum_over_groups(float v) {
 
 // CT = 16-column tiles (of consecutive samples) per wave: 4 -> a wave covers 64 samples with ~250 registers (2 waves/SIMD);
 // 2 -> 32 samples per wave, half the per-lane state, twice the waves (4 per SIMD) to hide the chain's latencies behind.
-template <bool DUAL, int MAXS, int CT>
+// FULL (round 6, as in shade_bwd.hip): all 32 encoding channels of both grids live AND the ray's samples fill every wave's tiles (N a
+// multiple of 16 CT: every lane's samples live, aligned for the vector form) -- known at compile time: no per-channel predicates, no
+// scalar-load fallback paths, the operand loads are straight-line code.
+template <bool DUAL, int MAXS, int CT, bool FULL = false>
 __global__ void __launch_bounds__(MAXS * 4 / CT, CT == 2 ? 4 : 2)
-shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, const float* __restrict__ center,
+shade_fwd_kernel(FieldC fc, int ch1_arg, int ch2_arg, const Packed* __restrict__ pk, const float* __restrict__ center,
                  const float* __restrict__ ray, int64_t p_pad, const float* __restrict__ E1,
                  const float* __restrict__ J1, const float* __restrict__ E2, float* __restrict__ rgb_out,
                  float* __restrict__ sdfs_out, float* __restrict__ normals_out, float* __restrict__ depth_out,
@@ -62,6 +77,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     __shared__ float s_x[MAXS][8];              // per sample: sdf, normal(3), colour(3)
     __shared__ float s_w[kMfmaSdfFloats];       // MFMA-ordered weights of the field being evaluated (29 KB)
     const int N = fc.n_samples;
+    const int ch1 = FULL ? 32 : ch1_arg, ch2 = FULL ? 32 : ch2_arg;
     const int64_t r = blockIdx.x;
     const int n = threadIdx.x, lane = n & 63, wave = n >> 6, n_waves = blockDim.x >> 6;
     const int jl = lane & 15, g = lane >> 4;
@@ -94,7 +110,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int ns = 16 * CT * wave + CT * jl + c;    // a lane's columns are CONSECUTIVE samples: 16- (8-) byte loads
-        live_c[c] = ns < N;
+        live_c[c] = FULL || ns < N;
         const int nn = live_c[c] ? ns : N - 1;
         is[c] = r * N + nn;
         float x[3];
@@ -103,15 +119,28 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 
     // all of the lane's samples live and aligned (p_pad is a multiple of 64): one float4 / float2 per channel row
     struct Cols { float v[CT]; };
-    const bool vec = live_c[CT - 1] && ((is[0] & (CT - 1)) == 0);
+    const bool vec = FULL || (live_c[CT - 1] && ((is[0] & (CT - 1)) == 0));
     const int64_t i0 = is[0], i1 = is[1], i2 = is[CT - 2], i3 = is[CT - 1];
-    auto loadv = [=](const float* __restrict__ row) -> Cols {        // by value: by-reference captures cost spilled registers
+    // LS2FM_FWD_OFF32 (round 6): the vector forms address uniform base + 32-bit byte offset (global_load ... v_off, s[base]) instead of a
+    // 64-bit address per lane: one register and one add per load instead of two and a 64-bit add chain (LS2FM_MAX_RENDER_POINTS = 2^23
+    // keeps 32 rows x p_pad x 12 bytes under 2^32)
+    const unsigned pp = (unsigned)p_pad, u0 = (unsigned)i0;
+    auto loadv = [=](const float* __restrict__ base, int rowidx) -> Cols {        // by value: by-reference captures cost spilled registers
         Cols o;
+        const float* __restrict__ row = base + (int64_t)rowidx * p_pad;
+        const char* __restrict__ cb = reinterpret_cast<const char*>(base);
+        const unsigned off = ((unsigned)rowidx * pp + u0) * 4u;
         if (CT == 4) {
-            if (vec) { const float4 t = *reinterpret_cast<const float4*>(row + i0); o.v[0] = t.x; o.v[1] = t.y; o.v[CT - 2] = t.z; o.v[CT - 1] = t.w; }
+            if (vec) {
+                const float4 t = LS2FM_FWD_OFF32 ? *reinterpret_cast<const float4*>(cb + off) : *reinterpret_cast<const float4*>(row + i0);
+                o.v[0] = t.x; o.v[1] = t.y; o.v[CT - 2] = t.z; o.v[CT - 1] = t.w;
+            }
             else { o.v[0] = row[i0]; o.v[1] = row[i1]; o.v[CT - 2] = row[i2]; o.v[CT - 1] = row[i3]; }
         } else {
-            if (vec) { const float2 t = *reinterpret_cast<const float2*>(row + i0); o.v[0] = t.x; o.v[1] = t.y; }
+            if (vec) {
+                const float2 t = LS2FM_FWD_OFF32 ? *reinterpret_cast<const float2*>(cb + off) : *reinterpret_cast<const float2*>(row + i0);
+                o.v[0] = t.x; o.v[1] = t.y;
+            }
             else { o.v[0] = row[i0]; o.v[1] = row[i1]; }
         }
         return o;
@@ -121,7 +150,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         Cols e{};
-        if ((4 * t + g) < ch1) e = loadv(E1 + (int64_t)(4 * t + g) * p_pad);
+        if ((4 * t + g) < ch1) e = loadv(E1, 4 * t + g);
 #pragma unroll
         for (int c = 0; c < CT; ++c) ub[t][c] = e.v[c];
     }
@@ -186,6 +215,9 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
     }
 
     FWD_PRIO_LOOP(0); FWD_PRIO_MFMA(0);
+#if LS2FM_FWD_SCHED_BAR
+    __builtin_amdgcn_sched_barrier(0);       // the Jacobian loads (48 registers) stay behind the hidden-block loop
+#endif
     // sdf and the analytic normal  n = kappa (R_p / rescale + inv_ext . J^T R_enc)
     float sdf[CT], nrm[CT][3];
     float part[CT][3];
@@ -196,13 +228,14 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ch = 16 * mk + 4 * g + q;
-            if (ch < ch1) {
+            if (ch < (LS2FM_FWD_FULL_J ? ch1 : ch1_arg)) {
                 // J rows are [channel][point][3]: the lane's CT consecutive samples are 3 CT consecutive floats
                 const float* __restrict__ jrow = J1 + (int64_t)ch * p_pad * 3;
+                const char* __restrict__ jb = reinterpret_cast<const char*>(J1) + ((unsigned)ch * (pp * 3u) + u0 * 3u) * 4u;
                 float jv[CT][3];
                 if (vec) {
                     if (CT == 4) {
-                        const float4* q4 = reinterpret_cast<const float4*>(jrow + i0 * 3);
+                        const float4* q4 = LS2FM_FWD_OFF32 ? reinterpret_cast<const float4*>(jb) : reinterpret_cast<const float4*>(jrow + i0 * 3);
                         const float4 x0 = q4[0], x1 = q4[1], x2 = q4[2];
                         const float f[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
 #pragma unroll
@@ -210,7 +243,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
                             for (int a = 0; a < 3; ++a) jv[c][a] = f[3 * c + a];
                     } else {
-                        const float2* q2 = reinterpret_cast<const float2*>(jrow + i0 * 3);
+                        const float2* q2 = LS2FM_FWD_OFF32 ? reinterpret_cast<const float2*>(jb) : reinterpret_cast<const float2*>(jrow + i0 * 3);
                         const float2 x0 = q2[0], x1 = q2[1], x2 = q2[2];
                         const float f[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
 #pragma unroll
@@ -243,10 +276,14 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         }
     }
     const bool l0 = live_c[0], l1 = live_c[1], l2 = live_c[CT - 2], l3 = live_c[CT - 1];
-    auto storev = [=](float* __restrict__ row, const f32x4 (&acc)[CT], int q) {
+    auto storev = [=](float* __restrict__ base, int rowidx, const f32x4 (&acc)[CT], int q) {
+        float* __restrict__ row = base + (int64_t)rowidx * p_pad;
+        char* __restrict__ cb = reinterpret_cast<char*>(base);
+        const unsigned off = ((unsigned)rowidx * pp + u0) * 4u;
         if (CT == 4) {
             if (vec) {
-                *reinterpret_cast<float4*>(row + i0) = make_float4(acc[0][q], acc[1][q], acc[CT - 2][q], acc[CT - 1][q]);
+                if (LS2FM_FWD_OFF32) *reinterpret_cast<float4*>(cb + off) = make_float4(acc[0][q], acc[1][q], acc[CT - 2][q], acc[CT - 1][q]);
+                else *reinterpret_cast<float4*>(row + i0) = make_float4(acc[0][q], acc[1][q], acc[CT - 2][q], acc[CT - 1][q]);
             } else {
                 if (l0) row[i0] = acc[0][q];
                 if (l1) row[i1] = acc[1][q];
@@ -256,9 +293,11 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         } else {
             if (vec) {
 #if LS2FM_FWD_NT
-                { typedef float f32x2 __attribute__((ext_vector_type(2))); f32x2 v = {acc[0][q], acc[1][q]}; __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(row + i0)); }
+                { typedef float f32x2 __attribute__((ext_vector_type(2))); f32x2 v = {acc[0][q], acc[1][q]};
+                  __builtin_nontemporal_store(v, LS2FM_FWD_OFF32 ? reinterpret_cast<f32x2*>(cb + off) : reinterpret_cast<f32x2*>(row + i0)); }
 #else
-                *reinterpret_cast<float2*>(row + i0) = make_float2(acc[0][q], acc[1][q]);
+                if (LS2FM_FWD_OFF32) *reinterpret_cast<float2*>(cb + off) = make_float2(acc[0][q], acc[1][q]);
+                else *reinterpret_cast<float2*>(row + i0) = make_float2(acc[0][q], acc[1][q]);
 #endif
             } else {
                 if (l0) row[i0] = acc[0][q];
@@ -267,7 +306,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
         }
     };
 #pragma unroll
-    for (int q = 0; q < 4; ++q) storev(FE + (int64_t)(4 * g + q) * p_pad, facc, q);
+    for (int q = 0; q < 4; ++q) storev(FE, 4 * g + q, facc, q);
 
     // ---- second field (Geometry_feat of RadF): features only
     f32x4 facc2[CT];
@@ -281,7 +320,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             Cols e{};
-            if ((4 * t + g) < ch2) e = loadv(E2 + (int64_t)(4 * t + g) * p_pad);
+            if ((4 * t + g) < ch2) e = loadv(E2, 4 * t + g);
 #pragma unroll
             for (int c = 0; c < CT; ++c) ub[t][c] = e.v[c];
         }
@@ -309,7 +348,7 @@ shade_fwd_kernel(FieldC fc, int ch1, int ch2, const Packed* __restrict__ pk, con
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) storev(FE2 + (int64_t)(4 * g + q) * p_pad, facc2, q);
+        for (int q = 0; q < 4; ++q) storev(FE2, 4 * g + q, facc2, q);
     }
     __syncthreads();          // s_view ready
 
@@ -456,13 +495,14 @@ int ls2fm_launch_shade_fwd(const FieldC& fc, int dual, int ch1, int ch2, const P
     const int threads = (fc.n_samples + per_wave - 1) / per_wave * 64;
     ls2fm_loss_spec ls{};            // rgb_gt == null: plain render
     if (loss) ls = *loss;
-#define LS2FM_SHADE_FWD(DUAL, MAXS, CT)                                                                            \
-    shade_fwd_kernel<DUAL, MAXS, CT><<<(unsigned)n_rays, threads, 0, s>>>(                                          \
+    const bool full = LS2FM_FWD_FULL && small && ch1 == 32 && (!dual || ch2 == 32) && fc.n_samples % 32 == 0;
+#define LS2FM_SHADE_FWD(DUAL, MAXS, CT, FULL)                                                                      \
+    shade_fwd_kernel<DUAL, MAXS, CT, FULL><<<(unsigned)n_rays, threads, 0, s>>>(                                    \
         fc, ch1, ch2, pk, center, ray, w.p_pad, ws + w.e1, ws + w.j1, DUAL ? ws + w.e2 : nullptr, rgb, sdfs_volume, \
         normals, depth_mlp, normal_mlp, ws + w.sdfv, ws + w.nrm, ws + w.rgbs, ws + w.fe, DUAL ? ws + w.fe2 : nullptr,        \
         ws + w.rout, ws + w.lpart, w.r_pad, ls)
-    if (dual) { if (small) LS2FM_SHADE_FWD(true, 256, 2); else LS2FM_SHADE_FWD(true, 512, 4); }
-    else      { if (small) LS2FM_SHADE_FWD(false, 256, 2); else LS2FM_SHADE_FWD(false, 512, 4); }
+    if (dual) { if (full) LS2FM_SHADE_FWD(true, 256, 2, true); else if (small) LS2FM_SHADE_FWD(true, 256, 2, false); else LS2FM_SHADE_FWD(true, 512, 4, false); }
+    else      { if (full) LS2FM_SHADE_FWD(false, 256, 2, true); else if (small) LS2FM_SHADE_FWD(false, 256, 2, false); else LS2FM_SHADE_FWD(false, 512, 4, false); }
 #undef LS2FM_SHADE_FWD
     return LS2FM_OK;
 }
