@@ -94,6 +94,26 @@ __device__ __forceinline__ void st2(float* p, const float2 v) {
     *reinterpret_cast<float2*>(p) = v;
 #endif
 }
+// LS2FM_BWD_OFF32 (round 6, as in shade_fwd.hip): per-sample rows are addressed as uniform base + 32-bit BYTE offset -- the offset is
+// formed in 32-bit arithmetic, so the access is `global_load v, v_off, s[base]` (one register, one add) instead of a 64-bit address per
+// lane (an element index scaled in 64 bits defeats that form).  LS2FM_MAX_RENDER_POINTS = 2^23 keeps 32 rows x p_pad x 12 bytes and 16
+// levels x p_pad x 16 bytes under 2^32.
+#ifndef LS2FM_BWD_OFF32
+#define LS2FM_BWD_OFF32 1
+#endif
+template <typename T> __device__ __forceinline__ const T* at_bytes(const float* base, uint32_t bytes) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + bytes);
+}
+template <typename T> __device__ __forceinline__ T* at_bytes(float* base, uint32_t bytes) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + bytes);
+}
+// element `idx` of a float row block / the `idx`-th group of K floats
+__device__ __forceinline__ const float* elem(const float* base, uint32_t idx, uint32_t k = 1u) {
+    return LS2FM_BWD_OFF32 ? at_bytes<float>(base, idx * (4u * k)) : base + (int64_t)idx * k;
+}
+__device__ __forceinline__ float* elem(float* base, uint32_t idx, uint32_t k = 1u) {
+    return LS2FM_BWD_OFF32 ? at_bytes<float>(base, idx * (4u * k)) : base + (int64_t)idx * k;
+}
 // lane J of this lane's 16-lane row (DPP row_share: folds into the consuming VALU instruction)
 template <int J> __device__ __forceinline__ float row_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, false));
@@ -215,9 +235,9 @@ __device__ __forceinline__ void wg_flush(const f32x4 (&acc0)[4][2], const f32x4 
     if (wave == 0) {
 #pragma unroll
 #if LS2FM_BWD_PART_NT
-        for (int q = 0; q < R; ++q) __builtin_nontemporal_store(regs[q], dst + q * 64);
+        for (int q = 0; q < R; ++q) __builtin_nontemporal_store(regs[q], LS2FM_BWD_OFF32 ? at_bytes<float>(dst, (uint32_t)lane * 4u + (uint32_t)q * 256u) : dst + lane + q * 64);
 #else
-        for (int q = 0; q < R; ++q) dst[q * 64] = regs[q];
+        for (int q = 0; q < R; ++q) (dst + lane)[q * 64] = regs[q];
 #endif
     }
 }
@@ -573,7 +593,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
             for (int cc = 0; cc < NC; ++cc) {
                 const int ch = 4 * t + g;
                 const bool on = ch < ch1;
-                ub[t][cc] = on ? f_e1[(uint32_t)ch * P32 + is[cc]] : 0.f;
+                ub[t][cc] = on ? *elem(f_e1, (uint32_t)ch * P32 + is[cc]) : 0.f;
                 // J rows are [channel][point][3]: one 12-byte load per (channel, sample)
                 // (a 4-byte-aligned 3-vector, NOT a struct of float[3]: the conditionally assigned struct stayed an alloca, which the
                 // compiler promoted to LDS indexed by the FLAT work-item id -- and for that it read the workgroup's y / z sizes from the
@@ -581,7 +601,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                 typedef float f32x3 __attribute__((ext_vector_type(3)));
                 typedef f32x3 f32x3_a4 __attribute__((aligned(4)));
                 f32x3 jv = {0.f, 0.f, 0.f};
-                if (on) jv = *reinterpret_cast<const f32x3_a4*>(f_j1 + ((uint32_t)ch * P32 + is[cc]) * 3u);
+                if (on) jv = *reinterpret_cast<const f32x3_a4*>(elem(f_j1, (uint32_t)ch * P32 + is[cc], 3u));
                 float acc = fmaf(jv.x, gns[cc][0], 0.f);
                 acc = fmaf(jv.y, gns[cc][1], acc);
                 acc = fmaf(jv.z, gns[cc][2], acc);
@@ -614,16 +634,16 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const int kp = 4 * t + g;                             // k' -> the reference's input column
-                        if (kp < 35) o_v[(uint32_t)(kp < 32 ? 3 + kp : kp - 32) * P32 + is[cc]] = vb[t][cc];
+                        if (kp < 35) *elem(o_v, (uint32_t)(kp < 32 ? 3 + kp : kp - 32) * P32 + is[cc]) = vb[t][cc];
                     }
 #pragma unroll
                     for (int t = 0; t < 5; ++t)
-                        if (4 * t + g < kOut) o_gf[(uint32_t)(4 * t + g) * P32 + is[cc]] = gfb[t][cc];
+                        if (4 * t + g < kOut) *elem(o_gf, (uint32_t)(4 * t + g) * P32 + is[cc]) = gfb[t][cc];
                 }
                 if (g < 3) {
                     const float pg = g == 0 ? pw[cc][0] : (g == 1 ? pw[cc][1] : pw[cc][2]);
-                    (out + w.p3)[(uint32_t)g * P32 + is[cc]] = pg;
-                    (out + w.dz)[(uint32_t)g * P32 + is[cc]] = dz_g[cc];
+                    *elem(out + w.p3, (uint32_t)g * P32 + is[cc]) = pg;
+                    *elem(out + w.dz, (uint32_t)g * P32 + is[cc]) = dz_g[cc];
                 }
             }
 
@@ -631,7 +651,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc)
             if (live_c[cc] && g == 0) {
-                float* dst = out + w.rpt + (int64_t)is[cc] * 8;
+                float* dst = elem(out + w.rpt, is[cc], 8u);
                 st4(dst, make_float4(xg[cc][0], xg[cc][1], xg[cc][2], gns[cc][0]));
                 st4(dst + 4, make_float4(gns[cc][1], gns[cc][2], 0.f, 0.f));
             }
@@ -786,7 +806,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
             for (int cc = 0; cc < NC; ++cc)
                 if (live_c[cc]) {
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) (out + w.dexyz)[(uint32_t)a * P32 + is[cc]] = dex[cc][a];
+                    for (int a = 0; a < 3; ++a) *elem(out + w.dexyz, (uint32_t)a * P32 + is[cc]) = dex[cc][a];
                 }
         }
         // scatter payload of the SDF grid: 16 bytes per (level, point); this lane owns rows 16 mk + 4 g + {0..3}
@@ -802,7 +822,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                     if (2 * l < ch1 && live_c[cc]) {
                         const float d0 = de[mk][cc][2 * hv], d1 = de[mk][cc][2 * hv + 1];
                         const float r0 = rr[mk][cc][2 * hv], r1 = rr[mk][cc][2 * hv + 1];
-                        st4(out + w.rec1 + ((int64_t)l * P + is[cc]) * 4, make_float4(d0, d1, r0, r1));
+                        st4(elem(out + w.rec1, (uint32_t)l * P32 + is[cc], 4u), make_float4(d0, d1, r0, r1));
                         const float b = fmaxf(fabsf(d0), fabsf(d1)) + lsc.s[l] * g1[cc] * fmaxf(fabsf(r0), fabsf(r1));
                         bnd[mk][hv] = fmaxf(bnd[mk][hv], b);
                     }
@@ -817,7 +837,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int cc = 0; cc < NC; ++cc) ub[t][cc] = (4 * t + g) < ch2 ? f_e2[(uint32_t)(4 * t + g) * P32 + is[cc]] : 0.f;
+                for (int cc = 0; cc < NC; ++cc) ub[t][cc] = (4 * t + g) < ch2 ? *elem(f_e2, (uint32_t)(4 * t + g) * P32 + is[cc]) : 0.f;
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) {
 #pragma unroll
@@ -826,7 +846,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
 #pragma unroll
                     for (int k = 0; k < 3; ++k) v = fmaf(s_wc[k][49 + 4 * t + g], dz[cc][k], v);
                     gf2b[t][cc] = v;
-                    if (!WG && live_c[cc]) o_gf2[(uint32_t)(1 + 4 * t + g) * P32 + is[cc]] = v;
+                    if (!WG && live_c[cc]) *elem(o_gf2, (uint32_t)(1 + 4 * t + g) * P32 + is[cc]) = v;
                 }
                 if (!WG && live_c[cc] && g == 0) o_gf2[is[cc]] = 0.f;
             }
@@ -945,7 +965,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                 for (int cc = 0; cc < NC; ++cc)
                     if (live_c[cc]) {
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) (out + w.dexyz)[(uint32_t)(3 + a) * P32 + is[cc]] = dex[cc][a];
+                        for (int a = 0; a < 3; ++a) *elem(out + w.dexyz, (uint32_t)(3 + a) * P32 + is[cc]) = dex[cc][a];
                     }
             }
 #pragma unroll
@@ -957,7 +977,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                         const int l = 8 * mk + 2 * g + hv;
                         if (2 * l < ch2 && live_c[cc]) {
                             const float d0 = de2[mk][cc][2 * hv], d1 = de2[mk][cc][2 * hv + 1];
-                            st2(out + w.rec2 + ((int64_t)l * P + is[cc]) * 2, make_float2(d0, d1));
+                            st2(elem(out + w.rec2, (uint32_t)l * P32 + is[cc], 2u), make_float2(d0, d1));
                             bnd[mk][hv] = fmaxf(bnd[mk][hv], fmaxf(fabsf(d0), fabsf(d1)));
                         }
                     }
@@ -971,7 +991,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
             if (2 * l < (pass == 0 ? ch1 : ch2)) atomicMax(&s_bound[16 * pass + l], __float_as_int(bnd[mk][hv]));
         }
     if constexpr (WG) {
-        float* __restrict__ dst = (pass == 0 ? slot_sdf : slot_geo) + r * ((pass == 0 ? kRegsSdf : kRegsGeo) * 64) + lane;
+        float* __restrict__ dst = (pass == 0 ? slot_sdf : slot_geo) + r * ((pass == 0 ? kRegsSdf : kRegsGeo) * 64);      // the ray's slot (uniform); wg_flush adds the lane
         if (pass == 0) wg_flush<false>(acc0, acc1, pacc, w1p, gs16, g0s, s_w, dst, wave, n_waves, lane);
         else wg_flush<true>(acc0, acc1, pacc, w1p, gs16, g0s, s_w, dst, wave, n_waves, lane);
     }
