@@ -350,6 +350,15 @@ __device__ __forceinline__ void locate_sample(const FieldC& fc, const float* __r
 #ifndef LS2FM_ENC_MINW
 #define LS2FM_ENC_MINW 1
 #endif
+#ifndef LS2FM_ENC_OFF32
+#define LS2FM_ENC_OFF32 0
+#endif
+#ifndef LS2FM_ENC_OFF32_LD
+#define LS2FM_ENC_OFF32_LD LS2FM_ENC_OFF32
+#endif
+#ifndef LS2FM_ENC_OFF32_ST
+#define LS2FM_ENC_OFF32_ST LS2FM_ENC_OFF32
+#endif
 template <bool INTERLEAVED>
 __global__ void __launch_bounds__(kEncThreads, LS2FM_ENC_MINW)
 ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict__ center, const float* __restrict__ ray,
@@ -400,6 +409,13 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
         uint32_t g[3];
         Cell c;
         locate_sample(fc, center, ray, ex.pts, i, lv, g, c);
+        // row `row` of a [channel][p_pad] (k = 1) / [channel][p_pad][3] (k = 3) block, this thread's point: uniform base + 32-bit byte
+        // offset (LS2FM_ENC_OFF32: `global_store v_off, v, s[base]` instead of a 64-bit address per store; 32 rows x 2^23 points x 12 B < 2^32)
+        const uint32_t pp32 = (uint32_t)p_pad, i32 = (uint32_t)i;
+        auto enc_at = [=](float* __restrict__ base, int row, uint32_t k) -> float* {
+            return LS2FM_ENC_OFF32_ST ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + ((uint32_t)row * pp32 + i32) * (4u * k))
+                                   : base + ((int64_t)row * p_pad + i) * k;
+        };
         if (INTERLEAVED) {
             const float4* __restrict__ table = reinterpret_cast<const float4*>(table1);
             float4 v[8];
@@ -414,7 +430,8 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                     if ((((c.idx[k] - lv.offset) >= hb) ? 1u : 0u) != want) c.idx[k] = lv.offset + want * hb;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = table[c.idx[k]];
+            for (int k = 0; k < 8; ++k)
+                v[k] = LS2FM_ENC_OFF32_LD ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table1) + c.idx[k] * 16u) : table[c.idx[k]];
             ENC_PRIO_HEAD(0); ENC_PRIO_TAIL(2);
             float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
 #pragma unroll
@@ -427,10 +444,10 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
             }
             const bool st = ENC_PROBE(ex) != 4 || y0 == 1234.5f;          // (probe 4, timing only: no value / Jacobian stores)
             if (st) {
-            __builtin_nontemporal_store(y0, enc1 + (2 * l + 0) * p_pad + i);
-            __builtin_nontemporal_store(y1, enc1 + (2 * l + 1) * p_pad + i);
-            __builtin_nontemporal_store(y2, enc2 + (2 * l + 0) * p_pad + i);
-            __builtin_nontemporal_store(y3, enc2 + (2 * l + 1) * p_pad + i);
+            __builtin_nontemporal_store(y0, enc_at(enc1, 2 * l + 0, 1u));
+            __builtin_nontemporal_store(y1, enc_at(enc1, 2 * l + 1, 1u));
+            __builtin_nontemporal_store(y2, enc_at(enc2, 2 * l + 0, 1u));
+            __builtin_nontemporal_store(y3, enc_at(enc2, 2 * l + 1, 1u));
             }
 #pragma unroll
             for (int gd = 0; gd < 3; ++gd) {
@@ -442,15 +459,17 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                     g1 = fmaf(dw, v[k].y, g1);
                 }
                 if (st || g0 == 1234.5f) {
-                __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * p_pad + i) * 3 + gd);      // [channel][point][3]
-                __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * p_pad + i) * 3 + gd);
+                __builtin_nontemporal_store(lv.scale * g0, enc_at(jac, 2 * l + 0, 3u) + gd);      // [channel][point][3]
+                __builtin_nontemporal_store(lv.scale * g1, enc_at(jac, 2 * l + 1, 3u) + gd);
                 }
             }
         } else {
             const float* __restrict__ table = second ? table2 : table1;
             float2 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
+            for (int k = 0; k < 8; ++k)
+                v[k] = LS2FM_ENC_OFF32_LD ? *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(table) + c.idx[k] * 8u)
+                                       : *reinterpret_cast<const float2*>(table + 2ull * c.idx[k]);
             ENC_PRIO_HEAD(0); ENC_PRIO_TAIL(2);
             float y0 = 0.f, y1 = 0.f;
 #pragma unroll
@@ -460,8 +479,8 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                 y1 = fmaf(wt, v[k].y, y1);
             }
             float* __restrict__ enc = second ? enc2 : enc1;
-            __builtin_nontemporal_store(y0, enc + (2 * l + 0) * p_pad + i);
-            __builtin_nontemporal_store(y1, enc + (2 * l + 1) * p_pad + i);
+            __builtin_nontemporal_store(y0, enc_at(enc, 2 * l + 0, 1u));
+            __builtin_nontemporal_store(y1, enc_at(enc, 2 * l + 1, 1u));
             if (!second) {
 #pragma unroll
                 for (int gd = 0; gd < 3; ++gd) {
@@ -472,8 +491,8 @@ ray_encode_kernel(LevelSet lv1, LevelSet lv2, FieldC fc, const float* __restrict
                         g0 = fmaf(dw, v[k].x, g0);
                         g1 = fmaf(dw, v[k].y, g1);
                     }
-                    __builtin_nontemporal_store(lv.scale * g0, jac + ((2 * l + 0) * p_pad + i) * 3 + gd);  // [channel][point][3]
-                    __builtin_nontemporal_store(lv.scale * g1, jac + ((2 * l + 1) * p_pad + i) * 3 + gd);
+                    __builtin_nontemporal_store(lv.scale * g0, enc_at(jac, 2 * l + 0, 3u) + gd);  // [channel][point][3]
+                    __builtin_nontemporal_store(lv.scale * g1, enc_at(jac, 2 * l + 1, 3u) + gd);
                 }
             }
         }
