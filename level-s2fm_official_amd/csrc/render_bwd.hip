@@ -111,6 +111,8 @@ extern "C" int ls2fm_render_bwd(const ls2fm_field_desc* field, const ls2fm_grid_
     if (field->bg_sdf) return LS2FM_ERR_UNSUPPORTED;
     if (field->dual_field && !same_grid_geometry(sdf_grid, rad_grid)) return LS2FM_ERR_UNSUPPORTED;
     if (field->n_samples < 1 || field->n_samples > 512) return LS2FM_ERR_UNSUPPORTED;
+    // (the forward refuses such a batch, too; said again here because shade_bwd's 32-bit byte offsets depend on it)
+    if (n_rays * (int64_t)field->n_samples > LS2FM_MAX_RENDER_POINTS) return LS2FM_ERR_UNSUPPORTED;
     LS2FM_CHECK_ARG((d_center == nullptr) == (d_ray == nullptr));     // pose gradients: both or neither
     const int want_pose = d_center != nullptr;
     const ls2fm_loss_spec* loss = opts ? opts->loss : nullptr;

@@ -173,6 +173,48 @@ def test_full_shape_sparse_oracle_sample_and_properties(name):
         assert rel_err(v, ref) < 1e-4, name_
 
 
+def test_maximum_batch_size_matches_its_shards():
+    """LS2FM_MAX_RENDER_POINTS = 2^23 sample points in ONE call (64 views x 1024 rays x 128 samples, dual field, full L16/F2/T19 grids):
+    the largest batch the ABI accepts, where the kernels' 32-bit element / byte offsets are closest to their range (32 rows x p_pad x 12 B
+    = 3.2 GB of Jacobian rows, 16 levels x p_pad x 16 B = 2.1 GB of scatter records).  A ray's outputs do not depend on its batch: the
+    whole batch must reproduce its 8 shards BIT FOR BIT, and the gradient of a sum-type loss must be the sum over the shards."""
+    b, r, n, shards = 64, 1024, 128, 8
+    opt = make_options("DTU", device=DEV, dual_field=True, sample_intvs=n)
+    sdf, rad, ren = _randomized(opt, 71)
+    s = float(opt.data.bound_max[0])
+    center, ray = _view_rays(b, r, s, 72)
+    tgt = torch.rand(b, r, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(73))
+    assert b * r * n == 1 << 23 and fused.can_render(ren, opt, center, ray, sdf, rad)
+    keys = ("rgb", "sdfs_volume", "normals", "depth_mlp", "normal_mlp")
+    sdf.zero_grad(); rad.zero_grad()
+    ret = ren.forward(opt, center, ray, sdf, rad)
+    for k in keys:
+        assert torch.isfinite(ret[k]).all(), k
+    _loss(ret, tgt).backward()
+    full = {k: torch.as_tensor(v).detach().clone() for k, v in _all_grads(sdf, rad).items()}
+    whole = {k: ret[k].detach().clone() for k in keys}
+    del ret
+    acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in full.items()}
+    vs = b // shards
+    for q in range(shards):
+        sdf.zero_grad(); rad.zero_grad()
+        sl = slice(q * vs, (q + 1) * vs)
+        part = ren.forward(opt, center[sl].contiguous(), ray[sl].contiguous(), sdf, rad)
+        for k in keys:
+            assert torch.equal(part[k], whole[k][sl]), (k, q)
+        _loss(part, tgt[sl]).backward()
+        for k, v in _all_grads(sdf, rad).items():
+            acc[k] += torch.as_tensor(v).double()
+        del part
+    for k in full:
+        assert torch.isfinite(full[k]).all(), k
+        assert rel_err(full[k], acc[k]) < (1e-4 if k == "s.beta" else 2e-5), k
+    assert full["s.embed_fn.embedder_obj.params"].abs().max() > 0 and full["r.embed_fn.embedder_obj.params"].abs().max() > 0
+    # one ray more is not handed to the fused kernels (the composed form serves it): nothing wraps around
+    c1 = torch.cat([center.view(-1, 3), center.view(-1, 3)[:1]]).view(1, -1, 3)
+    assert not fused.can_render(ren, opt, c1, c1, sdf, rad)
+
+
 def test_config1_whole_batch_vs_oracle():
     """BASELINE.json configs[0] at ITS OWN shape -- one synthetic view, 256 rays x 32 samples, single field, full L16/F2/T19 grid,
     the benchmark's synthetic inputs and loss (`bench.py --config C1`): small enough for the CPU oracle to
