@@ -219,8 +219,9 @@ int ls2fm_sdf_points_bwd_add(const ls2fm_field_desc* field, const ls2fm_grid_des
  * for the same inputs, so it must be kept untouched between the two calls (ls2fm_render_bwd may run more than once on it).
  * The hash-table gradient outputs of ls2fm_render_bwd must be 16-byte aligned (float4 stores).
  */
-#define LS2FM_MAX_RENDER_POINTS (1 << 23)   /* n_rays * n_samples per call (32-bit offsets and item counts inside);
-                                               more: LS2FM_ERR_UNSUPPORTED -- split the rays over several calls */
+#define LS2FM_MAX_RENDER_POINTS (1 << 23)   /* n_rays * n_samples per call (32-bit element / byte offsets and item counts
+                                               inside); more: LS2FM_ERR_UNSUPPORTED from the size query, ls2fm_render_fwd
+                                               and ls2fm_render_bwd -- split the rays over several calls */
 int64_t ls2fm_render_workspace_bytes(const ls2fm_field_desc* field, const ls2fm_grid_desc* grid, int64_t n_rays);
 /* Dual field, optional: write both hash tables (same geometry, [n_entries][2] each) entry-interleaved into
  * dual_table [n_entries][4] for ls2fm_params.dual_table.  The forward then gathers ONE 16-byte entry per corner for both
