@@ -29,8 +29,10 @@ write = read(f"gpurun_out/{tag}_pmc_write.txt", "WRITE_SIZE")
 doc = {"_about": "HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes with --kernel-trace "
                  "only, LS2FM_SERIAL=1, bench.py default workload C2), counter KB * 1024.  `fetch_raw` is the RAW counter; `fetch` "
                  "applies the guide's gfx950 correction for wide coalesced streaming reads (FETCH_SIZE reports half: "
-                 "MI355X_MICROARCH.md, HBM section) -- valid for the streaming kernels (slab_accumulate, scatter_fill, shade_*), an "
-                 "over-estimate for the 8-byte gathers of ray_encode (uncalibrated there).  Infinity-Cache hits are counted.  "
+                 "MI355X_MICROARCH.md, HBM section) -- calibrated on this hardware for streaming reads AND for 8- / 16-byte gathers of scattered lines "
+                 "(tools/fetch_calib.hip, profiles/r06_raw/c83_fetch_calib.txt: 1 GiB of distinct 128-byte lines touched -> FETCH_SIZE "
+                 "512 MiB, one TCC miss and one EA read request per line, whatever part of the line is used; the gathers take as long "
+                 "as streaming the lines whole).  Infinity-Cache hits are counted.  "
                  "bench.py quotes fetch + write as roofline.traffic.",
        "_commit": commit}
 for name in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
