@@ -66,6 +66,10 @@ namespace {
 #ifndef LS2FM_FILL_FLAT
 #define LS2FM_FILL_FLAT 1
 #endif
+// LS2FM_FILL_REC_NT (round 6): the scatter records (read exactly once, here) as non-temporal loads
+#ifndef LS2FM_FILL_REC_NT
+#define LS2FM_FILL_REC_NT 0
+#endif
 #ifndef LS2FM_FILL_MINW
 #define LS2FM_FILL_MINW 5
 #endif
@@ -166,7 +170,13 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
 #else
         const float4 a = reinterpret_cast<const float4*>(rpt)[2 * i];
         const float4 c = reinterpret_cast<const float4*>(rpt)[2 * i + 1];
+#if LS2FM_FILL_REC_NT
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 bv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rec1) + ((int64_t)l * p_pad + i));
+        const float4 b = make_float4(bv[0], bv[1], bv[2], bv[3]);
+#else
         const float4 b = reinterpret_cast<const float4*>(rec1)[(int64_t)l * p_pad + i];
+#endif
 #endif
         const float x[3] = {a.x, a.y, a.z};                 // the grid-normalised position the forward classified (same bits)
 #pragma unroll
@@ -174,8 +184,14 @@ scatter_fill_kernel(LevelSet lv, FieldC fc, const float* __restrict__ center, co
         d0 = b.x; d1 = b.y; r0 = b.z; r1 = b.w;
         qd[0] = L.scale * a.w; qd[1] = L.scale * c.x; qd[2] = L.scale * c.y;
         if (DUAL) {
+#if LS2FM_FILL_REC_NT
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 e = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(rec2) + ((int64_t)l * p_pad + i));
+            e0 = e[0]; e1 = e[1];
+#else
             const float2 e = reinterpret_cast<const float2*>(rec2)[(int64_t)l * p_pad + i];
             e0 = e.x; e1 = e.y;
+#endif
         }
     }
     // runs of consecutive points in one cell (bin_items.h): the same flags the counting pass derived

@@ -98,6 +98,9 @@ __device__ __forceinline__ void st2(float* p, const float2 v) {
 // formed in 32-bit arithmetic, so the access is `global_load v, v_off, s[base]` (one register, one add) instead of a 64-bit address per
 // lane (an element index scaled in 64 bits defeats that form).  LS2FM_MAX_RENDER_POINTS = 2^23 keeps 32 rows x p_pad x 12 bytes and 16
 // levels x p_pad x 16 bytes under 2^32.
+#ifndef LS2FM_BWD_EJ_NT
+#define LS2FM_BWD_EJ_NT 0
+#endif
 #ifndef LS2FM_BWD_OFF32
 #define LS2FM_BWD_OFF32 1
 #endif
@@ -593,7 +596,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
             for (int cc = 0; cc < NC; ++cc) {
                 const int ch = 4 * t + g;
                 const bool on = ch < ch1;
-                ub[t][cc] = on ? *elem(f_e1, (uint32_t)ch * P32 + is[cc]) : 0.f;
+                ub[t][cc] = on ? (LS2FM_BWD_EJ_NT ? __builtin_nontemporal_load(elem(f_e1, (uint32_t)ch * P32 + is[cc])) : *elem(f_e1, (uint32_t)ch * P32 + is[cc])) : 0.f;
                 // J rows are [channel][point][3]: one 12-byte load per (channel, sample)
                 // (a 4-byte-aligned 3-vector, NOT a struct of float[3]: the conditionally assigned struct stayed an alloca, which the
                 // compiler promoted to LDS indexed by the FLAT work-item id -- and for that it read the workgroup's y / z sizes from the
@@ -601,7 +604,8 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
                 typedef float f32x3 __attribute__((ext_vector_type(3)));
                 typedef f32x3 f32x3_a4 __attribute__((aligned(4)));
                 f32x3 jv = {0.f, 0.f, 0.f};
-                if (on) jv = *reinterpret_cast<const f32x3_a4*>(elem(f_j1, (uint32_t)ch * P32 + is[cc], 3u));
+                if (on) jv = LS2FM_BWD_EJ_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x3_a4*>(elem(f_j1, (uint32_t)ch * P32 + is[cc], 3u)))
+                                             : *reinterpret_cast<const f32x3_a4*>(elem(f_j1, (uint32_t)ch * P32 + is[cc], 3u));
                 float acc = fmaf(jv.x, gns[cc][0], 0.f);
                 acc = fmaf(jv.y, gns[cc][1], acc);
                 acc = fmaf(jv.z, gns[cc][2], acc);
@@ -837,7 +841,7 @@ shade_bwd_kernel(FieldC fc, LevelScales lsc, int ch1_arg, int ch2_arg, WsLayout 
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int cc = 0; cc < NC; ++cc) ub[t][cc] = (4 * t + g) < ch2 ? *elem(f_e2, (uint32_t)(4 * t + g) * P32 + is[cc]) : 0.f;
+                for (int cc = 0; cc < NC; ++cc) ub[t][cc] = (4 * t + g) < ch2 ? (LS2FM_BWD_EJ_NT ? __builtin_nontemporal_load(elem(f_e2, (uint32_t)(4 * t + g) * P32 + is[cc])) : *elem(f_e2, (uint32_t)(4 * t + g) * P32 + is[cc])) : 0.f;
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) {
 #pragma unroll

@@ -38,6 +38,11 @@ __device__ __forceinline__ float4 mask4(const float4 v, int64_t s, int64_t n, bo
 // adds row k of the rays [sg * per, (sg + 1) * per) -- wave v takes the rays v, v + 4, ... of the segment, eight loads in
 // flight, then the four waves' sums are added in order -- and leaves row k of segment sum sg.  The order of the additions is a
 // function of (n_rays, kL1Seg) alone: deterministic.
+// LS2FM_SIDE_PART_NT (round 6): the per-ray partials (written once by shade_bwd with non-temporal stores, read once here) as
+// non-temporal loads
+#ifndef LS2FM_SIDE_PART_NT
+#define LS2FM_SIDE_PART_NT 0
+#endif
 struct L1Job { const float* slot_sdf; const float* slot_geo; float* l1_sdf; float* l1_geo; int n_slots, dual; };
 
 template <bool WT>
@@ -58,11 +63,12 @@ __device__ __forceinline__ void wgrad_l1_job_a(const L1Job& jb, int job, float* 
     for (; b + 7 * kWmWaves < hi; b += 8 * kWmWaves) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + u * kWmWaves) * (R * 64)];
+        for (int u = 0; u < 8; ++u)
+            v[u] = LS2FM_SIDE_PART_NT ? __builtin_nontemporal_load(&src[(int64_t)(b + u * kWmWaves) * (R * 64)]) : src[(int64_t)(b + u * kWmWaves) * (R * 64)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; b < hi; b += kWmWaves) acc += src[(int64_t)b * (R * 64)];
+    for (; b < hi; b += kWmWaves) acc += LS2FM_SIDE_PART_NT ? __builtin_nontemporal_load(&src[(int64_t)b * (R * 64)]) : src[(int64_t)b * (R * 64)];
     s_l1[wave][lane] = acc;
     __syncthreads();
     if (wave == 0) {
