@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef LS2FM_FWD_FULL_J
 #define LS2FM_FWD_FULL_J 0
 #endif
+#ifndef LS2FM_FWD_REPOS
+#define LS2FM_FWD_REPOS 1
+#endif
 #ifndef LS2FM_FWD_OFF32
 #define LS2FM_FWD_OFF32 1
 #endif
@@ -361,6 +364,17 @@ shade_fwd_kernel(FieldC fc, int ch1_arg, int ch2_arg, const Packed* __restrict__
             wf[k][q] = pk->wc[k][33 + 4 * g + q];
             wf2[k][q] = DUAL ? pk->wc[k][49 + 4 * g + q] : 0.f;
         }
+#if LS2FM_FWD_REPOS
+    // the sample positions are formed again for the decoder instead of being held across both MLP chains (six registers under a cap the
+    // kernel spills at; same operations, same bits -- the sample number goes through an empty asm so that the two evaluations stay apart)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        int ns = 16 * CT * wave + CT * jl + c;
+        asm volatile("" : "+v"(ns));
+        float x[3];
+        sample_position(fc, gm, sample_depth(gm, (FULL || ns < N) ? ns : N - 1, N), pw[c], x);
+    }
+#endif
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         float col[3];
