@@ -12,7 +12,8 @@ OBJS=""
 for f in $C/*.hip; do
   b=$(basename $f .hip)
   if [[ " $* " == *" $b.hip "* ]]; then
-    /opt/rocm/bin/hipcc $BASE $FLAGS -c $f -o $OUT/obj_$NAME/$b.o
+    PF=""; [ $b = render_fwd ] && PF="-mllvm -amdgpu-sched-strategy=max-memory-clause"     # = the Makefile's FLAGS_<file>
+    /opt/rocm/bin/hipcc $BASE $PF $FLAGS -c $f -o $OUT/obj_$NAME/$b.o
     OBJS="$OBJS $OUT/obj_$NAME/$b.o"
   else
     OBJS="$OBJS $C/_build/$b.o"
